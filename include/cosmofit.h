@@ -1,0 +1,250 @@
+/*
+ * cosmofit.h — C-ABI of the MI355X (gfx950) batched cosmological log-likelihood engine.
+ *
+ * This is the drop-in boundary for ONE hot path of franciscotln/cosmology-model-fit:
+ * the per-walker chi^2 / log-likelihood that emcee / nautilus call through
+ * `log_probability(theta)` or `log_probs_vectorized(Theta[W,ndim])`.
+ * Plain C types only (pointers + sizes); loadable with ctypes.
+ *
+ * Reference interfaces each entry point replaces (paths relative to the reference repo):
+ *   cf_create            module-level data set-up        sn/pantheon.py:10-19, bao/desi_cmb_des5y.py:14-22
+ *   cf_eval              chi_squared / log_likelihood /
+ *                        log_probability / *_vectorized  sn/pantheon.py:57-97, bao/desi.py:63-106,
+ *                                                        bao/desi_cmb.py:137-143, bao/desi_cmb_des5y.py:138-145
+ *   cf_eval_device       the same on device-resident Theta (on-device ensemble; replaces the
+ *                        emcee pool.map dispatch          sn/pantheon.py:119-125)
+ *   cf_eval_parts        DM_z / mu_theory / mu_corr accessors used by the post-fit plots
+ *                                                        sn/pantheon.py:34-54,152-155
+ *   cf_interp_hermite    interp_hermite                   interpolator.py:117-119
+ *   cf_interp_pchip      interp_pchip                     interpolator.py:111-114
+ *   cf_solve_triangular  solve_triangular (returns y.y)   solve_triangular.py:5-14
+ *
+ * Error convention: every function returns 0 on success, a negative cf_status otherwise;
+ * the message is available through cf_last_error() (thread-local). Nothing throws across
+ * the ABI. Numerical convention: theta outside the strict prior box -> -inf for CF_OUT_LOGP
+ * (sn/pantheon.py:82-83); a non-finite chi^2 for an in-box theta -> -inf (never NaN: emcee
+ * raises ValueError on NaN) and is counted in cf_info.nonfinite_count.
+ *
+ * Threading: one caller per handle at a time (the reference callers are single-threaded per
+ * process). Different handles may be used from different threads.
+ */
+#ifndef COSMOFIT_H
+#define COSMOFIT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CF_ABI_VERSION 1
+
+typedef struct cf_handle cf_handle;
+
+enum cf_status {
+  CF_OK = 0,
+  CF_ERR_INVALID = -1,   /* bad descriptor / argument */
+  CF_ERR_NO_DEVICE = -2, /* no HIP device visible */
+  CF_ERR_HIP = -3,       /* a HIP runtime call failed */
+  CF_ERR_NOT_POSDEF = -4,/* a zero / negative / non-finite pivot in L */
+  CF_ERR_UNSUPPORTED = -5
+};
+
+/* Expansion-rate family (a2-a4). */
+enum cf_ez_model {
+  /* H = H0 * sqrt(Om*(1+z)^3 + (1-Om)*f_DE(z))            sn/pantheon.py:28-31, bao/desi.py:32-35 */
+  CF_EZ_LATE_FLAT = 0,
+  /* H = H0 * sqrt(Or*zp1^4 + Obc*zp1^3 + Ode*f_DE + Onu*Omnu_z(z)), densities = omega/h^2,
+     Ode = 1-Obc-Or-Onu                                   bao/desi_cmb_des5y.py:34-54 */
+  CF_EZ_PHYSICAL = 1
+};
+
+/* Dark-energy density ratio f_DE(z) (SURVEY section 2 "f_DE(z)"). */
+enum cf_fde {
+  CF_FDE_LCDM = 0,    /* 1 */
+  CF_FDE_WCDM = 1,    /* zp1^(3(1+w0))                        sn/pantheon_and_sh0es.py:26-28 */
+  CF_FDE_THAWING = 2, /* (2 zp1^3 / (1+w0+(1-w0) zp1^3))^2    bao/desi.py:26-28 */
+  CF_FDE_CPL = 3      /* zp1^(3(1+w0+wa)) exp(-3 wa z/zp1)    bao/desi_fs_lya_cmb.py:19-22 */
+};
+
+/* Physical-parameter slots. Each slot is either read from theta[idx]*scale or fixed. */
+enum cf_param_slot {
+  CF_P_OFFSET = 0, /* M (absolute magnitude) or delta-M offset, subtracted from the SN residual */
+  CF_P_H0 = 1,     /* km/s/Mpc; use scale=100 when the sampler parameter is h */
+  CF_P_OM = 2,     /* Omega_m (CF_EZ_LATE_FLAT) */
+  CF_P_OBH2 = 3,   /* omega_b (CF_EZ_PHYSICAL) */
+  CF_P_OCH2 = 4,   /* omega_c (CF_EZ_PHYSICAL) */
+  CF_P_W0 = 5,
+  CF_P_WA = 6,
+  CF_P_V = 7,      /* peculiar-velocity step amplitude in units of 100 km/s (mu_corr) */
+  CF_P_RD = 8,     /* sound horizon in Mpc when fixed or free (BAO block) */
+  CF_P_NSLOTS = 9
+};
+
+typedef struct cf_param {
+  int32_t idx;   /* index into theta, or -1 when the slot is fixed / unused */
+  int32_t _pad;
+  double scale;  /* value = theta[idx]*scale  (scale is applied as `scale*theta`, cf. `100 * h`) */
+  double fixed;  /* value when idx < 0 */
+} cf_param;
+
+/* BAO quantity codes (bao/desi_cmb_des5y.py:69-79). */
+enum cf_bao_qty { CF_BAO_DV = 0, CF_BAO_DM = 1, CF_BAO_DH = 2, CF_BAO_FAP = 3 };
+
+enum cf_bao_dh_mode {
+  CF_BAO_DH_PCHIP = 0, /* DH interpolated from the grid with PCHIP  bao/desi_cmb_des5y.py:88 */
+  CF_BAO_DH_EXACT = 1  /* DH = c/H(z) evaluated at the datum       bao/desi_cmb.py:54-56 */
+};
+
+enum cf_rd_mode {
+  CF_RD_PARAM = 0,  /* from slot CF_P_RD (fixed constant or free parameter) */
+  CF_RD_FIT = 1     /* r_drag(omega_b, omega_m) fitting formula, coefficients in cf_desc.rd_fit */
+};
+
+enum cf_cmb_mode {
+  CF_CMB_NONE = 0,
+  CF_CMB_R_LA_WB = 1,   /* (R, l_A, omega_b) 3-vector x 3x3 inverse cov   bao/desi_cmb_des5y.py:126-129 */
+  CF_CMB_LA_ONLY = 2,   /* only the l_A component                        bao/desi_des5y_bbn_theta_star.py:110-111 */
+  CF_CMB_THETA_WB_WM = 3 /* (100 theta*, omega_b, omega_m)               cmb/data_early_lcdm_compression.py:198-207 */
+};
+
+/* Output selector for cf_eval*. */
+enum cf_out {
+  CF_OUT_CHI2 = 0, /* chi^2 */
+  CF_OUT_LOGL = 1, /* -0.5 chi^2                                  (nautilus: likelihood only) */
+  CF_OUT_LOGP = 2  /* log prior + log L, -inf outside the box     (emcee log_probability) */
+};
+
+typedef struct cf_gauss_prior {
+  int32_t idx;   /* theta index */
+  int32_t _pad;
+  double mean;
+  double sigma;  /* term: -0.5*(theta[idx]-mean)^2/sigma^2        sn/pantheon.py:85 */
+} cf_gauss_prior;
+
+/*
+ * Immutable likelihood descriptor. All arrays are host pointers, copied at cf_create and
+ * free to be released as soon as it returns.
+ */
+typedef struct cf_desc {
+  int32_t abi_version;  /* CF_ABI_VERSION */
+  int32_t struct_size;  /* sizeof(cf_desc) as seen by the caller */
+  int32_t device;       /* HIP device ordinal */
+  int32_t ndim;         /* length of one theta row */
+
+  int32_t ez_model;     /* cf_ez_model */
+  int32_t fde;          /* cf_fde */
+  int32_t n_grid;       /* G, points of the uniform z grid (4000 in every reference script) */
+  int32_t _pad0;
+  double z_max;         /* grid = linspace(0, z_max, G)            sn/pantheon.py:16 */
+  double c_km_s;        /* speed of light in km/s                  sn/pantheon.py:12 */
+
+  cf_param param[CF_P_NSLOTS];
+
+  /* ---- SN block (may be absent: n_sn = 0) ---- */
+  int64_t n_sn;
+  const double* sn_z_cmb;   /* [n_sn] */
+  const double* sn_z_hel;   /* [n_sn] */
+  const double* sn_obs;     /* [n_sn] m_b or mu */
+  const double* sn_step;    /* [n_sn] per-SN sign/weight s_i multiplying 100*v/c in z_cosmo; NULL -> use z_turn */
+  double sn_z_turn;         /* s_i = +1 if z_cmb <= z_turn else -1     sn/pantheon.py:46 */
+  const double* sn_chol;    /* [n_sn*ld] row-major lower Cholesky factor; ONLY L[i][j<=i] is read
+                               (cho_factor leaves garbage above the diagonal, sn/pantheon.py:14) */
+  int64_t sn_chol_ld;       /* row stride of sn_chol in elements (>= n_sn) */
+
+  /* ---- BAO block (n_bao = 0 -> absent) ---- */
+  int32_t n_bao;
+  int32_t bao_dh_mode;      /* cf_bao_dh_mode */
+  int32_t rd_mode;          /* cf_rd_mode */
+  int32_t _pad1;
+  const double* bao_z;      /* [n_bao] */
+  const double* bao_val;    /* [n_bao] */
+  const int32_t* bao_qty;   /* [n_bao] cf_bao_qty */
+  const double* bao_inv_cov;/* [n_bao*n_bao] row-major explicit inverse */
+  double rd_fit[11];        /* r_drag coefficients b, m, a1..a9     cmb/data_planck_act_compression.py:102-124 */
+
+  /* ---- compressed-CMB block ---- */
+  int32_t cmb_mode;         /* cf_cmb_mode */
+  int32_t n_gl;             /* Gauss-Legendre nodes (100) */
+  const double* gl_x;       /* [n_gl] nodes on [-1,1]   (np.polynomial.legendre.leggauss) */
+  const double* gl_w;       /* [n_gl] weights */
+  double cmb_prior[3];
+  double cmb_inv_cov[9];
+  double zstar_fit[11];     /* z_star coefficients s1,s2,b,m + 7 numeric constants  cmb/...:86-99 */
+  double o_gamma_h2;        /* photon density for R_b                 cmb/...:29 */
+
+  /* ---- radiation + massive neutrino constants (CF_EZ_PHYSICAL) ---- */
+  double or_h2;             /* cmb.Or_h2 */
+  double omnu_h2;           /* cmb.Omnu_h2 */
+  double nu_m0;             /* m0 */
+  double nu_rho0;           /* rho0 */
+  double nu_qs_sq[5];       /* qs**2 */
+  double nu_ws[5];          /* weights */
+
+  /* ---- priors (CF_OUT_LOGP only) ---- */
+  const double* bounds;     /* [ndim*2] (lo,hi) strict box; NULL -> no box */
+  int32_t n_gauss;
+  int32_t cpl_wall;         /* 1: w0+wa >= 0 -> -1e8             bao/desi_fs_lya_cmb.py:118-121 */
+  const cf_gauss_prior* gauss; /* [n_gauss] Gaussian terms added to the log-prior */
+  /* Gaussian terms added to chi^2 itself (e.g. BBN omega_b, bao/desi_des5y_bbn_theta_star.py:139) */
+  int32_t n_chi2_gauss;
+  int32_t _pad2;
+  const cf_gauss_prior* chi2_gauss;
+} cf_desc;
+
+typedef struct cf_info {
+  int64_t n_sn;
+  int64_t n_sn_pad;        /* rows after padding to the 16-row MFMA tile */
+  int64_t packed_chol_bytes;
+  int64_t workspace_bytes; /* current device workspace (grows with W) */
+  int64_t max_walkers;     /* walkers the current workspace holds */
+  int64_t nonfinite_count; /* in-box evaluations whose chi^2 was not finite since create */
+  int32_t device;
+  int32_t cu_count;
+  char gcn_arch[64];
+} cf_info;
+
+int cf_device_count(void);
+const char* cf_last_error(void);
+int cf_abi_version(void);
+
+int cf_create(const cf_desc* desc, cf_handle** out);
+void cf_destroy(cf_handle* h);
+int cf_get_info(cf_handle* h, cf_info* info);
+
+/* Host buffers. theta: [W*ndim] C-order float64; out: [W] float64. Synchronous. */
+int cf_eval(cf_handle* h, const double* theta, int64_t W, double* out, int32_t out_kind);
+
+/* Device buffers on the handle's device; asynchronous on `hip_stream` (a hipStream_t, NULL =
+ * the handle's own stream). Grows the workspace if needed (then it synchronises once). */
+int cf_eval_device(cf_handle* h, const double* d_theta, int64_t W, double* d_out,
+                   int32_t out_kind, void* hip_stream);
+
+/* Intermediates for plots/tests. Any output pointer may be NULL. Host buffers.
+ *   dm_obs [W*n_sn]  DM(z_cmb)           sn/pantheon.py:58
+ *   mu_corr[W*n_sn]                      sn/pantheon.py:43-49
+ *   delta  [W*n_sn]  residual vector     sn/pantheon.py:59-60
+ *   chi2_blocks[W*3] (sn, bao, cmb)      bao/desi_cmb_des5y.py:138-141
+ *   bao_theory[W*n_bao]                  bao/desi_cmb_des5y.py:82-100 */
+int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, double* dm_obs, double* mu_corr,
+                  double* delta, double* chi2_blocks, double* bao_theory);
+
+/* Time (ms, HIP events on the launch stream) of the kernels of the last evaluation call:
+ * t[0] = distance+residual kernel, t[1] = triangular solve + chi^2 kernel. Waits for them. */
+int cf_last_kernel_ms(cf_handle* h, float t[2]);
+
+/* ---- stand-alone operators with the reference's signatures (host buffers) ---- */
+/* out[k] = Hermite(xq[k]; x, y, y_prime), linear extrapolation outside   interpolator.py:117-119 */
+int cf_interp_hermite(const double* xq, int64_t nq, const double* x, const double* y,
+                      const double* y_prime, int64_t n, double* out);
+/* out[k] = PCHIP(xq[k]; x, y), clamped outside                             interpolator.py:111-114 */
+int cf_interp_pchip(const double* xq, int64_t nq, const double* x, const double* y, int64_t n,
+                    double* out);
+/* out[w] = || L^-1 b_w ||^2 for nrhs right-hand sides b[nrhs*n] (row w = b_w)  solve_triangular.py:5-14 */
+int cf_solve_triangular(const double* L, int64_t n, int64_t ld, const double* b, int64_t nrhs,
+                        double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COSMOFIT_H */
