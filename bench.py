@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""
+bench.py — walker-logL evals/s on Pantheon+-shaped full-covariance chi^2 (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--walkers-per-gpu 4096] [--n-sn 1701]
+
+N > 1 is launched by the driver as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+one process per GPU (RCCL).  A "step" is one pass of the hot path over the ensemble: every rank
+evaluates log P for the walkers it owns (weak scaling: --walkers-per-gpu each) with theta already
+resident in HBM; for N > 1 the step first all-gathers the walker positions (the exchange an
+ensemble move needs to pick partners from the complementary set).  Rank 0 prints ONE JSON line.
+
+Workload at N=1 = BASELINE.json configs[1]: Pantheon+ 1701-SN full-cov flat-LambdaCDM, 4096 walkers.
+Data are synthetic (the real covariance is not in the reference snapshot): see
+cosmology-model-fit_amd/synthetic.py.  All arithmetic float64.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix (= vector) peak, AMD datasheet; see DESIGN.md
+
+
+def flops_per_eval_solve(n):
+    """Algorithmic FP64 flops of the chi^2 phase per walker: TRSV n(n-1) + n divisions + 2n norm."""
+    return n * (n - 1) + 3 * n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--walkers-per-gpu", type=int, default=4096)
+    ap.add_argument("--n-sn", type=int, default=1701)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (rank 0, N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no HIP device visible); there is no CPU path to time instead")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    pkg = importlib.import_module("cosmology-model-fit_amd")
+    sn = pkg.sn_pantheon
+    Wl = args.walkers_per_gpu
+    W_total = Wl * world
+
+    syn = pkg.synthetic.pantheon_like(n_sn=args.n_sn, seed=0)
+    lk = sn.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"], device=local_rank)
+    eng = lk.engine
+
+    theta_all_host = pkg.synthetic.walkers(sn.bounds, W_total, seed=0)
+    mine = slice(rank * Wl, (rank + 1) * Wl)
+    theta_local = torch.from_numpy(theta_all_host[mine].copy()).to(dev)
+    theta_all = torch.empty((W_total, 4), dtype=torch.float64, device=dev)
+    logp = torch.empty(Wl, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        if world > 1:
+            # exchange step of an ensemble move: every rank needs the complementary walkers' positions
+            dist.all_gather_into_tensor(theta_all, theta_local)
+        eng.eval_device(theta_local.data_ptr(), Wl, logp.data_ptr(), pkg.CF_OUT_LOGP, stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.enable_timing(min(args.steps, 4096))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    kms = eng.kernel_ms()
+    eng.enable_timing(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        got = theta_all.cpu().numpy()
+        assert np.array_equal(got, theta_all_host), "all-gather of walker positions is wrong"
+
+    result = logp.cpu().numpy()
+    assert np.all(np.isfinite(result)), "in-box walkers must give a finite log-probability"
+
+    if rank == 0:
+        resid_ms = float(np.mean([a for a, _ in kms]))
+        solve_ms = float(np.mean([b for _, b in kms]))
+        solve_flops = flops_per_eval_solve(args.n_sn) * Wl
+        achieved = solve_flops / (solve_ms * 1e-3) / 1e12
+        out = {
+            "metric": "walker-logL evals/s, Pantheon+ 1701-SN full-cov chi2",
+            "value": W_total * args.steps / dt,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"Pantheon+-shaped {args.n_sn}-SN full-cov flat-LCDM chi2 + prior, "
+                            f"{Wl} walkers per GPU per step (BASELINE configs[1] at N=1), G=4000, theta resident in HBM",
+                "walkers_per_gpu": Wl, "walkers_total": W_total, "n_sn": args.n_sn, "n_grid": 4000, "ndim": 4,
+                "parallelism": f"walkers sharded over {world} GPU(s)" + (", RCCL all-gather of positions per step" if world > 1 else ""),
+            },
+            "roofline": {
+                "kernel": "trsm_chi2_kernel",
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": FP64_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                "traffic": None,
+                "flops_per_launch": solve_flops,
+                "avg_kernel_ms": solve_ms,
+            },
+            "kernels_ms": {"sn_residual_kernel": resid_ms, "trsm_chi2_kernel": solve_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, syn, lk, theta_all_host, result, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pkg, syn, lk, theta, gpu_logp, budget_s):
+    """The C restatement of the reference algorithm (oracle/, kind 'port') timed on this host's cores on a
+    bounded sample of the same walkers; also reports the GPU-vs-CPU parity on that sample."""
+    from oracle import oracle_c, oracle_np as onp
+
+    sn = pkg.sn_pantheon
+    co = oracle_c.COracle(onp.Likelihood(
+        ndim=4, z_max=lk.z_max, offset=onp.Slot(0), H0=onp.Slot(1), Om=onp.Slot(2), v=onp.Slot(3),
+        z_cmb=syn["z_cmb"], z_hel=syn["z_hel"], obs=syn["obs"], chol=syn["chol"],
+        bounds=sn.bounds, gauss=[sn.H0_PRIOR]))
+    nthreads = min(oracle_c.max_threads(), len(os.sched_getaffinity(0)))
+    probe = min(4 * nthreads, len(theta))
+    t0 = time.perf_counter()
+    co.logp(theta[:probe], nthreads=nthreads)
+    rate = probe / (time.perf_counter() - t0)
+    n = int(max(probe, min(len(theta), rate * budget_s)))
+    t0 = time.perf_counter()
+    ref = co.logp(theta[:n], nthreads=nthreads)
+    dt = time.perf_counter() - t0
+    cores = co.threads_used
+    rel = float(np.max(np.abs(gpu_logp[:n] - ref) / np.abs(ref)))
+    # single-thread rate on a smaller sample
+    n1 = max(8, min(n, int(rate / nthreads * min(budget_s, 5.0))))
+    t0 = time.perf_counter()
+    co.logp(theta[:n1], nthreads=1)
+    dt1 = time.perf_counter() - t0
+    return {
+        "value": n / dt, "unit": "evals/s", "cores": cores, "kind": "port",
+        "sample": f"first {n} of the {len(theta)} walkers of the timed step, C restatement (oracle/cosmofit_oracle.c, "
+                  f"-O2, OpenMP over walkers); single-thread: {n1 / dt1:.1f} evals/s on {n1} walkers",
+        "single_thread_value": n1 / dt1,
+        "parity_max_rel_logp": rel,
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,15 @@
+"""
+cosmology-model-fit_amd — MI355X (gfx950) batched log-likelihood engine for the emcee / nautilus
+hot path of franciscotln/cosmology-model-fit.  See DESIGN.md / INTEGRATION.md at the repo root.
+
+The directory name contains a hyphen; import it with
+``importlib.import_module("cosmology-model-fit_amd")``.
+"""
+from . import _lib
+from ._lib import CosmofitError, build, lib
+from ._lib import (CF_FDE_CPL, CF_FDE_LCDM, CF_FDE_THAWING, CF_FDE_WCDM, CF_OUT_CHI2, CF_OUT_LOGL, CF_OUT_LOGP)
+from .engine import C_KM_S, LikelihoodEngine, Param
+from . import interpolator, solve_triangular, sn_pantheon, synthetic
+
+__all__ = ["LikelihoodEngine", "Param", "CosmofitError", "build", "lib", "interpolator", "solve_triangular",
+           "sn_pantheon", "C_KM_S"]

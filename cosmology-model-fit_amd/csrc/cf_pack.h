@@ -1,0 +1,153 @@
+// cf_pack.h — host-side packing of the lower Cholesky factor into the fragment streams that
+// trsm_chi2_kernel consumes (layout documented above that kernel and in DESIGN.md).
+//
+// Reference semantics kept: only L[i][j<=i] is read (cho_factor(..., lower=True)[0] leaves
+// garbage above the diagonal: sn/pantheon.py:14, solve_triangular.py:13).
+#ifndef CF_PACK_H
+#define CF_PACK_H
+
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "cosmofit_device.h"
+
+struct cf_host_pack {
+  int64_t n = 0, n_pad = 0;
+  int32_t n_blocks = 0;
+  std::vector<cf_d2> frags;        // 64 lane elements (1 KiB) per fragment
+  std::vector<int64_t> upd_off;    // [n_blocks*4] in fragments
+  std::vector<int64_t> diag_off;   // [n_blocks*4]
+};
+
+static inline int cf_tiles_in_block(int64_t T, int b) {
+  int64_t left = T - (int64_t)b * CF_BLOCK_TILES;
+  return (int)(left < CF_BLOCK_TILES ? left : CF_BLOCK_TILES);
+}
+static inline int cf_slots_of_wave(int tiles_b, int w) { return tiles_b > w ? (tiles_b - w + 3) / 4 : 0; }
+
+// Returns 0, or -1 when a pivot is not finite-positive.
+static int cf_pack_cholesky(const double* L, int64_t n, int64_t ld, cf_host_pack& out) {
+  const int64_t n_pad = (n + 15) / 16 * 16;
+  const int64_t T = n_pad / 16;
+  const int n_blocks = (int)((T + CF_BLOCK_TILES - 1) / CF_BLOCK_TILES);
+  out.n = n;
+  out.n_pad = n_pad;
+  out.n_blocks = n_blocks;
+  out.upd_off.assign((size_t)n_blocks * 4, 0);
+  out.diag_off.assign((size_t)n_blocks * 4, 0);
+  for (int64_t i = 0; i < n; ++i) {
+    double p = L[i * ld + i];
+    if (!(p > 0.0) || !std::isfinite(p)) return -1;
+  }
+  // padded element accessor: identity on the padding rows, zero above the diagonal
+  auto Lp = [&](int64_t i, int64_t j) -> double {
+    if (j > i) return 0.0;
+    if (i >= n) return i == j ? 1.0 : 0.0;
+    return L[i * ld + j];
+  };
+  // size pass
+  int64_t total = 0;
+  for (int b = 0; b < n_blocks; ++b) {
+    const int tiles_b = cf_tiles_in_block(T, b);
+    for (int w = 0; w < 4; ++w) {
+      const int nt = cf_slots_of_wave(tiles_b, w);
+      out.upd_off[b * 4 + w] = total;
+      total += (int64_t)32 * b * nt;
+      out.diag_off[b * 4 + w] = total;
+      if (nt > 0) total += (int64_t)(2 * (w + 4 * (nt - 1)) + 2) * nt;
+    }
+  }
+  out.frags.assign((size_t)total * 64, cf_d2{0.0, 0.0});
+
+  std::vector<long double> inv;  // inverse of the current diagonal block, row-major nb x nb
+  for (int b = 0; b < n_blocks; ++b) {
+    const int tiles_b = cf_tiles_in_block(T, b);
+    const int nb = tiles_b * 16;
+    const int64_t r0 = (int64_t)b * CF_BLOCK_ROWS;
+    // inverse of the lower-triangular diagonal block by column-wise forward substitution, in
+    // extended precision so that the stored double is the correctly rounded inverse entry
+    inv.assign((size_t)nb * nb, 0.0L);
+    for (int j = 0; j < nb; ++j) {
+      inv[(size_t)j * nb + j] = 1.0L / (long double)Lp(r0 + j, r0 + j);
+      for (int i = j + 1; i < nb; ++i) {
+        long double s = 0.0L;
+        for (int k = j; k < i; ++k) s += (long double)Lp(r0 + i, r0 + k) * inv[(size_t)k * nb + j];
+        inv[(size_t)i * nb + j] = -s / (long double)Lp(r0 + i, r0 + i);
+      }
+    }
+    for (int w = 0; w < 4; ++w) {
+      const int nt = cf_slots_of_wave(tiles_b, w);
+      if (nt == 0) continue;
+      cf_d2* up = out.frags.data() + out.upd_off[b * 4 + w] * 64;
+      for (int64_t s2 = 0; s2 < (int64_t)32 * b; ++s2)
+        for (int j = 0; j < nt; ++j)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int64_t row = r0 + 16 * (w + 4 * j) + (lane & 15);
+            const int64_t c0 = 8 * s2 + (lane >> 4);
+            cf_d2& f = up[(s2 * nt + j) * 64 + lane];
+            f.x = -Lp(row, c0);
+            f.y = -Lp(row, c0 + 4);
+          }
+      cf_d2* dg = out.frags.data() + out.diag_off[b * 4 + w] * 64;
+      const int ml_max = w + 4 * (nt - 1);
+      for (int sl2 = 0; sl2 <= 2 * ml_max + 1; ++sl2)
+        for (int j = 0; j < nt; ++j)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int rl = 16 * (w + 4 * j) + (lane & 15);
+            const int c0 = 8 * sl2 + (lane >> 4);
+            cf_d2& f = dg[((int64_t)sl2 * nt + j) * 64 + lane];
+            f.x = (c0 <= rl) ? (double)inv[(size_t)rl * nb + c0] : 0.0;
+            f.y = (c0 + 4 <= rl) ? (double)inv[(size_t)rl * nb + c0 + 4] : 0.0;
+          }
+    }
+  }
+  return 0;
+}
+
+// Replays the fragment streams for ONE right-hand side on the host, with the kernel's block
+// structure (update through -L fragments, diagonal through the inverse fragments).  Used only by
+// the CPU test-suite to validate the packing logic without a GPU; cf_eval never calls it.
+static double cf_pack_replay_host(const cf_host_pack& pk, const double* b_in) {
+  const int64_t n_pad = pk.n_pad, T = n_pad / 16;
+  std::vector<double> y((size_t)n_pad, 0.0), rhs(CF_BLOCK_ROWS);
+  double chi = 0.0;
+  for (int b = 0; b < pk.n_blocks; ++b) {
+    const int tiles_b = cf_tiles_in_block(T, b);
+    const int64_t r0 = (int64_t)b * CF_BLOCK_ROWS;
+    for (int i = 0; i < tiles_b * 16; ++i) rhs[i] = (r0 + i < pk.n) ? b_in[r0 + i] : 0.0;
+    for (int w = 0; w < 4; ++w) {
+      const int nt = cf_slots_of_wave(tiles_b, w);
+      const cf_d2* up = pk.frags.data() + pk.upd_off[b * 4 + w] * 64;
+      for (int64_t s2 = 0; s2 < (int64_t)32 * b; ++s2)
+        for (int j = 0; j < nt; ++j)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int rl = 16 * (w + 4 * j) + (lane & 15);
+            const int64_t c0 = 8 * s2 + (lane >> 4);
+            const cf_d2& f = up[(s2 * nt + j) * 64 + lane];
+            rhs[rl] += f.x * y[c0] + f.y * y[c0 + 4];
+          }
+    }
+    for (int w = 0; w < 4; ++w) {
+      const int nt = cf_slots_of_wave(tiles_b, w);
+      if (nt == 0) continue;
+      const cf_d2* dg = pk.frags.data() + pk.diag_off[b * 4 + w] * 64;
+      const int ml_max = w + 4 * (nt - 1);
+      for (int j = 0; j < nt; ++j)
+        for (int li = 0; li < 16; ++li) {
+          const int rl = 16 * (w + 4 * j) + li;
+          double s = 0.0;
+          for (int sl2 = 0; sl2 <= 2 * ml_max + 1 && sl2 <= 2 * (w + 4 * j) + 1; ++sl2)
+            for (int kq = 0; kq < 4; ++kq) {
+              const cf_d2& f = dg[((int64_t)sl2 * nt + j) * 64 + kq * 16 + li];
+              s += f.x * rhs[8 * sl2 + kq] + f.y * rhs[8 * sl2 + 4 + kq];
+            }
+          y[r0 + rl] = s;
+        }
+    }
+    for (int i = 0; i < tiles_b * 16; ++i) chi += y[r0 + i] * y[r0 + i];
+  }
+  return chi;
+}
+
+#endif

@@ -1,0 +1,489 @@
+// cosmofit_api.hip — host side of the C-ABI declared in include/cosmofit.h.
+//
+// Owns device memory (data vectors, packed factor, per-call workspace), one HIP stream per
+// handle, and the launches of the kernels in cosmofit_kernels.hip.  There is NO CPU evaluation
+// path here: without a HIP device every entry point returns CF_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/cosmofit.h"
+#include "cf_pack.h"
+#include "cosmofit_device.h"
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+extern "C" __global__ void sn_residual_kernel(cf_dev_desc d, const double* theta, int64_t W, double* delta,
+                                              double* dm_out, double* mucorr_out);
+extern "C" __global__ void trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* theta, int64_t W,
+                                            const double* delta, d2* ypk, const double* chi2_extra, double* out,
+                                            int out_kind, unsigned long long* nonfinite);
+extern "C" __global__ void finalize_kernel(cf_dev_desc d, const double* theta, int64_t W, const double* chi2_extra,
+                                           double* out, int out_kind, unsigned long long* nonfinite);
+extern "C" __global__ void interp_kernel(const double* xq, int64_t nq, const double* x, const double* y,
+                                         const double* yp, int64_t n, double* out, int mode);
+extern "C" __global__ void pad_rhs_kernel(const double* b, int64_t nrhs, int64_t n, int64_t n_pad, double* delta);
+
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(CF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int ensure(size_t need) {
+    if (need <= bytes) return 0;
+    if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+    HIP_TRY(hipMalloc(&p, need));
+    bytes = need;
+    return 0;
+  }
+  template <class T> T* as() const { return (T*)p; }
+};
+
+struct PackedFactor {
+  DevBuf frags, upd_off, diag_off;
+  cf_dev_pack dev{};
+  int64_t n = 0, n_pad = 0, bytes = 0;
+  int upload(const cf_host_pack& hp) {
+    n = hp.n;
+    n_pad = hp.n_pad;
+    bytes = (int64_t)(hp.frags.size() * sizeof(cf_d2));
+    if (frags.ensure(hp.frags.size() * sizeof(cf_d2) + 16)) return CF_ERR_HIP;
+    if (upd_off.ensure(hp.upd_off.size() * 8)) return CF_ERR_HIP;
+    if (diag_off.ensure(hp.diag_off.size() * 8)) return CF_ERR_HIP;
+    HIP_TRY(hipMemcpy(frags.p, hp.frags.data(), hp.frags.size() * sizeof(cf_d2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(upd_off.p, hp.upd_off.data(), hp.upd_off.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(diag_off.p, hp.diag_off.data(), hp.diag_off.size() * 8, hipMemcpyHostToDevice));
+    dev.frags = frags.as<const cf_d2>();
+    dev.upd_off = upd_off.as<const int64_t>();
+    dev.diag_off = diag_off.as<const int64_t>();
+    dev.n_blocks = hp.n_blocks;
+    return 0;
+  }
+};
+
+struct cf_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // timing ring: 3 events per evaluation (before A, between A and B, after B)
+  std::vector<hipEvent_t> ev;
+  int timing_slots = 0;
+  int64_t timed_calls = 0;
+  cf_dev_desc d{};
+  PackedFactor pack;
+  DevBuf z_cmb, z_hel, obs, sn_step;
+  DevBuf theta, out, delta, ypk, nonfinite;
+  int64_t max_walkers = 0;
+  int cu_count = 0;
+  char arch[64] = {0};
+  std::mutex mu;
+};
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int cf_abi_version(void) { return CF_ABI_VERSION; }
+extern "C" const char* cf_last_error(void) { return g_err.c_str(); }
+
+extern "C" int cf_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+static int upload_vec(DevBuf& b, const double* src, int64_t n) {
+  if (b.ensure((size_t)n * 8)) return CF_ERR_HIP;
+  HIP_TRY(hipMemcpy(b.p, src, (size_t)n * 8, hipMemcpyHostToDevice));
+  return 0;
+}
+
+static int ensure_workspace(cf_handle* h, int64_t W) {
+  const int64_t w_pad = (W + 15) / 16 * 16;
+  if (w_pad <= h->max_walkers) return 0;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const int64_t n_pad = h->d.n_pad > 0 ? h->d.n_pad : 16;
+  if (h->theta.ensure((size_t)w_pad * (h->d.ndim > 0 ? h->d.ndim : 1) * 8)) return CF_ERR_HIP;
+  if (h->out.ensure((size_t)w_pad * 8)) return CF_ERR_HIP;
+  if (h->d.n_sn > 0) {
+    if (h->delta.ensure((size_t)w_pad * n_pad * 8)) return CF_ERR_HIP;
+    if (h->ypk.ensure((size_t)w_pad * n_pad * 8)) return CF_ERR_HIP;
+    // columns of a partly filled last panel must hold finite numbers
+    HIP_TRY(hipMemsetAsync(h->delta.p, 0, (size_t)w_pad * n_pad * 8, h->stream));
+    HIP_TRY(hipMemsetAsync(h->ypk.p, 0, (size_t)w_pad * n_pad * 8, h->stream));
+  }
+  h->max_walkers = w_pad;
+  return 0;
+}
+
+extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
+  if (!c || !out) return fail(CF_ERR_INVALID, "cf_create: null argument");
+  *out = nullptr;
+  if (c->abi_version != CF_ABI_VERSION || c->struct_size != (int32_t)sizeof(cf_desc))
+    return fail(CF_ERR_INVALID, "cf_create: descriptor ABI version / size mismatch (got version " +
+                                    std::to_string(c->abi_version) + ", size " + std::to_string(c->struct_size) +
+                                    ", expected " + std::to_string(CF_ABI_VERSION) + ", " +
+                                    std::to_string(sizeof(cf_desc)) + ")");
+  if (c->ndim < 1 || c->ndim > CF_MAX_NDIM) return fail(CF_ERR_INVALID, "cf_create: ndim must be in 1..16");
+  if (c->n_grid < 4 || (size_t)c->n_grid * 16 + 64 > 160 * 1024)
+    return fail(CF_ERR_INVALID, "cf_create: n_grid must be in 4..10236 (two float64 tables must fit the 160 KB LDS)");
+  if (!(c->z_max > 0.0) || !std::isfinite(c->z_max)) return fail(CF_ERR_INVALID, "cf_create: z_max must be > 0");
+  if (!(c->c_km_s > 0.0)) return fail(CF_ERR_INVALID, "cf_create: c_km_s must be > 0");
+  if (c->ez_model != CF_EZ_LATE_FLAT) return fail(CF_ERR_UNSUPPORTED, "cf_create: only CF_EZ_LATE_FLAT is built so far");
+  if (c->fde < CF_FDE_LCDM || c->fde > CF_FDE_CPL) return fail(CF_ERR_INVALID, "cf_create: bad fde");
+  if (c->n_bao != 0 || c->cmb_mode != CF_CMB_NONE)
+    return fail(CF_ERR_UNSUPPORTED, "cf_create: BAO / CMB blocks are not built yet");
+  if (c->n_gauss > CF_MAX_GAUSS || c->n_chi2_gauss > CF_MAX_GAUSS || c->n_gauss < 0 || c->n_chi2_gauss < 0)
+    return fail(CF_ERR_INVALID, "cf_create: at most 8 Gaussian terms of each kind");
+  for (int s = 0; s < CF_P_NSLOTS; ++s)
+    if (c->param[s].idx >= c->ndim) return fail(CF_ERR_INVALID, "cf_create: parameter slot index >= ndim");
+  if (c->n_sn < 0 || c->n_sn > (1 << 20)) return fail(CF_ERR_INVALID, "cf_create: bad n_sn");
+  if (c->n_sn > 0) {
+    if (!c->sn_z_cmb || !c->sn_z_hel || !c->sn_obs || !c->sn_chol)
+      return fail(CF_ERR_INVALID, "cf_create: SN block arrays must not be null");
+    if (c->sn_chol_ld < c->n_sn) return fail(CF_ERR_INVALID, "cf_create: sn_chol_ld < n_sn");
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(CF_ERR_NO_DEVICE, "cf_create: no HIP device visible (this library has no CPU path)");
+  if (c->device < 0 || c->device >= ndev) return fail(CF_ERR_INVALID, "cf_create: device ordinal out of range");
+
+  cf_handle* h = new cf_handle();
+  auto bail = [&](int code) { cf_destroy(h); return code; };
+  h->device = c->device;
+  if (hipSetDevice(h->device) != hipSuccess) return bail(fail(CF_ERR_HIP, "hipSetDevice failed"));
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) {
+    h->cu_count = prop.multiProcessorCount;
+    snprintf(h->arch, sizeof(h->arch), "%s", prop.gcnArchName);
+  }
+  if (strncmp(h->arch, "gfx950", 6) != 0)
+    return bail(fail(CF_ERR_UNSUPPORTED, std::string("cf_create: device is ") + h->arch + ", this library is built for gfx950 only"));
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(fail(CF_ERR_HIP, "hipStreamCreate failed"));
+
+  cf_dev_desc& d = h->d;
+  d.ndim = c->ndim;
+  d.n_grid = c->n_grid;
+  d.ez_model = c->ez_model;
+  d.fde = c->fde;
+  d.z_max = c->z_max;
+  d.step = c->z_max / (double)(c->n_grid - 1);  // np.linspace step
+  d.c = c->c_km_s;
+  for (int s = 0; s < CF_P_NSLOTS; ++s) {
+    d.slot[s].idx = c->param[s].idx;
+    d.slot[s].scale = c->param[s].scale;
+    d.slot[s].fixed = c->param[s].fixed;
+  }
+  d.n_sn = (int32_t)c->n_sn;
+  d.n_pad = (int32_t)((c->n_sn + 15) / 16 * 16);
+  d.cpl_wall = c->cpl_wall;
+  d.has_bounds = c->bounds != nullptr;
+  d.log_norm = 0.0;
+  if (c->bounds) {
+    double s = 0.0;
+    for (int k = 0; k < c->ndim; ++k) {
+      d.lo[k] = c->bounds[2 * k];
+      d.hi[k] = c->bounds[2 * k + 1];
+      if (!(d.hi[k] > d.lo[k])) return bail(fail(CF_ERR_INVALID, "cf_create: bounds must satisfy lo < hi"));
+      s += std::log(d.hi[k] - d.lo[k]);  // normalization = -sum(log(hi-lo)), sn/pantheon.py:77
+    }
+    d.log_norm = -s;
+  }
+  d.n_gauss = c->n_gauss;
+  for (int g = 0; g < c->n_gauss; ++g) {
+    if (c->gauss[g].idx < 0 || c->gauss[g].idx >= c->ndim) return bail(fail(CF_ERR_INVALID, "cf_create: gauss idx"));
+    d.gauss_idx[g] = c->gauss[g].idx;
+    d.gauss_mean[g] = c->gauss[g].mean;
+    d.gauss_sigma[g] = c->gauss[g].sigma;
+  }
+  d.n_chi2_gauss = c->n_chi2_gauss;
+  for (int g = 0; g < c->n_chi2_gauss; ++g) {
+    if (c->chi2_gauss[g].idx < 0 || c->chi2_gauss[g].idx >= c->ndim)
+      return bail(fail(CF_ERR_INVALID, "cf_create: chi2_gauss idx"));
+    d.chi2_gauss_idx[g] = c->chi2_gauss[g].idx;
+    d.chi2_gauss_mean[g] = c->chi2_gauss[g].mean;
+    d.chi2_gauss_sigma[g] = c->chi2_gauss[g].sigma;
+  }
+
+  if (c->n_sn > 0) {
+    std::vector<double> step((size_t)c->n_sn);
+    for (int64_t i = 0; i < c->n_sn; ++i)
+      step[i] = c->sn_step ? c->sn_step[i] : (c->sn_z_cmb[i] <= c->sn_z_turn ? 1.0 : -1.0);  // sn/pantheon.py:46
+    int rc;
+    if ((rc = upload_vec(h->z_cmb, c->sn_z_cmb, c->n_sn))) return bail(rc);
+    if ((rc = upload_vec(h->z_hel, c->sn_z_hel, c->n_sn))) return bail(rc);
+    if ((rc = upload_vec(h->obs, c->sn_obs, c->n_sn))) return bail(rc);
+    if ((rc = upload_vec(h->sn_step, step.data(), c->n_sn))) return bail(rc);
+    d.z_cmb = h->z_cmb.as<const double>();
+    d.z_hel = h->z_hel.as<const double>();
+    d.obs = h->obs.as<const double>();
+    d.sn_step = h->sn_step.as<const double>();
+    cf_host_pack hp;
+    if (cf_pack_cholesky(c->sn_chol, c->n_sn, c->sn_chol_ld, hp) != 0)
+      return bail(fail(CF_ERR_NOT_POSDEF, "cf_create: the Cholesky factor has a non-positive or non-finite pivot"));
+    if ((rc = h->pack.upload(hp))) return bail(rc);
+  }
+  if (h->nonfinite.ensure(8)) return bail(CF_ERR_HIP);
+  if (hipMemset(h->nonfinite.p, 0, 8) != hipSuccess) return bail(fail(CF_ERR_HIP, "hipMemset failed"));
+  *out = h;
+  return CF_OK;
+}
+
+extern "C" void cf_destroy(cf_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (auto& e : h->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+extern "C" int cf_get_info(cf_handle* h, cf_info* info) {
+  if (!h || !info) return fail(CF_ERR_INVALID, "cf_get_info: null argument");
+  std::lock_guard<std::mutex> lk(h->mu);
+  memset(info, 0, sizeof(*info));
+  info->n_sn = h->d.n_sn;
+  info->n_sn_pad = h->d.n_pad;
+  info->packed_chol_bytes = h->pack.bytes;
+  info->workspace_bytes = (int64_t)(h->theta.bytes + h->out.bytes + h->delta.bytes + h->ypk.bytes);
+  info->max_walkers = h->max_walkers;
+  info->device = h->device;
+  info->cu_count = h->cu_count;
+  snprintf(info->gcn_arch, sizeof(info->gcn_arch), "%s", h->arch);
+  unsigned long long nf = 0;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(&nf, h->nonfinite.p, 8, hipMemcpyDeviceToHost));
+  info->nonfinite_count = (int64_t)nf;
+  return CF_OK;
+}
+
+extern "C" int cf_enable_timing(cf_handle* h, int slots) {
+  if (!h) return fail(CF_ERR_INVALID, "cf_enable_timing: null handle");
+  if (slots < 0 || slots > 4096) return fail(CF_ERR_INVALID, "cf_enable_timing: slots must be in 0..4096");
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIP_TRY(hipSetDevice(h->device));
+  while ((int)h->ev.size() < 3 * slots) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    h->ev.push_back(e);
+  }
+  h->timing_slots = slots;
+  h->timed_calls = 0;
+  return CF_OK;
+}
+
+extern "C" int64_t cf_timed_calls(cf_handle* h) { return h ? h->timed_calls : 0; }
+
+extern "C" int cf_kernel_ms(cf_handle* h, int64_t call, float t[2]) {
+  if (!h || !t) return fail(CF_ERR_INVALID, "cf_kernel_ms: null argument");
+  if (h->timing_slots == 0 || call < 0 || call >= h->timed_calls || call < h->timed_calls - h->timing_slots)
+    return fail(CF_ERR_INVALID, "cf_kernel_ms: that call is not in the timing ring");
+  hipEvent_t* e = &h->ev[3 * (call % h->timing_slots)];
+  HIP_TRY(hipEventSynchronize(e[2]));
+  HIP_TRY(hipEventElapsedTime(&t[0], e[0], e[1]));
+  HIP_TRY(hipEventElapsedTime(&t[1], e[1], e[2]));
+  return CF_OK;
+}
+
+extern "C" int cf_last_kernel_ms(cf_handle* h, float t[2]) {
+  if (!h || !t) return fail(CF_ERR_INVALID, "cf_last_kernel_ms: null argument");
+  if (h->timed_calls == 0) return fail(CF_ERR_INVALID, "cf_last_kernel_ms: call cf_enable_timing(h, slots>0) before evaluating");
+  return cf_kernel_ms(h, h->timed_calls - 1, t);
+}
+
+// Launch the path on `st`: residual kernel, then solve + chi^2 (+ epilogue).
+static int launch_path(cf_handle* h, const double* d_theta, int64_t W, double* d_out, int out_kind, hipStream_t st,
+                       double* dm_out, double* mucorr_out) {
+  const cf_dev_desc& d = h->d;
+  unsigned long long* nf = h->nonfinite.as<unsigned long long>();
+  hipEvent_t* ev = h->timing_slots ? &h->ev[3 * (h->timed_calls % h->timing_slots)] : nullptr;
+  if (ev) HIP_TRY(hipEventRecord(ev[0], st));
+  if (d.n_sn > 0) {
+    const size_t lds = ((size_t)2 * d.n_grid + 8) * sizeof(double);
+    hipLaunchKernelGGL(sn_residual_kernel, dim3((unsigned)W), dim3(256), lds, st, d, d_theta, W, h->delta.as<double>(),
+                       dm_out, mucorr_out);
+    if (ev) HIP_TRY(hipEventRecord(ev[1], st));
+    const unsigned panels = (unsigned)((W + 15) / 16);
+    hipLaunchKernelGGL(trsm_chi2_kernel, dim3(panels), dim3(256), 0, st, d, h->pack.dev, d_theta, W,
+                       h->delta.as<const double>(), h->ypk.as<d2>(), (const double*)nullptr, d_out, out_kind, nf);
+  } else {
+    if (ev) HIP_TRY(hipEventRecord(ev[1], st));
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, d, d_theta, W,
+                       (const double*)nullptr, d_out, out_kind, nf);
+  }
+  if (ev) {
+    HIP_TRY(hipEventRecord(ev[2], st));
+    h->timed_calls++;
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int check_eval_args(cf_handle* h, const void* theta, int64_t W, const void* out, int out_kind, const char* fn) {
+  if (!h || !theta || !out) return fail(CF_ERR_INVALID, std::string(fn) + ": null argument");
+  if (W < 0 || W > ((int64_t)1 << 24)) return fail(CF_ERR_INVALID, std::string(fn) + ": W out of range");
+  if (out_kind < CF_OUT_CHI2 || out_kind > CF_OUT_LOGP) return fail(CF_ERR_INVALID, std::string(fn) + ": bad out_kind");
+  return 0;
+}
+
+extern "C" int cf_eval_device(cf_handle* h, const double* d_theta, int64_t W, double* d_out, int32_t out_kind,
+                              void* hip_stream) {
+  int rc = check_eval_args(h, d_theta, W, d_out, out_kind, "cf_eval_device");
+  if (rc) return rc;
+  if (W == 0) return CF_OK;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIP_TRY(hipSetDevice(h->device));
+  if ((rc = ensure_workspace(h, W))) return rc;
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
+  return launch_path(h, d_theta, W, d_out, out_kind, st, nullptr, nullptr);
+}
+
+extern "C" int cf_eval(cf_handle* h, const double* theta, int64_t W, double* out, int32_t out_kind) {
+  int rc = check_eval_args(h, theta, W, out, out_kind, "cf_eval");
+  if (rc) return rc;
+  if (W == 0) return CF_OK;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIP_TRY(hipSetDevice(h->device));
+  if ((rc = ensure_workspace(h, W))) return rc;
+  HIP_TRY(hipMemcpyAsync(h->theta.p, theta, (size_t)W * h->d.ndim * 8, hipMemcpyHostToDevice, h->stream));
+  if ((rc = launch_path(h, h->theta.as<const double>(), W, h->out.as<double>(), out_kind, h->stream, nullptr, nullptr)))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(out, h->out.p, (size_t)W * 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return CF_OK;
+}
+
+extern "C" int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, double* dm_obs, double* mu_corr,
+                             double* delta, double* chi2_blocks, double* bao_theory) {
+  if (!h || !theta) return fail(CF_ERR_INVALID, "cf_eval_parts: null argument");
+  if (W <= 0 || W > (1 << 20)) return fail(CF_ERR_INVALID, "cf_eval_parts: W out of range");
+  if (bao_theory) return fail(CF_ERR_UNSUPPORTED, "cf_eval_parts: no BAO block");
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIP_TRY(hipSetDevice(h->device));
+  int rc;
+  if ((rc = ensure_workspace(h, W))) return rc;
+  const int64_t n = h->d.n_sn, n_pad = h->d.n_pad;
+  DevBuf dm, mc;
+  if (dm_obs && dm.ensure((size_t)W * n * 8)) return CF_ERR_HIP;
+  if (mu_corr && mc.ensure((size_t)W * n * 8)) return CF_ERR_HIP;
+  HIP_TRY(hipMemcpyAsync(h->theta.p, theta, (size_t)W * h->d.ndim * 8, hipMemcpyHostToDevice, h->stream));
+  if ((rc = launch_path(h, h->theta.as<const double>(), W, h->out.as<double>(), CF_OUT_CHI2, h->stream,
+                        dm.as<double>(), mc.as<double>())))
+    return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (dm_obs) HIP_TRY(hipMemcpy(dm_obs, dm.p, (size_t)W * n * 8, hipMemcpyDeviceToHost));
+  if (mu_corr) HIP_TRY(hipMemcpy(mu_corr, mc.p, (size_t)W * n * 8, hipMemcpyDeviceToHost));
+  if (delta && n > 0)
+    HIP_TRY(hipMemcpy2D(delta, (size_t)n * 8, h->delta.p, (size_t)n_pad * 8, (size_t)n * 8, (size_t)W,
+                        hipMemcpyDeviceToHost));
+  if (chi2_blocks) {
+    std::vector<double> c2((size_t)W);
+    HIP_TRY(hipMemcpy(c2.data(), h->out.p, (size_t)W * 8, hipMemcpyDeviceToHost));
+    for (int64_t w = 0; w < W; ++w) {
+      chi2_blocks[3 * w + 0] = c2[w];
+      chi2_blocks[3 * w + 1] = 0.0;
+      chi2_blocks[3 * w + 2] = 0.0;
+    }
+  }
+  return CF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stand-alone operators
+// ------------------------------------------------------------------------------------------------
+static int interp_common(const double* xq, int64_t nq, const double* x, const double* y, const double* yp, int64_t n,
+                         double* out, int mode) {
+  if (!xq || !x || !y || !out || (mode == 0 && !yp)) return fail(CF_ERR_INVALID, "cf_interp: null argument");
+  if (nq < 0 || n < 2) return fail(CF_ERR_INVALID, "cf_interp: need n >= 2 nodes");
+  if (mode == 1 && n < 3) return fail(CF_ERR_INVALID, "cf_interp_pchip: need n >= 3 nodes");
+  if (cf_device_count() == 0) return fail(CF_ERR_NO_DEVICE, "cf_interp: no HIP device visible (this library has no CPU path)");
+  if (nq == 0) return CF_OK;
+  DevBuf dxq, dx, dy, dyp, dout;
+  if (dxq.ensure((size_t)nq * 8) || dx.ensure((size_t)n * 8) || dy.ensure((size_t)n * 8) || dout.ensure((size_t)nq * 8))
+    return CF_ERR_HIP;
+  HIP_TRY(hipMemcpy(dxq.p, xq, (size_t)nq * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dx.p, x, (size_t)n * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dy.p, y, (size_t)n * 8, hipMemcpyHostToDevice));
+  if (mode == 0) {
+    if (dyp.ensure((size_t)n * 8)) return CF_ERR_HIP;
+    HIP_TRY(hipMemcpy(dyp.p, yp, (size_t)n * 8, hipMemcpyHostToDevice));
+  }
+  hipLaunchKernelGGL(interp_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, 0, dxq.as<const double>(), nq,
+                     dx.as<const double>(), dy.as<const double>(), dyp.as<const double>(), n, dout.as<double>(), mode);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, dout.p, (size_t)nq * 8, hipMemcpyDeviceToHost));
+  return CF_OK;
+}
+
+extern "C" int cf_interp_hermite(const double* xq, int64_t nq, const double* x, const double* y, const double* y_prime,
+                                 int64_t n, double* out) {
+  return interp_common(xq, nq, x, y, y_prime, n, out, 0);
+}
+
+extern "C" int cf_interp_pchip(const double* xq, int64_t nq, const double* x, const double* y, int64_t n, double* out) {
+  return interp_common(xq, nq, x, y, nullptr, n, out, 1);
+}
+
+extern "C" int cf_solve_triangular(const double* L, int64_t n, int64_t ld, const double* b, int64_t nrhs, double* out) {
+  if (!L || !b || !out) return fail(CF_ERR_INVALID, "cf_solve_triangular: null argument");
+  if (n < 1 || ld < n || nrhs < 0 || n > (1 << 20)) return fail(CF_ERR_INVALID, "cf_solve_triangular: bad sizes");
+  if (cf_device_count() == 0)
+    return fail(CF_ERR_NO_DEVICE, "cf_solve_triangular: no HIP device visible (this library has no CPU path)");
+  if (nrhs == 0) return CF_OK;
+  cf_host_pack hp;
+  if (cf_pack_cholesky(L, n, ld, hp) != 0)
+    return fail(CF_ERR_NOT_POSDEF, "cf_solve_triangular: non-positive or non-finite diagonal entry");
+  PackedFactor pf;
+  int rc;
+  if ((rc = pf.upload(hp))) return rc;
+  const int64_t w_pad = (nrhs + 15) / 16 * 16, n_pad = hp.n_pad;
+  DevBuf db, delta, ypk, dout, nf, dth;
+  if (db.ensure((size_t)nrhs * n * 8) || delta.ensure((size_t)w_pad * n_pad * 8) || ypk.ensure((size_t)w_pad * n_pad * 8) ||
+      dout.ensure((size_t)w_pad * 8) || nf.ensure(8) || dth.ensure(8))
+    return CF_ERR_HIP;
+  HIP_TRY(hipMemcpy(db.p, b, (size_t)nrhs * n * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(nf.p, 0, 8));
+  hipLaunchKernelGGL(pad_rhs_kernel, dim3((unsigned)w_pad), dim3(256), 0, 0, db.as<const double>(), nrhs, n, n_pad,
+                     delta.as<double>());
+  cf_dev_desc d{};
+  d.n_sn = (int32_t)n;
+  d.n_pad = (int32_t)n_pad;
+  hipLaunchKernelGGL(trsm_chi2_kernel, dim3((unsigned)(w_pad / 16)), dim3(256), 0, 0, d, pf.dev, dth.as<const double>(),
+                     nrhs, delta.as<const double>(), ypk.as<d2>(), (const double*)nullptr, dout.as<double>(),
+                     (int)CF_OUT_CHI2, nf.as<unsigned long long>());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, dout.p, (size_t)nrhs * 8, hipMemcpyDeviceToHost));
+  return CF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host-only self-test of the packing logic (CPU test-suite; never on the evaluation path).
+// Returns || L^-1 b ||^2 computed by replaying the packed fragment streams on the host.
+// ------------------------------------------------------------------------------------------------
+extern "C" int cf_selftest_pack_host(const double* L, int64_t n, int64_t ld, const double* b, double* chi2_out,
+                                     int64_t* packed_bytes) {
+  if (!L || !b || !chi2_out) return fail(CF_ERR_INVALID, "cf_selftest_pack_host: null argument");
+  cf_host_pack hp;
+  if (cf_pack_cholesky(L, n, ld, hp) != 0) return fail(CF_ERR_NOT_POSDEF, "cf_selftest_pack_host: bad pivot");
+  *chi2_out = cf_pack_replay_host(hp, b);
+  if (packed_bytes) *packed_bytes = (int64_t)(hp.frags.size() * sizeof(cf_d2));
+  return CF_OK;
+}

@@ -1,0 +1,450 @@
+// cosmofit_kernels.hip — gfx950 (MI355X, CDNA4) device code of the batched log-likelihood engine.
+//
+// Two kernels make the hot path:
+//
+//   sn_residual_kernel  (a1-a10)  one 256-thread workgroup per walker.  E(z) on the G-point grid,
+//        cumulative trapezoid as chunk-sequential sums + a wave64 shuffle scan + LDS carry, the
+//        two tables (cum_dm, dh) staged in LDS (2*G*8 B = 64 KB), cubic-Hermite at the N data
+//        redshifts and at z_cosmo(theta), mu_corr, mu_theory, residual -> Delta[w][0..Npad).
+//
+//   trsm_chi2_kernel    (a11)     one 256-thread workgroup per PANEL of 16 walkers.  Blocked
+//        forward substitution  Y = L^-1 Delta  on FP64 matrix cores (v_mfma_f64_16x16x4_f64):
+//        256-row block rows, off-diagonal updates as MFMA GEMM steps streamed from the packed
+//        (pre-negated, fragment-ordered) factor, diagonal blocks applied through their
+//        pre-computed inverses; chi^2 = column sums of Y^2, then prior / out_kind epilogue.
+//
+// Written for wave64 / gfx950 only; no other target is supported.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cosmofit_device.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+#define CF_WAVE 64
+
+// ------------------------------------------------------------------------------------------------
+// Parameter slots
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double slot_get(const cf_dev_desc& d, int s, const double* __restrict__ th) {
+  const cf_dev_slot& p = d.slot[s];
+  return p.idx >= 0 ? p.scale * th[p.idx] : p.fixed;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Expansion rate.  dh(z) = c / H(z).   Reference: sn/pantheon.py:28-31, bao/desi.py:26-35,
+// sn/pantheon_and_sh0es.py:26-28, bao/desi_fs_lya_cmb.py:19-22.  (1+z)^3 by multiplies (numba).
+// ------------------------------------------------------------------------------------------------
+struct WalkerCosmo {
+  double H0, Om, w0, wa, c;
+  int fde;
+};
+
+__device__ __forceinline__ double f_de(const WalkerCosmo& wc, double z, double zp1, double cubed) {
+  switch (wc.fde) {
+    case CF_FDE_LCDM_D: return 1.0;
+    case CF_FDE_WCDM_D: return pow(zp1, 3 * (1 + wc.w0));
+    case CF_FDE_THAWING_D: {
+      double r = 2 * cubed / ((1.0 + wc.w0) + (1.0 - wc.w0) * cubed);
+      return r * r;
+    }
+    default: return pow(zp1, 3 * (1 + wc.w0 + wc.wa)) * exp(-3 * wc.wa * z / zp1);
+  }
+}
+
+__device__ __forceinline__ double dh_of_z(const WalkerCosmo& wc, double z) {
+  double zp1 = 1.0 + z;
+  double cubed = zp1 * zp1 * zp1;
+  double e2 = (wc.fde == CF_FDE_LCDM_D) ? wc.Om * cubed + (1.0 - wc.Om)
+                                        : wc.Om * cubed + (1.0 - wc.Om) * f_de(wc, z, zp1, cubed);
+  return wc.c / (wc.H0 * sqrt(e2));
+}
+
+// Grid node i of np.linspace(0, z_max, G): i*step, last node forced to z_max (sn/pantheon.py:16).
+__device__ __forceinline__ double grid_z(int i, int G, double step, double z_max) {
+  return i == G - 1 ? z_max : (double)i * step;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cubic Hermite on the uniform grid with nodes `cum`, slopes `dh` (both in LDS).
+// interpolator.py:71-108 with exact=True: interval i = searchsorted_left(x, xi) - 1, i.e.
+// x[i] < xi <= x[i+1]; linear extrapolation outside.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double hermite_lds(double xi, const double* cum, const double* dh, int G,
+                                              double step, double inv_step, double z_max) {
+  if (xi <= 0.0) return cum[0] + dh[0] * (xi - 0.0);
+  if (xi >= z_max) return cum[G - 1] + dh[G - 1] * (xi - z_max);
+  int i = (int)(xi * inv_step);
+  i = i > G - 2 ? G - 2 : i;
+  while (i > 0 && grid_z(i, G, step, z_max) >= xi) --i;
+  while (i < G - 2 && grid_z(i + 1, G, step, z_max) < xi) ++i;
+  double x0 = grid_z(i, G, step, z_max);
+  double h_i = grid_z(i + 1, G, step, z_max) - x0;
+  double t = (xi - x0) / h_i;
+  double t2 = t * t, t3 = t2 * t;
+  double h00 = 2 * t3 - 3 * t2 + 1;
+  double h10 = t3 - 2 * t2 + t;
+  double h01 = -2 * t3 + 3 * t2;
+  double h11 = t3 - t2;
+  return h00 * cum[i] + h10 * h_i * dh[i] + h01 * cum[i + 1] + h11 * h_i * dh[i + 1];
+}
+
+// Inclusive scan across the 64 lanes of a wave (Hillis-Steele on shuffles).
+__device__ __forceinline__ double wave_inclusive_scan(double v, int lane) {
+#pragma unroll
+  for (int off = 1; off < CF_WAVE; off <<= 1) {
+    double n = __shfl_up(v, off, CF_WAVE);
+    if (lane >= off) v += n;
+  }
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Build the two distance tables of one walker in LDS.  All 256 threads call it.
+//   dh[g]  = c/H(z_g)
+//   cum[g] = sum_{k<g} (dh[k]+dh[k+1])/2 * (z[k+1]-z[k])          (sn/pantheon.py:35-39)
+// Thread t owns the contiguous nodes [t*CH, (t+1)*CH): sequential inside a chunk, wave shuffle
+// scan over the chunk totals, 4 wave totals carried through LDS.
+// ------------------------------------------------------------------------------------------------
+#define CF_TPB_A 256
+
+__device__ void build_distance_tables(const cf_dev_desc& d, const WalkerCosmo& wc, double* cum, double* dh,
+                                      double* wave_tot) {
+  const int G = d.n_grid;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int CH = (G + CF_TPB_A - 1) / CF_TPB_A;
+  const int g0 = tid * CH, g1 = min(g0 + CH, G);
+  for (int g = g0; g < g1; ++g) dh[g] = dh_of_z(wc, grid_z(g, G, d.step, d.z_max));
+  __syncthreads();
+  // local inclusive prefix of the trapezoid terms ending at node g (g >= 1)
+  double run = 0.0;
+  for (int g = max(g0, 1); g < g1; ++g) {
+    double dz = grid_z(g, G, d.step, d.z_max) - grid_z(g - 1, G, d.step, d.z_max);
+    run += (dh[g - 1] + dh[g]) / 2 * dz;
+    cum[g] = run;  // chunk-local for now
+  }
+  if (g0 == 0 && g1 > 0) cum[0] = 0.0;
+  double incl = wave_inclusive_scan(run, lane);
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  double carry = incl - run;  // exclusive within the wave
+  for (int w = 0; w < wave; ++w) carry += wave_tot[w];
+  for (int g = max(g0, 1); g < g1; ++g) cum[g] += carry;
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Kernel A: distance + residual, one workgroup per walker.
+// ------------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(CF_TPB_A)
+sn_residual_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double* __restrict__ delta,
+                   double* __restrict__ dm_out, double* __restrict__ mucorr_out) {
+  extern __shared__ __align__(16) double lds[];
+  double* cum = lds;
+  double* dh = lds + d.n_grid;
+  double* wave_tot = lds + 2 * d.n_grid;
+
+  const int64_t w = blockIdx.x;
+  if (w >= W) return;
+  const double* th = theta + w * d.ndim;
+  double* out = delta + w * d.n_pad;
+
+  WalkerCosmo wc;
+  wc.H0 = slot_get(d, CF_P_H0_D, th);
+  wc.Om = slot_get(d, CF_P_OM_D, th);
+  wc.w0 = slot_get(d, CF_P_W0_D, th);
+  wc.wa = slot_get(d, CF_P_WA_D, th);
+  wc.c = d.c;
+  wc.fde = d.fde;
+  const double off = slot_get(d, CF_P_OFFSET_D, th);
+  const double v = slot_get(d, CF_P_V_D, th);
+
+  build_distance_tables(d, wc, cum, dh, wave_tot);
+
+  const int G = d.n_grid;
+  const double inv_step = 1.0 / d.step;
+  for (int i = threadIdx.x; i < d.n_pad; i += CF_TPB_A) {
+    double res = 0.0;
+    if (i < d.n_sn) {
+      const double zc = d.z_cmb[i];
+      const double DM = hermite_lds(zc, cum, dh, G, d.step, inv_step, d.z_max);
+      // sn/pantheon.py:43-49
+      const double v_km_s = 100 * v * d.sn_step[i];
+      const double z_pec = v_km_s / d.c;
+      const double z_cosmo = -1.0 + (1.0 + zc) / (1.0 + z_pec);
+      const double mu_corr = 5.0 * log10(hermite_lds(z_cosmo, cum, dh, G, d.step, inv_step, d.z_max) / DM);
+      // sn/pantheon.py:52-54
+      const double mu_th = 25.0 + 5 * log10((1.0 + d.z_hel[i]) * DM);
+      // sn/pantheon.py:59-60
+      res = d.obs[i] - off - mu_corr - mu_th;
+      if (dm_out) dm_out[w * d.n_sn + i] = DM;
+      if (mucorr_out) mucorr_out[w * d.n_sn + i] = mu_corr;
+    }
+    out[i] = res;  // rows >= n_sn are zero padding for the 16-row MFMA tiles
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Prior / output epilogue shared by every likelihood form.   sn/pantheon.py:80-97
+// ------------------------------------------------------------------------------------------------
+__device__ double finalize_value(const cf_dev_desc& d, const double* __restrict__ th, double chi2, int out_kind,
+                                 unsigned long long* nonfinite) {
+  for (int g = 0; g < d.n_chi2_gauss; ++g) {
+    double diff = th[d.chi2_gauss_idx[g]] - d.chi2_gauss_mean[g];
+    chi2 += diff * diff / (d.chi2_gauss_sigma[g] * d.chi2_gauss_sigma[g]);
+  }
+  if (out_kind == CF_OUT_CHI2_D) return chi2;
+  bool inbox = true;
+  double lp = 0.0;
+  if (out_kind == CF_OUT_LOGP_D) {
+    if (d.has_bounds) {
+      for (int k = 0; k < d.ndim; ++k) inbox = inbox && (d.lo[k] < th[k]) && (th[k] < d.hi[k]);
+      lp = d.log_norm;
+    }
+    if (!inbox) return -INFINITY;
+    if (d.cpl_wall && d.fde == CF_FDE_CPL_D &&
+        slot_get(d, CF_P_W0_D, th) + slot_get(d, CF_P_WA_D, th) >= 0.0)
+      return -1e8;
+    for (int g = 0; g < d.n_gauss; ++g) {
+      double diff = th[d.gauss_idx[g]] - d.gauss_mean[g];
+      lp = lp - 0.5 * (diff * diff) / (d.gauss_sigma[g] * d.gauss_sigma[g]);
+    }
+  }
+  double val = lp - 0.5 * chi2;
+  if (!isfinite(chi2)) {  // emcee aborts on NaN: map to -inf and count it
+    atomicAdd(nonfinite, 1ull);
+    return -INFINITY;
+  }
+  return val;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Kernel B: blocked triangular solve + chi^2 on FP64 MFMA, one workgroup per 16-walker panel.
+//
+// v_mfma_f64_16x16x4_f64 operand maps (lane l):  A[i = l&15][k = l>>4],  B[k = l>>4][n = l&15],
+// C/D register r: row = (l>>4) + 4r, col = l&15.  Hence register r of a solved 16x16 tile IS the
+// B fragment of K-step r of that tile: Y tiles go back into the product with no lane movement.
+//
+// Packed factor (built once on the host, cf_pack.h): for block row b and wave w the fragments are
+// stored in the order the wave consumes them, two K-steps (8 columns) per 16-byte lane element:
+//   update stream  [s2 < 32b][slot j < nt][lane] -> {-L[row][8 s2 + k], -L[row][8 s2 + 4 + k]}
+//   diag stream    [sl2 <= 2 mlmax+1][slot j < nt][lane] -> the same for inv(L_bb)
+// with row = 16*(16b + w + 4j) + (l&15), k = l>>4.  Every load is one coalesced 1 KiB access.
+// ------------------------------------------------------------------------------------------------
+#define CF_TPB_B 256
+#define CF_PREFETCH 4
+
+__device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+template <int NT>
+__device__ __forceinline__ void update_loop(d4 (&acc)[4], const d2* __restrict__ A, const d2* __restrict__ Yp,
+                                            int n_s2, int lane) {
+  // Software pipeline of depth CF_PREFETCH over K-step pairs; n_s2 is a multiple of 32.
+  d2 a[CF_PREFETCH][NT];
+  d2 yb[CF_PREFETCH];
+#pragma unroll
+  for (int p = 0; p < CF_PREFETCH; ++p) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) a[p][j] = A[((int64_t)p * NT + j) * 64 + lane];
+    yb[p] = Yp[(int64_t)p * 64 + lane];
+  }
+  for (int s2 = 0; s2 < n_s2; s2 += CF_PREFETCH) {
+#pragma unroll
+    for (int p = 0; p < CF_PREFETCH; ++p) {
+      d2 ca[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) ca[j] = a[p][j];
+      d2 cy = yb[p];
+      const int nxt = s2 + p + CF_PREFETCH;
+      if (nxt < n_s2) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) a[p][j] = A[((int64_t)nxt * NT + j) * 64 + lane];
+        yb[p] = Yp[(int64_t)nxt * 64 + lane];
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = mfma_f64(ca[j].x, cy.x, acc[j]);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = mfma_f64(ca[j].y, cy.y, acc[j]);
+    }
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(CF_TPB_B)
+trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* __restrict__ theta, int64_t W,
+                 const double* __restrict__ delta, d2* __restrict__ ypk, const double* __restrict__ chi2_extra,
+                 double* __restrict__ out, int out_kind, unsigned long long* nonfinite) {
+  __shared__ __align__(16) d2 ldsT[CF_BLOCK_ROWS / 8 * 64];  // one 256x16 block as B fragments: 32 KB
+  __shared__ double chi_part[4][16];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 15, kq = lane >> 4;
+  const int64_t panel = blockIdx.x;
+  const int64_t w0 = panel * 16;
+  const int n_pad = d.n_pad;
+  const int T = n_pad / 16;
+  d2* Yp = ypk + panel * (int64_t)(n_pad / 8) * 64;
+  const double* dcol = delta + (w0 + col) * (int64_t)n_pad;
+  double chi = 0.0;
+
+  for (int b = 0; b < pk.n_blocks; ++b) {
+    const int tiles_b = min(CF_BLOCK_TILES, T - b * CF_BLOCK_TILES);
+    const int nt = tiles_b > wave ? (tiles_b - wave + 3) / 4 : 0;
+    const int r0 = b * CF_BLOCK_ROWS;
+    // residual tile in C layout: row = 4r + kq inside the tile
+    d4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
+      if (j < nt) {
+        const double* p = dcol + r0 + 16 * (wave + 4 * j) + kq;
+        acc[j] = (d4){p[0], p[4], p[8], p[12]};
+      }
+    }
+    // ---- off-diagonal update: acc += (-L[b, 0:r0]) * Y[0:r0] ----
+    if (b > 0 && nt > 0) {
+      const d2* A = pk.frags + pk.upd_off[b * 4 + wave] * 64;
+      const int n_s2 = r0 / 8;
+      switch (nt) {
+        case 4: update_loop<4>(acc, A, Yp, n_s2, lane); break;
+        case 3: update_loop<3>(acc, A, Yp, n_s2, lane); break;
+        case 2: update_loop<2>(acc, A, Yp, n_s2, lane); break;
+        default: update_loop<1>(acc, A, Yp, n_s2, lane); break;
+      }
+    }
+    // ---- publish the updated right-hand side of this block as B fragments in LDS ----
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < nt) {
+        const int ml = wave + 4 * j;
+        ldsT[(2 * ml) * 64 + lane] = (d2){acc[j][0], acc[j][1]};
+        ldsT[(2 * ml + 1) * 64 + lane] = (d2){acc[j][2], acc[j][3]};
+      }
+    __syncthreads();
+    // ---- diagonal block through its inverse: y = inv(L_bb) * rhs (lower triangular) ----
+    d4 y[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = (d4){0.0, 0.0, 0.0, 0.0};
+    if (nt > 0) {
+      const d2* D = pk.frags + pk.diag_off[b * 4 + wave] * 64;
+      const int ml_max = wave + 4 * (nt - 1);
+      for (int sl2 = 0; sl2 <= 2 * ml_max + 1; ++sl2) {
+        const d2 tb = ldsT[sl2 * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < nt && sl2 <= 2 * (wave + 4 * j) + 1) {
+            const d2 a = D[((int64_t)sl2 * nt + j) * 64 + lane];
+            y[j] = mfma_f64(a.x, tb.x, y[j]);
+            y[j] = mfma_f64(a.y, tb.y, y[j]);
+          }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < nt) {
+          chi += y[j][0] * y[j][0] + y[j][1] * y[j][1] + y[j][2] * y[j][2] + y[j][3] * y[j][3];
+          const int mt = b * CF_BLOCK_TILES + wave + 4 * j;
+          Yp[(int64_t)(2 * mt) * 64 + lane] = (d2){y[j][0], y[j][1]};
+          Yp[(int64_t)(2 * mt + 1) * 64 + lane] = (d2){y[j][2], y[j][3]};
+        }
+    }
+    __syncthreads();  // Y of this block visible to the whole workgroup; ldsT reusable
+  }
+
+  // ---- chi^2 per walker column: over the 4 row groups of a wave, then over the 4 waves ----
+  chi += __shfl_xor(chi, 16, CF_WAVE);
+  chi += __shfl_xor(chi, 32, CF_WAVE);
+  if (lane < 16) chi_part[wave][lane] = chi;
+  __syncthreads();
+  if (tid < 16 && w0 + tid < W) {
+    const int64_t w = w0 + tid;
+    double c2 = ((chi_part[0][tid] + chi_part[1][tid]) + chi_part[2][tid]) + chi_part[3][tid];
+    if (chi2_extra) c2 += chi2_extra[w];
+    out[w] = finalize_value(d, theta + w * d.ndim, c2, out_kind, nonfinite);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Likelihoods without an SN block: only the epilogue.
+// ------------------------------------------------------------------------------------------------
+extern "C" __global__ void finalize_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W,
+                                           const double* __restrict__ chi2_extra, double* __restrict__ out,
+                                           int out_kind, unsigned long long* nonfinite) {
+  const int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (w < W) out[w] = finalize_value(d, theta + w * d.ndim, chi2_extra ? chi2_extra[w] : 0.0, out_kind, nonfinite);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stand-alone interpolators (interpolator.py) on arbitrary (non-uniform) grids in global memory.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t searchsorted_left(const double* __restrict__ x, int64_t n, double v) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    int64_t mid = lo + (hi - lo) / 2;
+    if (x[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ double sgn(double v) { return (double)((v > 0) - (v < 0)); }
+
+// Fritsch-Carlson slope at node i (interpolator.py:5-68), 3-point local stencil.
+__device__ double pchip_slope_at(const double* __restrict__ x, const double* __restrict__ y, int64_t n, int64_t i) {
+  if (n < 2) return 0.0;
+  if (n == 2) return (y[1] - y[0]) / (x[1] - x[0]);
+  if (i > 0 && i < n - 1) {
+    double hl = x[i] - x[i - 1], hr = x[i + 1] - x[i];
+    double dl = (y[i] - y[i - 1]) / hl, dr = (y[i + 1] - y[i]) / hr;
+    if (dl != 0.0 && dr != 0.0 && dl * dr > 0.0) {
+      double w1 = 2.0 * hr + hl, w2 = hr + 2.0 * hl;
+      return (w1 + w2) / (w1 / dl + w2 / dr);
+    }
+    return 0.0;
+  }
+  // end points: non-centred three-point formula with the sign / overshoot guards
+  double h0, h1, d0, d1;
+  if (i == 0) {
+    h0 = x[1] - x[0]; h1 = x[2] - x[1];
+    d0 = (y[1] - y[0]) / h0; d1 = (y[2] - y[1]) / h1;
+  } else {
+    h0 = x[n - 1] - x[n - 2]; h1 = x[n - 2] - x[n - 3];
+    d0 = (y[n - 1] - y[n - 2]) / h0; d1 = (y[n - 2] - y[n - 3]) / h1;
+  }
+  double e = ((2 * h0 + h1) * d0 - h0 * d1) / (h0 + h1);
+  if (d0 == 0.0 || sgn(e) != sgn(d0)) return 0.0;
+  if (sgn(d0) != sgn(d1) && fabs(e) > fabs(3 * d0)) return 3 * d0;
+  return e;
+}
+
+// mode 0: Hermite with given slopes (exact=True); mode 1: PCHIP (slopes on the fly, clamped)
+extern "C" __global__ void interp_kernel(const double* __restrict__ xq, int64_t nq, const double* __restrict__ x,
+                                         const double* __restrict__ y, const double* __restrict__ yp, int64_t n,
+                                         double* __restrict__ out, int mode) {
+  const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (k >= nq) return;
+  const double xi = xq[k];
+  if (xi <= x[0]) {
+    out[k] = mode == 0 ? y[0] + yp[0] * (xi - x[0]) : y[0];
+    return;
+  }
+  if (xi >= x[n - 1]) {
+    out[k] = mode == 0 ? y[n - 1] + yp[n - 1] * (xi - x[n - 1]) : y[n - 1];
+    return;
+  }
+  const int64_t i = searchsorted_left(x, n, xi) - 1;
+  const double d_i = mode == 0 ? yp[i] : pchip_slope_at(x, y, n, i);
+  const double d_i1 = mode == 0 ? yp[i + 1] : pchip_slope_at(x, y, n, i + 1);
+  const double h_i = x[i + 1] - x[i];
+  const double t = (xi - x[i]) / h_i;
+  const double t2 = t * t, t3 = t2 * t;
+  const double h00 = 2 * t3 - 3 * t2 + 1, h10 = t3 - 2 * t2 + t, h01 = -2 * t3 + 3 * t2, h11 = t3 - t2;
+  out[k] = h00 * y[i] + h10 * h_i * d_i + h01 * y[i + 1] + h11 * h_i * d_i1;
+}
+
+// Copy right-hand sides b[nrhs][n] into the padded residual layout Delta[nrhs_pad][n_pad].
+extern "C" __global__ void pad_rhs_kernel(const double* __restrict__ b, int64_t nrhs, int64_t n, int64_t n_pad,
+                                          double* __restrict__ delta) {
+  const int64_t w = blockIdx.x;
+  for (int64_t i = threadIdx.x; i < n_pad; i += blockDim.x) delta[w * n_pad + i] = (w < nrhs && i < n) ? b[w * n + i] : 0.0;
+}

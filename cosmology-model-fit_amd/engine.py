@@ -1,0 +1,170 @@
+"""
+Batched log-likelihood engine: the host-side object behind the emcee / nautilus callbacks.
+
+One ``LikelihoodEngine`` = one ``cf_handle`` of the C-ABI (include/cosmofit.h): the data vectors
+and the packed Cholesky factor live on one MI355X, and ``chi_squared / log_likelihood /
+log_probability`` evaluate W walkers per call through the HIP kernels.
+
+Reference call sites this replaces: ``chi_squared`` / ``log_probability`` of sn/pantheon.py:57-97
+and the batch wrappers bao/desi.py:100-106, bao/desi_cmb.py:137-143.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+
+C_KM_S = 299792.458  # scipy.constants.c / 1000 (sn/pantheon.py:12)
+
+
+@dataclass
+class Param:
+    """A physical parameter: read from theta[idx]*scale, or fixed."""
+    idx: int = -1
+    scale: float = 1.0
+    fixed: float = 0.0
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class LikelihoodEngine:
+    def __init__(self, *, ndim: int, z_max: float, n_grid: int = 4000, fde: int = L.CF_FDE_LCDM,
+                 ez_model: int = L.CF_EZ_LATE_FLAT, params: dict, sn: Optional[dict] = None,
+                 bounds=None, gauss: Sequence = (), chi2_gauss: Sequence = (), cpl_wall: bool = False,
+                 device: int = 0, c_km_s: float = C_KM_S):
+        """
+        params: {"H0": Param(1), "Om": Param(2), ...} for the slots of include/cosmofit.h (cf_param_slot).
+        sn: dict(z_cmb, z_hel, obs, chol[, step | z_turn]) — chol is cho_factor(cov, lower=True)[0];
+            the strict upper triangle is never read.
+        gauss / chi2_gauss: sequences of (idx, mean, sigma).
+        """
+        lib = L.lib()
+        d = L.cf_desc()
+        d.abi_version, d.struct_size = L.CF_ABI_VERSION, C.sizeof(L.cf_desc)
+        d.device, d.ndim = device, ndim
+        d.ez_model, d.fde, d.n_grid = ez_model, fde, n_grid
+        d.z_max, d.c_km_s = float(z_max), float(c_km_s)
+        unknown = set(params) - set(L.SLOTS)
+        if unknown:
+            raise ValueError(f"unknown parameter slots {sorted(unknown)}; valid: {L.SLOTS}")
+        for i, name in enumerate(L.SLOTS):
+            p = params.get(name, Param(fixed=-1.0) if name == "w0" else Param())
+            d.param[i].idx, d.param[i].scale, d.param[i].fixed = p.idx, p.scale, p.fixed
+        keep = []
+        if sn is not None:
+            z_cmb, z_hel, obs = _f64(sn["z_cmb"]), _f64(sn["z_hel"]), _f64(sn["obs"])
+            chol = _f64(sn["chol"])
+            if chol.ndim != 2 or chol.shape[0] != chol.shape[1] or chol.shape[0] != z_cmb.size:
+                raise ValueError("sn['chol'] must be (N, N) with N = len(z_cmb)")
+            step = None if sn.get("step") is None else _f64(sn["step"])
+            keep += [z_cmb, z_hel, obs, chol, step]
+            d.n_sn = z_cmb.size
+            d.sn_z_cmb, d.sn_z_hel, d.sn_obs, d.sn_step = _ptr(z_cmb), _ptr(z_hel), _ptr(obs), _ptr(step)
+            d.sn_z_turn = float(sn.get("z_turn", 0.15))
+            d.sn_chol, d.sn_chol_ld = _ptr(chol), chol.shape[1]
+        self.bounds = None if bounds is None else _f64(bounds).reshape(ndim, 2)
+        d.bounds = _ptr(self.bounds)
+        g = (L.cf_gauss_prior * max(len(gauss), 1))()
+        for k, (idx, mean, sigma) in enumerate(gauss):
+            g[k].idx, g[k].mean, g[k].sigma = int(idx), float(mean), float(sigma)
+        d.n_gauss, d.gauss = len(gauss), C.cast(g, C.c_void_p)
+        cg = (L.cf_gauss_prior * max(len(chi2_gauss), 1))()
+        for k, (idx, mean, sigma) in enumerate(chi2_gauss):
+            cg[k].idx, cg[k].mean, cg[k].sigma = int(idx), float(mean), float(sigma)
+        d.n_chi2_gauss, d.chi2_gauss = len(chi2_gauss), C.cast(cg, C.c_void_p)
+        d.cpl_wall = int(cpl_wall)
+        self.ndim = ndim
+        self.n_sn = int(d.n_sn)
+        self._h = C.c_void_p()
+        L.check(lib.cf_create(C.byref(d), C.byref(self._h)))
+        del keep  # cf_create copied everything
+
+    # ---- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            L.lib().cf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- evaluation -------------------------------------------------------------------------
+    def _eval(self, theta, kind):
+        th = _f64(theta)
+        single = th.ndim == 1
+        th = np.atleast_2d(th)
+        if th.shape[1] != self.ndim:
+            raise ValueError(f"theta must have {self.ndim} columns, got {th.shape}")
+        out = np.empty(th.shape[0], dtype=np.float64)
+        L.check(L.lib().cf_eval(self._h, _ptr(th), th.shape[0], _ptr(out), kind))
+        return float(out[0]) if single else out
+
+    def chi_squared(self, theta):
+        """chi^2(theta) for one theta [ndim] -> float, or a batch [W, ndim] -> float64[W]."""
+        return self._eval(theta, L.CF_OUT_CHI2)
+
+    def log_likelihood(self, theta):
+        """-0.5 chi^2 (what nautilus wants: prior handled by the sampler)."""
+        return self._eval(theta, L.CF_OUT_LOGL)
+
+    def log_probability(self, theta):
+        """log prior + log L; -inf outside the strict box (emcee callback, vectorize=True capable)."""
+        return self._eval(theta, L.CF_OUT_LOGP)
+
+    def eval_device(self, theta_ptr: int, W: int, out_ptr: int, kind: int = L.CF_OUT_LOGP, stream: int = 0):
+        """Asynchronous evaluation on device-resident buffers (raw device pointers, e.g. tensor.data_ptr())."""
+        L.check(L.lib().cf_eval_device(self._h, C.c_void_p(theta_ptr), W, C.c_void_p(out_ptr), kind,
+                                       C.c_void_p(stream)))
+
+    def parts(self, theta):
+        """DM(z_cmb), mu_corr, residual and chi^2 blocks of a (small) batch — for plots and tests."""
+        th = np.atleast_2d(_f64(theta))
+        W, n = th.shape[0], self.n_sn
+        dm, mc, dl = np.empty((W, n)), np.empty((W, n)), np.empty((W, n))
+        blocks = np.empty((W, 3))
+        L.check(L.lib().cf_eval_parts(self._h, _ptr(th), W, _ptr(dm), _ptr(mc), _ptr(dl), _ptr(blocks), None))
+        return dict(dm=dm, mu_corr=mc, delta=dl, chi2_blocks=blocks)
+
+    def enable_timing(self, slots=1):
+        """Keep HIP-event timings of the last `slots` evaluations (0 = off)."""
+        L.check(L.lib().cf_enable_timing(self._h, int(slots)))
+
+    def kernel_ms(self):
+        """[(residual_ms, solve_ms), ...] for every evaluation still in the timing ring."""
+        lib = L.lib()
+        n = lib.cf_timed_calls(self._h)
+        out = []
+        t = (C.c_float * 2)()
+        for call in range(n):
+            if lib.cf_kernel_ms(self._h, call, C.byref(t)) == 0:
+                out.append((float(t[0]), float(t[1])))
+        return out
+
+    def last_kernel_ms(self):
+        t = (C.c_float * 2)()
+        L.check(L.lib().cf_last_kernel_ms(self._h, C.byref(t)))
+        return float(t[0]), float(t[1])
+
+    def info(self) -> dict:
+        i = L.cf_info()
+        L.check(L.lib().cf_get_info(self._h, C.byref(i)))
+        return {k: (getattr(i, k).decode() if k == "gcn_arch" else getattr(i, k)) for k, _ in L.cf_info._fields_}

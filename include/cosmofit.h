@@ -229,8 +229,14 @@ int cf_eval_device(cf_handle* h, const double* d_theta, int64_t W, double* d_out
 int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, double* dm_obs, double* mu_corr,
                   double* delta, double* chi2_blocks, double* bao_theory);
 
-/* Time (ms, HIP events on the launch stream) of the kernels of the last evaluation call:
- * t[0] = distance+residual kernel, t[1] = triangular solve + chi^2 kernel. Waits for them. */
+/* Per-kernel timing with HIP events recorded on the stream the kernels are launched on.
+ * cf_enable_timing(h, slots): keep events for the last `slots` evaluation calls (0 = off, the
+ * default) and reset the call counter.  cf_kernel_ms(h, call, t): t[0] = distance+residual
+ * kernel, t[1] = triangular solve + chi^2 kernel of evaluation number `call` (0-based since
+ * cf_enable_timing); waits for that call.  cf_last_kernel_ms = the most recent call. */
+int cf_enable_timing(cf_handle* h, int slots);
+int64_t cf_timed_calls(cf_handle* h);
+int cf_kernel_ms(cf_handle* h, int64_t call, float t[2]);
 int cf_last_kernel_ms(cf_handle* h, float t[2]);
 
 /* ---- stand-alone operators with the reference's signatures (host buffers) ---- */
@@ -243,6 +249,12 @@ int cf_interp_pchip(const double* xq, int64_t nq, const double* x, const double*
 /* out[w] = || L^-1 b_w ||^2 for nrhs right-hand sides b[nrhs*n] (row w = b_w)  solve_triangular.py:5-14 */
 int cf_solve_triangular(const double* L, int64_t n, int64_t ld, const double* b, int64_t nrhs,
                         double* out);
+
+/* Host-only self-test of the factor packing (validates the fragment streams the solve kernel
+ * consumes by replaying them for one right-hand side).  For the CPU test-suite; no evaluation
+ * entry point ever calls it. */
+int cf_selftest_pack_host(const double* L, int64_t n, int64_t ld, const double* b, double* chi2_out,
+                          int64_t* packed_bytes);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,98 @@
+"""CPU: the C-ABI library loads, exports every symbol include/cosmofit.h declares, and refuses loudly without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden
+
+HEADER = os.path.join(ROOT, "include", "cosmofit.h")
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cf_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_compiles_as_c():
+    subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-x", "c", HEADER], check=True)
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.lib()
+    names = _declared_functions()
+    assert len(names) >= 14
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in cosmofit.h but not exported"
+    assert set(names) == set(pkg._lib.EXPORTS), "ctypes table and header disagree"
+
+
+def test_desc_layout_matches_c(pkg, tmp_path):
+    """sizeof / offsetof of cf_desc and cf_info as gcc sees them == the ctypes mirror."""
+    fields = ["ndim", "z_max", "param", "n_sn", "sn_chol_ld", "n_bao", "rd_fit", "cmb_mode", "cmb_inv_cov", "nu_ws",
+              "bounds", "gauss", "chi2_gauss"]
+    prog = '#include <stdio.h>\n#include <stddef.h>\n#include "cosmofit.h"\nint main(){printf("%zu %zu", sizeof(cf_desc), sizeof(cf_info));' + \
+        "".join(f'printf(" %zu", offsetof(cf_desc, {f}));' for f in fields) + "return 0;}"
+    src = tmp_path / "sz.c"
+    src.write_text(prog)
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    vals = list(map(int, subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()))
+    L = pkg._lib
+    assert vals[0] == C.sizeof(L.cf_desc)
+    assert vals[1] == C.sizeof(L.cf_info)
+    for f, off in zip(fields, vals[2:]):
+        assert getattr(L.cf_desc, f).offset == off, f
+
+
+def test_no_gpu_is_a_loud_error_not_a_fallback(pkg):
+    if pkg.lib().cf_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    g = golden("interpolator")
+    with pytest.raises(pkg.CosmofitError, match="CF_ERR_NO_DEVICE"):
+        pkg.interpolator.interp_hermite(g["h_xq"], g["h_x"], g["h_y"], g["h_yp"])
+    with pytest.raises(pkg.CosmofitError, match="CF_ERR_NO_DEVICE"):
+        pkg.solve_triangular.solve_triangular(g["t_L"], g["t_b"][0])
+    with pytest.raises(pkg.CosmofitError, match="CF_ERR_NO_DEVICE"):
+        pkg.LikelihoodEngine(ndim=2, z_max=1.0, params=dict(H0=pkg.Param(0), Om=pkg.Param(1)))
+
+
+def test_descriptor_validation(pkg):
+    """Argument errors are reported before any device work (same on CPU and GPU boxes)."""
+    with pytest.raises(pkg.CosmofitError, match="CF_ERR_INVALID"):
+        pkg.LikelihoodEngine(ndim=0, z_max=1.0, params={})
+    with pytest.raises(pkg.CosmofitError, match="CF_ERR_INVALID"):
+        pkg.LikelihoodEngine(ndim=2, z_max=-1.0, params={})
+    with pytest.raises(pkg.CosmofitError, match="CF_ERR_INVALID"):
+        pkg.LikelihoodEngine(ndim=2, z_max=1.0, params=dict(H0=pkg.Param(5)))
+    with pytest.raises(ValueError):
+        pkg.LikelihoodEngine(ndim=2, z_max=1.0, params=dict(bogus=pkg.Param(0)))
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 129, 256, 257, 300, 531])
+def test_packed_factor_replay_matches_forward_substitution(pkg, n):
+    """Host packing logic: replaying the fragment streams == the oracle's forward substitution."""
+    from oracle import oracle_c as oc
+
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((n, n))
+    Lm = np.linalg.cholesky(M @ M.T + n * np.eye(n)) + np.triu(rng.standard_normal((n, n)), 1) * 3.0  # garbage above
+    b = rng.standard_normal(n)
+    chi2, nbytes = C.c_double(), C.c_int64()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    pkg._lib.check(pkg.lib().cf_selftest_pack_host(p(Lm), n, n, p(b), C.byref(chi2), C.byref(nbytes)))
+    assert chi2.value == pytest.approx(oc.solve_triangular(Lm, b), rel=1e-12)
+    assert nbytes.value > 0
+
+
+def test_packed_factor_rejects_bad_pivot(pkg):
+    Lm = np.eye(20)
+    Lm[7, 7] = 0.0
+    chi2 = C.c_double()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = pkg.lib().cf_selftest_pack_host(p(Lm), 20, 20, p(np.ones(20)), C.byref(chi2), None)
+    assert rc == -4
