@@ -110,6 +110,23 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64 (same
+    SONAME as /opt/rocm's); if both copies get loaded the second one sees no GPU.  bench.py and the
+    tests use torch for device tensors and torch.distributed, so when torch is installed we bind to
+    ITS runtime (whichever of the two is imported first); without torch the RUNPATH (/opt/rocm) applies."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load the shared library; raises if it has not been built (no fallback)."""
     global _lib
@@ -117,6 +134,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise CosmofitError(-2, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                     "(hipcc --offload-arch=gfx950); there is no CPU implementation to fall back to")
+        _preload_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in EXPORTS.items():
             fn = getattr(L, name)

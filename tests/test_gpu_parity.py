@@ -81,11 +81,14 @@ def test_interpolators_golden(gpu):
 def test_interp_hermite_reproduces_nodes_and_slopes(gpu):
     rng = np.random.default_rng(3)
     x = np.sort(rng.uniform(0, 5, 200))
-    y, yp = rng.standard_normal(200), rng.standard_normal(200)
-    np.testing.assert_allclose(gpu.interpolator.interp_hermite(x[1:-1], x, y, yp), y[1:-1], rtol=1e-13, atol=1e-14)
-    eps = 1e-7 * np.diff(x)[:-1]
-    num = (gpu.interpolator.interp_hermite(x[1:-1] + eps, x, y, yp) - gpu.interpolator.interp_hermite(x[1:-1] - 0 * eps, x, y, yp)) / eps
-    np.testing.assert_allclose(num, yp[1:-1], rtol=1e-4, atol=1e-5)
+    y, yp = np.sin(x), np.cos(x)
+    ih = gpu.interpolator.interp_hermite
+    np.testing.assert_allclose(ih(x[1:-1], x, y, yp), y[1:-1], rtol=1e-13, atol=1e-14)
+    eps = 1e-6
+    num = (ih(x[1:-1] + eps, x, y, yp) - ih(x[1:-1] - eps, x, y, yp)) / (2 * eps)
+    np.testing.assert_allclose(num, yp[1:-1], rtol=0, atol=1e-6)
+    # linear extrapolation outside the grid with the end slopes
+    np.testing.assert_allclose(ih(np.array([-1.0, 7.0]), x, y, yp), [y[0] + yp[0] * (-1 - x[0]), y[-1] + yp[-1] * (7 - x[-1])], rtol=1e-14)
 
 
 # ---- a1-a10 + a11 + a17: the SN likelihood against the reference's golden vectors -----------
