@@ -14,10 +14,10 @@
 
 struct cf_host_pack {
   int64_t n = 0, n_pad = 0;
-  int32_t n_blocks = 0;
+  int32_t n_blocks = 0, ksplit = 1;
   std::vector<cf_d2> frags;        // 64 lane elements (1 KiB) per fragment
-  std::vector<int64_t> upd_off;    // [n_blocks*4] in fragments
-  std::vector<int64_t> diag_off;   // [n_blocks*4]
+  std::vector<int64_t> upd_off;    // [n_blocks*4*ksplit] in fragments
+  std::vector<int64_t> diag_off;   // [n_blocks*4*ksplit]
 };
 
 static inline int cf_tiles_in_block(int64_t T, int b) {
@@ -26,16 +26,28 @@ static inline int cf_tiles_in_block(int64_t T, int b) {
 }
 static inline int cf_slots_of_wave(int tiles_b, int w) { return tiles_b > w ? (tiles_b - w + 3) / 4 : 0; }
 
-// Returns 0, or -1 when a pivot is not finite-positive.
-static int cf_pack_cholesky(const double* L, int64_t n, int64_t ld, cf_host_pack& out) {
+// Highest valid tile of wave v in the diagonal phase of a block with tiles_b tiles (-1: none).
+static inline int cf_diag_ml_max(int NW, int v, int tiles_b) {
+  int m = -1;
+  for (int j = 0; j < cf_diag_slots(NW); ++j) {
+    int t = cf_diag_tile(NW, v, j);
+    if (t >= 0 && t < tiles_b && t > m) m = t;
+  }
+  return m;
+}
+
+// Returns 0, or -1 when a pivot is not finite-positive.  ksplit in {1, 2, 4}.
+static int cf_pack_cholesky(const double* L, int64_t n, int64_t ld, cf_host_pack& out, int ksplit = 2) {
   const int64_t n_pad = (n + 15) / 16 * 16;
   const int64_t T = n_pad / 16;
   const int n_blocks = (int)((T + CF_BLOCK_TILES - 1) / CF_BLOCK_TILES);
+  const int KS = ksplit, NW = 4 * KS, NTD = cf_diag_slots(NW);
   out.n = n;
   out.n_pad = n_pad;
   out.n_blocks = n_blocks;
-  out.upd_off.assign((size_t)n_blocks * 4, 0);
-  out.diag_off.assign((size_t)n_blocks * 4, 0);
+  out.ksplit = KS;
+  out.upd_off.assign((size_t)n_blocks * NW, 0);
+  out.diag_off.assign((size_t)n_blocks * NW, 0);
   for (int64_t i = 0; i < n; ++i) {
     double p = L[i * ld + i];
     if (!(p > 0.0) || !std::isfinite(p)) return -1;
@@ -50,14 +62,18 @@ static int cf_pack_cholesky(const double* L, int64_t n, int64_t ld, cf_host_pack
   int64_t total = 0;
   for (int b = 0; b < n_blocks; ++b) {
     const int tiles_b = cf_tiles_in_block(T, b);
-    for (int w = 0; w < 4; ++w) {
-      const int nt = cf_slots_of_wave(tiles_b, w);
-      out.upd_off[b * 4 + w] = total;
-      total += (int64_t)32 * b * nt;
-      out.diag_off[b * 4 + w] = total;
-      if (nt > 0) total += (int64_t)(2 * (w + 4 * (nt - 1)) + 2) * nt;
+    for (int wq = 0; wq < 4; ++wq)
+      for (int g = 0; g < KS; ++g) {
+        out.upd_off[(b * 4 + wq) * KS + g] = total;
+        total += (int64_t)(32 * b / KS) * cf_slots_of_wave(tiles_b, wq);
+      }
+    for (int v = 0; v < NW; ++v) {
+      out.diag_off[b * NW + v] = total;
+      const int mlm = cf_diag_ml_max(NW, v, tiles_b);
+      if (mlm >= 0) total += (int64_t)(2 * mlm + 2) * NTD;
     }
   }
+  total += 8 * NTD;  // slack so the kernel's diagonal prefetch may run past the last fragment
   out.frags.assign((size_t)total * 64, cf_d2{0.0, 0.0});
 
   std::vector<long double> inv;  // inverse of the current diagonal block, row-major nb x nb
@@ -76,74 +92,90 @@ static int cf_pack_cholesky(const double* L, int64_t n, int64_t ld, cf_host_pack
         inv[(size_t)i * nb + j] = -s / (long double)Lp(r0 + i, r0 + i);
       }
     }
-    for (int w = 0; w < 4; ++w) {
-      const int nt = cf_slots_of_wave(tiles_b, w);
-      if (nt == 0) continue;
-      cf_d2* up = out.frags.data() + out.upd_off[b * 4 + w] * 64;
-      for (int64_t s2 = 0; s2 < (int64_t)32 * b; ++s2)
-        for (int j = 0; j < nt; ++j)
+    const int64_t n_s2g = 32 * b / KS;
+    for (int wq = 0; wq < 4; ++wq) {
+      const int nt = cf_slots_of_wave(tiles_b, wq);
+      for (int g = 0; g < KS && nt > 0; ++g) {
+        cf_d2* up = out.frags.data() + out.upd_off[(b * 4 + wq) * KS + g] * 64;
+        for (int64_t q = 0; q < n_s2g; ++q) {
+          const int64_t s2 = g * n_s2g + q;
+          for (int j = 0; j < nt; ++j)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int64_t row = r0 + 16 * (wq + 4 * j) + (lane & 15);
+              const int64_t c0 = 8 * s2 + (lane >> 4);
+              cf_d2& f = up[(q * nt + j) * 64 + lane];
+              f.x = -Lp(row, c0);
+              f.y = -Lp(row, c0 + 4);
+            }
+        }
+      }
+    }
+    for (int v = 0; v < NW; ++v) {
+      const int mlm = cf_diag_ml_max(NW, v, tiles_b);
+      if (mlm < 0) continue;
+      cf_d2* dg = out.frags.data() + out.diag_off[b * NW + v] * 64;
+      for (int sl2 = 0; sl2 <= 2 * mlm + 1; ++sl2)
+        for (int j = 0; j < NTD; ++j) {
+          const int ml = cf_diag_tile(NW, v, j);
+          if (ml < 0 || ml >= tiles_b) continue;  // stays zero
           for (int lane = 0; lane < 64; ++lane) {
-            const int64_t row = r0 + 16 * (w + 4 * j) + (lane & 15);
-            const int64_t c0 = 8 * s2 + (lane >> 4);
-            cf_d2& f = up[(s2 * nt + j) * 64 + lane];
-            f.x = -Lp(row, c0);
-            f.y = -Lp(row, c0 + 4);
-          }
-      cf_d2* dg = out.frags.data() + out.diag_off[b * 4 + w] * 64;
-      const int ml_max = w + 4 * (nt - 1);
-      for (int sl2 = 0; sl2 <= 2 * ml_max + 1; ++sl2)
-        for (int j = 0; j < nt; ++j)
-          for (int lane = 0; lane < 64; ++lane) {
-            const int rl = 16 * (w + 4 * j) + (lane & 15);
+            const int rl = 16 * ml + (lane & 15);
             const int c0 = 8 * sl2 + (lane >> 4);
-            cf_d2& f = dg[((int64_t)sl2 * nt + j) * 64 + lane];
+            cf_d2& f = dg[((int64_t)sl2 * NTD + j) * 64 + lane];
             f.x = (c0 <= rl) ? (double)inv[(size_t)rl * nb + c0] : 0.0;
             f.y = (c0 + 4 <= rl) ? (double)inv[(size_t)rl * nb + c0 + 4] : 0.0;
           }
+        }
     }
   }
   return 0;
 }
 
 // Replays the fragment streams for ONE right-hand side on the host, with the kernel's block
-// structure (update through -L fragments, diagonal through the inverse fragments).  Used only by
-// the CPU test-suite to validate the packing logic without a GPU; cf_eval never calls it.
+// structure (update through -L fragments per K-split group, diagonal through the inverse
+// fragments).  Used only by the CPU test-suite to validate the packing logic without a GPU;
+// cf_eval never calls it.
 static double cf_pack_replay_host(const cf_host_pack& pk, const double* b_in) {
   const int64_t n_pad = pk.n_pad, T = n_pad / 16;
+  const int KS = pk.ksplit, NW = 4 * KS, NTD = cf_diag_slots(NW);
   std::vector<double> y((size_t)n_pad, 0.0), rhs(CF_BLOCK_ROWS);
   double chi = 0.0;
   for (int b = 0; b < pk.n_blocks; ++b) {
     const int tiles_b = cf_tiles_in_block(T, b);
     const int64_t r0 = (int64_t)b * CF_BLOCK_ROWS;
+    const int64_t n_s2g = 32 * b / KS;
     for (int i = 0; i < tiles_b * 16; ++i) rhs[i] = (r0 + i < pk.n) ? b_in[r0 + i] : 0.0;
-    for (int w = 0; w < 4; ++w) {
-      const int nt = cf_slots_of_wave(tiles_b, w);
-      const cf_d2* up = pk.frags.data() + pk.upd_off[b * 4 + w] * 64;
-      for (int64_t s2 = 0; s2 < (int64_t)32 * b; ++s2)
-        for (int j = 0; j < nt; ++j)
-          for (int lane = 0; lane < 64; ++lane) {
-            const int rl = 16 * (w + 4 * j) + (lane & 15);
-            const int64_t c0 = 8 * s2 + (lane >> 4);
-            const cf_d2& f = up[(s2 * nt + j) * 64 + lane];
-            rhs[rl] += f.x * y[c0] + f.y * y[c0 + 4];
-          }
+    for (int wq = 0; wq < 4; ++wq) {
+      const int nt = cf_slots_of_wave(tiles_b, wq);
+      for (int g = 0; g < KS; ++g) {
+        const cf_d2* up = pk.frags.data() + pk.upd_off[(b * 4 + wq) * KS + g] * 64;
+        for (int64_t q = 0; q < n_s2g; ++q)
+          for (int j = 0; j < nt; ++j)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int rl = 16 * (wq + 4 * j) + (lane & 15);
+              const int64_t c0 = 8 * (g * n_s2g + q) + (lane >> 4);
+              const cf_d2& f = up[(q * nt + j) * 64 + lane];
+              rhs[rl] += f.x * y[c0] + f.y * y[c0 + 4];
+            }
+      }
     }
-    for (int w = 0; w < 4; ++w) {
-      const int nt = cf_slots_of_wave(tiles_b, w);
-      if (nt == 0) continue;
-      const cf_d2* dg = pk.frags.data() + pk.diag_off[b * 4 + w] * 64;
-      const int ml_max = w + 4 * (nt - 1);
-      for (int j = 0; j < nt; ++j)
+    for (int v = 0; v < NW; ++v) {
+      const int mlm = cf_diag_ml_max(NW, v, tiles_b);
+      if (mlm < 0) continue;
+      const cf_d2* dg = pk.frags.data() + pk.diag_off[b * NW + v] * 64;
+      for (int j = 0; j < NTD; ++j) {
+        const int ml = cf_diag_tile(NW, v, j);
+        if (ml < 0 || ml >= tiles_b) continue;
         for (int li = 0; li < 16; ++li) {
-          const int rl = 16 * (w + 4 * j) + li;
           double s = 0.0;
-          for (int sl2 = 0; sl2 <= 2 * ml_max + 1 && sl2 <= 2 * (w + 4 * j) + 1; ++sl2)
+          for (int sl2 = 0; sl2 <= 2 * ml + 1; ++sl2)
             for (int kq = 0; kq < 4; ++kq) {
-              const cf_d2& f = dg[((int64_t)sl2 * nt + j) * 64 + kq * 16 + li];
+              const cf_d2& f = dg[((int64_t)sl2 * NTD + j) * 64 + kq * 16 + li];
               s += f.x * rhs[8 * sl2 + kq] + f.y * rhs[8 * sl2 + 4 + kq];
             }
-          y[r0 + rl] = s;
+          y[r0 + 16 * ml + li] = s;
         }
+      }
     }
     for (int i = 0; i < tiles_b * 16; ++i) chi += y[r0 + i] * y[r0 + i];
   }

@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -20,9 +21,16 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 extern "C" __global__ void sn_residual_kernel(cf_dev_desc d, const double* theta, int64_t W, double* delta,
                                               double* dm_out, double* mucorr_out);
-extern "C" __global__ void trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* theta, int64_t W,
-                                            const double* delta, d2* ypk, const double* chi2_extra, double* out,
-                                            int out_kind, unsigned long long* nonfinite);
+template <int KS>
+__global__ void trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* theta, int64_t W, const double* delta,
+                                 d2* ypk, const double* chi2_extra, double* out, int out_kind,
+                                 unsigned long long* nonfinite);
+extern template __global__ void trsm_chi2_kernel<1>(cf_dev_desc, cf_dev_pack, const double*, int64_t, const double*,
+                                                    d2*, const double*, double*, int, unsigned long long*);
+extern template __global__ void trsm_chi2_kernel<2>(cf_dev_desc, cf_dev_pack, const double*, int64_t, const double*,
+                                                    d2*, const double*, double*, int, unsigned long long*);
+extern template __global__ void trsm_chi2_kernel<4>(cf_dev_desc, cf_dev_pack, const double*, int64_t, const double*,
+                                                    d2*, const double*, double*, int, unsigned long long*);
 extern "C" __global__ void finalize_kernel(cf_dev_desc d, const double* theta, int64_t W, const double* chi2_extra,
                                            double* out, int out_kind, unsigned long long* nonfinite);
 extern "C" __global__ void interp_kernel(const double* xq, int64_t nq, const double* x, const double* y,
@@ -31,6 +39,17 @@ extern "C" __global__ void pad_rhs_kernel(const double* b, int64_t nrhs, int64_t
 
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
+
+// K-split of the solve kernel's workgroup (4*KS waves). 2 = two waves per SIMD, the default;
+// CF_KSPLIT=1|2|4 in the environment overrides it (tuning / tests).
+static int default_ksplit() {
+  const char* e = getenv("CF_KSPLIT");
+  if (e) {
+    int k = atoi(e);
+    if (k == 1 || k == 2 || k == 4) return k;
+  }
+  return 2;
+}
 
 static int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -76,6 +95,7 @@ struct PackedFactor {
     dev.upd_off = upd_off.as<const int64_t>();
     dev.diag_off = diag_off.as<const int64_t>();
     dev.n_blocks = hp.n_blocks;
+    dev.ksplit = hp.ksplit;
     return 0;
   }
 };
@@ -140,8 +160,8 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
                                     ", expected " + std::to_string(CF_ABI_VERSION) + ", " +
                                     std::to_string(sizeof(cf_desc)) + ")");
   if (c->ndim < 1 || c->ndim > CF_MAX_NDIM) return fail(CF_ERR_INVALID, "cf_create: ndim must be in 1..16");
-  if (c->n_grid < 4 || (size_t)c->n_grid * 16 + 64 > 160 * 1024)
-    return fail(CF_ERR_INVALID, "cf_create: n_grid must be in 4..10236 (two float64 tables must fit the 160 KB LDS)");
+  if (c->n_grid < 4 || c->n_grid > 8192)
+    return fail(CF_ERR_INVALID, "cf_create: n_grid must be in 4..8192 (the {cum_dm, dh} table must fit the 160 KB LDS)");
   if (!(c->z_max > 0.0) || !std::isfinite(c->z_max)) return fail(CF_ERR_INVALID, "cf_create: z_max must be > 0");
   if (!(c->c_km_s > 0.0)) return fail(CF_ERR_INVALID, "cf_create: c_km_s must be > 0");
   if (c->ez_model != CF_EZ_LATE_FLAT) return fail(CF_ERR_UNSUPPORTED, "cf_create: only CF_EZ_LATE_FLAT is built so far");
@@ -184,6 +204,10 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
   d.fde = c->fde;
   d.z_max = c->z_max;
   d.step = c->z_max / (double)(c->n_grid - 1);  // np.linspace step
+  d.inv_step = 1.0 / d.step;
+  d.inv_last = 1.0 / (c->z_max - (double)(c->n_grid - 2) * d.step);
+  d.chunk_shift = 0;
+  while ((512 << d.chunk_shift) < c->n_grid) d.chunk_shift++;
   d.c = c->c_km_s;
   for (int s = 0; s < CF_P_NSLOTS; ++s) {
     d.slot[s].idx = c->param[s].idx;
@@ -235,7 +259,7 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
     d.obs = h->obs.as<const double>();
     d.sn_step = h->sn_step.as<const double>();
     cf_host_pack hp;
-    if (cf_pack_cholesky(c->sn_chol, c->n_sn, c->sn_chol_ld, hp) != 0)
+    if (cf_pack_cholesky(c->sn_chol, c->n_sn, c->sn_chol_ld, hp, default_ksplit()) != 0)
       return bail(fail(CF_ERR_NOT_POSDEF, "cf_create: the Cholesky factor has a non-positive or non-finite pivot"));
     if ((rc = h->pack.upload(hp))) return bail(rc);
   }
@@ -309,6 +333,35 @@ extern "C" int cf_last_kernel_ms(cf_handle* h, float t[2]) {
   return cf_kernel_ms(h, h->timed_calls - 1, t);
 }
 
+template <int KS>
+static int launch_trsm_t(const cf_dev_desc& d, const cf_dev_pack& pk, const double* d_theta, int64_t W,
+                         const double* delta, d2* ypk, double* d_out, int out_kind, unsigned long long* nf,
+                         hipStream_t st) {
+  const size_t lds = (size_t)KS * (CF_BLOCK_ROWS / 8 * 64) * sizeof(d2);
+  static thread_local int attr_device = -1;  // > 64 KB of dynamic LDS must be allowed once per device
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (lds > 64 * 1024 && attr_device != dev) {
+    HIP_TRY(hipFuncSetAttribute((const void*)trsm_chi2_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_device = dev;
+  }
+  const unsigned panels = (unsigned)((W + 15) / 16);
+  hipLaunchKernelGGL(trsm_chi2_kernel<KS>, dim3(panels), dim3(256 * KS), lds, st, d, pk, d_theta, W, delta, ypk,
+                     (const double*)nullptr, d_out, out_kind, nf);
+  return 0;
+}
+
+static int launch_trsm(const cf_dev_desc& d, const cf_dev_pack& pk, const double* d_theta, int64_t W,
+                       const double* delta, d2* ypk, double* d_out, int out_kind, unsigned long long* nf,
+                       hipStream_t st) {
+  switch (pk.ksplit) {
+    case 1: return launch_trsm_t<1>(d, pk, d_theta, W, delta, ypk, d_out, out_kind, nf, st);
+    case 2: return launch_trsm_t<2>(d, pk, d_theta, W, delta, ypk, d_out, out_kind, nf, st);
+    case 4: return launch_trsm_t<4>(d, pk, d_theta, W, delta, ypk, d_out, out_kind, nf, st);
+  }
+  return fail(CF_ERR_INVALID, "bad ksplit");
+}
+
 // Launch the path on `st`: residual kernel, then solve + chi^2 (+ epilogue).
 static int launch_path(cf_handle* h, const double* d_theta, int64_t W, double* d_out, int out_kind, hipStream_t st,
                        double* dm_out, double* mucorr_out) {
@@ -317,13 +370,13 @@ static int launch_path(cf_handle* h, const double* d_theta, int64_t W, double* d
   hipEvent_t* ev = h->timing_slots ? &h->ev[3 * (h->timed_calls % h->timing_slots)] : nullptr;
   if (ev) HIP_TRY(hipEventRecord(ev[0], st));
   if (d.n_sn > 0) {
-    const size_t lds = ((size_t)2 * d.n_grid + 8) * sizeof(double);
-    hipLaunchKernelGGL(sn_residual_kernel, dim3((unsigned)W), dim3(256), lds, st, d, d_theta, W, h->delta.as<double>(),
+    // skewed {cum, dh} table: one spare 16-byte slot per 2^chunk_shift nodes
+    const size_t lds = ((size_t)d.n_grid + (d.n_grid >> d.chunk_shift) + 2) * 16;
+    hipLaunchKernelGGL(sn_residual_kernel, dim3((unsigned)W), dim3(512), lds, st, d, d_theta, W, h->delta.as<double>(),
                        dm_out, mucorr_out);
     if (ev) HIP_TRY(hipEventRecord(ev[1], st));
-    const unsigned panels = (unsigned)((W + 15) / 16);
-    hipLaunchKernelGGL(trsm_chi2_kernel, dim3(panels), dim3(256), 0, st, d, h->pack.dev, d_theta, W,
-                       h->delta.as<const double>(), h->ypk.as<d2>(), (const double*)nullptr, d_out, out_kind, nf);
+    int rc = launch_trsm(d, h->pack.dev, d_theta, W, h->delta.as<const double>(), h->ypk.as<d2>(), d_out, out_kind, nf, st);
+    if (rc) return rc;
   } else {
     if (ev) HIP_TRY(hipEventRecord(ev[1], st));
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, d, d_theta, W,
@@ -449,7 +502,7 @@ extern "C" int cf_solve_triangular(const double* L, int64_t n, int64_t ld, const
     return fail(CF_ERR_NO_DEVICE, "cf_solve_triangular: no HIP device visible (this library has no CPU path)");
   if (nrhs == 0) return CF_OK;
   cf_host_pack hp;
-  if (cf_pack_cholesky(L, n, ld, hp) != 0)
+  if (cf_pack_cholesky(L, n, ld, hp, default_ksplit()) != 0)
     return fail(CF_ERR_NOT_POSDEF, "cf_solve_triangular: non-positive or non-finite diagonal entry");
   PackedFactor pf;
   int rc;
@@ -466,9 +519,9 @@ extern "C" int cf_solve_triangular(const double* L, int64_t n, int64_t ld, const
   cf_dev_desc d{};
   d.n_sn = (int32_t)n;
   d.n_pad = (int32_t)n_pad;
-  hipLaunchKernelGGL(trsm_chi2_kernel, dim3((unsigned)(w_pad / 16)), dim3(256), 0, 0, d, pf.dev, dth.as<const double>(),
-                     nrhs, delta.as<const double>(), ypk.as<d2>(), (const double*)nullptr, dout.as<double>(),
-                     (int)CF_OUT_CHI2, nf.as<unsigned long long>());
+  if ((rc = launch_trsm(d, pf.dev, dth.as<const double>(), nrhs, delta.as<const double>(), ypk.as<d2>(),
+                        dout.as<double>(), (int)CF_OUT_CHI2, nf.as<unsigned long long>(), (hipStream_t)0)))
+    return rc;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, dout.p, (size_t)nrhs * 8, hipMemcpyDeviceToHost));
   return CF_OK;
@@ -482,7 +535,7 @@ extern "C" int cf_selftest_pack_host(const double* L, int64_t n, int64_t ld, con
                                      int64_t* packed_bytes) {
   if (!L || !b || !chi2_out) return fail(CF_ERR_INVALID, "cf_selftest_pack_host: null argument");
   cf_host_pack hp;
-  if (cf_pack_cholesky(L, n, ld, hp) != 0) return fail(CF_ERR_NOT_POSDEF, "cf_selftest_pack_host: bad pivot");
+  if (cf_pack_cholesky(L, n, ld, hp, default_ksplit()) != 0) return fail(CF_ERR_NOT_POSDEF, "cf_selftest_pack_host: bad pivot");
   *chi2_out = cf_pack_replay_host(hp, b);
   if (packed_bytes) *packed_bytes = (int64_t)(hp.frags.size() * sizeof(cf_d2));
   return CF_OK;

@@ -44,6 +44,8 @@ struct cf_dev_slot {
 struct cf_dev_desc {
   int32_t ndim, n_grid, ez_model, fde;
   double z_max, step, c;
+  double inv_step, inv_last;  // 1/(z[1]-z[0]) and 1/(z[G-1]-z[G-2]) of the linspace grid
+  int32_t chunk_shift, pad0;  // residual kernel: each of its 512 threads owns 2^chunk_shift grid nodes
   cf_dev_slot slot[CF_N_SLOTS];
   // SN block (device pointers)
   int32_t n_sn, n_pad;
@@ -68,12 +70,30 @@ typedef struct { double x, y; } cf_d2;
 #endif
 
 // Packed Cholesky factor: fragment streams per (block row, wave). Offsets in 1 KiB fragments.
+// ksplit = K-split of the update phase: the workgroup has 4*ksplit waves; wave (wq = wave&3,
+// g = wave>>2) updates the tiles wq, wq+4, .. of the block row with the K-step pairs
+// [g*n, (g+1)*n), n = 32 b / ksplit.
 struct cf_dev_pack {
   const cf_d2* frags;
-  const int64_t* upd_off;   // [n_blocks*4]
-  const int64_t* diag_off;  // [n_blocks*4]
+  const int64_t* upd_off;   // [n_blocks*4*ksplit]  index (b*4 + wq)*ksplit + g
+  const int64_t* diag_off;  // [n_blocks*4*ksplit]  index b*NW + wave
   int32_t n_blocks;
-  int32_t pad;
+  int32_t ksplit;
 };
+
+#ifdef __HIPCC__
+#define CF_HD __host__ __device__
+#else
+#define CF_HD
+#endif
+
+// Tiles of a block row that wave v (of NW = 4, 8 or 16) solves in the diagonal phase, slot j.
+// Pairs (v, 2NW-1-v) balance the triangular work.  Returns -1 when the slot does not exist.
+CF_HD static inline int cf_diag_slots(int NW) { return CF_BLOCK_TILES / NW; }
+CF_HD static inline int cf_diag_tile(int NW, int v, int j) {
+  if (NW >= CF_BLOCK_TILES) return j == 0 ? v : -1;
+  const int chunk = j >> 1, span = 2 * NW;
+  return (j & 1) ? chunk * span + span - 1 - v : chunk * span + v;
+}
 
 #endif

@@ -61,33 +61,64 @@ __device__ __forceinline__ double dh_of_z(const WalkerCosmo& wc, double z) {
   return wc.c / (wc.H0 * sqrt(e2));
 }
 
+// dh(z) without the sqrt + divide pair: (c/H0) * rsqrt(E^2).  <= 2 ulp from c/(H0*sqrt(E^2)).
+__device__ __forceinline__ double dh_of_z_fast(const WalkerCosmo& wc, double c_over_H0, double z) {
+  double zp1 = 1.0 + z;
+  double cubed = zp1 * zp1 * zp1;
+  double e2 = (wc.fde == CF_FDE_LCDM_D) ? wc.Om * cubed + (1.0 - wc.Om)
+                                        : wc.Om * cubed + (1.0 - wc.Om) * f_de(wc, z, zp1, cubed);
+  return c_over_H0 * rsqrt(e2);
+}
+
 // Grid node i of np.linspace(0, z_max, G): i*step, last node forced to z_max (sn/pantheon.py:16).
 __device__ __forceinline__ double grid_z(int i, int G, double step, double z_max) {
   return i == G - 1 ? z_max : (double)i * step;
 }
 
 // ------------------------------------------------------------------------------------------------
-// Cubic Hermite on the uniform grid with nodes `cum`, slopes `dh` (both in LDS).
-// interpolator.py:71-108 with exact=True: interval i = searchsorted_left(x, xi) - 1, i.e.
-// x[i] < xi <= x[i+1]; linear extrapolation outside.
+// Distance table of one walker in LDS: element g = {cum_dm[g], dh[g]} (16 B), stored at the
+// skewed position g + (g >> CHS).  Thread t owns the 2^CHS contiguous nodes starting at t << CHS,
+// so during the chunk-sequential prefix pass lane t touches position t*(2^CHS + 1) + k: a lane
+// stride of an odd number of 16-byte slots, which is bank-conflict free for ds_write_b128 /
+// ds_read_b128 (a power-of-two stride would put all 64 lanes on the same banks).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double hermite_lds(double xi, const double* cum, const double* dh, int G,
-                                              double step, double inv_step, double z_max) {
-  if (xi <= 0.0) return cum[0] + dh[0] * (xi - 0.0);
-  if (xi >= z_max) return cum[G - 1] + dh[G - 1] * (xi - z_max);
-  int i = (int)(xi * inv_step);
+#define CF_TPB_A 512
+
+struct DistTable {
+  const d2* tab;
+  int G, chs;
+  double step, inv_step, inv_last, z_max;
+  __device__ __forceinline__ d2 at(int g) const { return tab[g + (g >> chs)]; }
+};
+
+// Cubic Hermite on the uniform grid (nodes cum_dm, slopes dh).  interpolator.py:71-108 with
+// exact=True: interval i = searchsorted_left(x, xi) - 1, i.e. x[i] < xi <= x[i+1]; linear
+// extrapolation outside.  t = (xi - x_i)/h_i is formed with the precomputed 1/h_i (<= 1 ulp).
+__device__ __forceinline__ double hermite_tab(const DistTable& T, double xi) {
+  const int G = T.G;
+  if (xi <= 0.0) {
+    const d2 e = T.at(0);
+    return e.x + e.y * (xi - 0.0);
+  }
+  if (xi >= T.z_max) {
+    const d2 e = T.at(G - 1);
+    return e.x + e.y * (xi - T.z_max);
+  }
+  int i = (int)(xi * T.inv_step);
   i = i > G - 2 ? G - 2 : i;
-  while (i > 0 && grid_z(i, G, step, z_max) >= xi) --i;
-  while (i < G - 2 && grid_z(i + 1, G, step, z_max) < xi) ++i;
-  double x0 = grid_z(i, G, step, z_max);
-  double h_i = grid_z(i + 1, G, step, z_max) - x0;
-  double t = (xi - x0) / h_i;
-  double t2 = t * t, t3 = t2 * t;
-  double h00 = 2 * t3 - 3 * t2 + 1;
-  double h10 = t3 - 2 * t2 + t;
-  double h01 = -2 * t3 + 3 * t2;
-  double h11 = t3 - t2;
-  return h00 * cum[i] + h10 * h_i * dh[i] + h01 * cum[i + 1] + h11 * h_i * dh[i + 1];
+  // the estimate is off by at most one node: x[i] < xi <= x[i+1]
+  if (i > 0 && grid_z(i, G, T.step, T.z_max) >= xi) --i;
+  if (i < G - 2 && grid_z(i + 1, G, T.step, T.z_max) < xi) ++i;
+  const double x0 = grid_z(i, G, T.step, T.z_max);
+  const double h_i = grid_z(i + 1, G, T.step, T.z_max) - x0;
+  const double t = (xi - x0) * (i == G - 2 ? T.inv_last : T.inv_step);
+  const double t2 = t * t, t3 = t2 * t;
+  const double h00 = 2 * t3 - 3 * t2 + 1;
+  const double h10 = t3 - 2 * t2 + t;
+  const double h01 = -2 * t3 + 3 * t2;
+  const double h11 = t3 - t2;
+  const d2 e0 = T.at(i), e1 = T.at(i + 1);
+  return h00 * e0.x + h10 * h_i * e0.y + h01 * e1.x + h11 * h_i * e1.y;
 }
 
 // Inclusive scan across the 64 lanes of a wave (Hillis-Steele on shuffles).
@@ -100,50 +131,59 @@ __device__ __forceinline__ double wave_inclusive_scan(double v, int lane) {
   return v;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Build the two distance tables of one walker in LDS.  All 256 threads call it.
+// Build the table.  All CF_TPB_A threads call it.
 //   dh[g]  = c/H(z_g)
 //   cum[g] = sum_{k<g} (dh[k]+dh[k+1])/2 * (z[k+1]-z[k])          (sn/pantheon.py:35-39)
-// Thread t owns the contiguous nodes [t*CH, (t+1)*CH): sequential inside a chunk, wave shuffle
-// scan over the chunk totals, 4 wave totals carried through LDS.
-// ------------------------------------------------------------------------------------------------
-#define CF_TPB_A 256
-
-__device__ void build_distance_tables(const cf_dev_desc& d, const WalkerCosmo& wc, double* cum, double* dh,
-                                      double* wave_tot) {
-  const int G = d.n_grid;
+// Chunk-sequential inside a thread, wave64 shuffle scan over the chunk totals, wave totals
+// carried through LDS.  Thread t owns CH = 2^chs contiguous nodes, CH*CF_TPB_A >= G.
+__device__ __forceinline__ void build_distance_table(const cf_dev_desc& d, const WalkerCosmo& wc, d2* tab,
+                                                     double* wave_tot) {
+  const int G = d.n_grid, chs = d.chunk_shift, CH = 1 << chs;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int CH = (G + CF_TPB_A - 1) / CF_TPB_A;
-  const int g0 = tid * CH, g1 = min(g0 + CH, G);
-  for (int g = g0; g < g1; ++g) dh[g] = dh_of_z(wc, grid_z(g, G, d.step, d.z_max));
+  const int g0 = tid << chs;
+  const int base = g0 + tid;  // skewed position of node g0
+  const int n_own = max(0, min(CH, G - g0));
+  const double c_over_H0 = wc.c / wc.H0;
+  for (int k = 0; k < n_own; ++k)
+    tab[base + k].y = dh_of_z_fast(wc, c_over_H0, grid_z(g0 + k, G, d.step, d.z_max));
   __syncthreads();
-  // local inclusive prefix of the trapezoid terms ending at node g (g >= 1)
+  // chunk-local inclusive prefix of the trapezoid terms (node g needs dh[g-1]: the last node of
+  // the previous thread's chunk sits at skewed position base-2)
   double run = 0.0;
-  for (int g = max(g0, 1); g < g1; ++g) {
-    double dz = grid_z(g, G, d.step, d.z_max) - grid_z(g - 1, G, d.step, d.z_max);
-    run += (dh[g - 1] + dh[g]) / 2 * dz;
-    cum[g] = run;  // chunk-local for now
+  double prev = g0 > 0 && n_own > 0 ? tab[base - 2].y : 0.0;
+  for (int k = 0; k < n_own; ++k) {
+    const int g = g0 + k;
+    const double cur = tab[base + k].y;
+    if (g >= 1) {
+      const double dz = grid_z(g, G, d.step, d.z_max) - grid_z(g - 1, G, d.step, d.z_max);
+      run += (prev + cur) / 2 * dz;
+    }
+    tab[base + k].x = run;
+    prev = cur;
   }
-  if (g0 == 0 && g1 > 0) cum[0] = 0.0;
-  double incl = wave_inclusive_scan(run, lane);
+  const double incl = wave_inclusive_scan(run, lane);
   if (lane == 63) wave_tot[wave] = incl;
   __syncthreads();
-  double carry = incl - run;  // exclusive within the wave
+  double carry = incl - run;  // exclusive inside the wave
   for (int w = 0; w < wave; ++w) carry += wave_tot[w];
-  for (int g = max(g0, 1); g < g1; ++g) cum[g] += carry;
+  for (int k = 0; k < n_own; ++k) tab[base + k].x += carry;
   __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------
-// Kernel A: distance + residual, one workgroup per walker.
+// Kernel A: distance + residual, one 512-thread workgroup per walker.
+//
+// Fast path (dm_out == mucorr_out == NULL): the two magnitude terms of the reference,
+//   mu_corr + mu_theory = 5 log10(DM(z_cosmo)/DM(z_cmb)) + 25 + 5 log10((1+z_hel) DM(z_cmb)),
+// are evaluated as the algebraically identical 25 + 5 log10((1+z_hel) DM(z_cosmo)): one Hermite
+// and one log10 per SN instead of two and two (difference ~1e-15 mag, tests/test_gpu_parity.py).
+// The accessor path (cf_eval_parts) keeps the reference's exact sequence  sn/pantheon.py:43-61.
 // ------------------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(CF_TPB_A)
+extern "C" __global__ void __launch_bounds__(CF_TPB_A, 4)
 sn_residual_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double* __restrict__ delta,
                    double* __restrict__ dm_out, double* __restrict__ mucorr_out) {
-  extern __shared__ __align__(16) double lds[];
-  double* cum = lds;
-  double* dh = lds + d.n_grid;
-  double* wave_tot = lds + 2 * d.n_grid;
+  extern __shared__ __align__(16) d2 lds_tab[];
+  __shared__ double wave_tot[16];
 
   const int64_t w = blockIdx.x;
   if (w >= W) return;
@@ -160,26 +200,38 @@ sn_residual_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, d
   const double off = slot_get(d, CF_P_OFFSET_D, th);
   const double v = slot_get(d, CF_P_V_D, th);
 
-  build_distance_tables(d, wc, cum, dh, wave_tot);
+  build_distance_table(d, wc, lds_tab, wave_tot);
 
-  const int G = d.n_grid;
-  const double inv_step = 1.0 / d.step;
+  DistTable T;
+  T.tab = lds_tab;
+  T.G = d.n_grid;
+  T.chs = d.chunk_shift;
+  T.step = d.step;
+  T.inv_step = d.inv_step;
+  T.inv_last = d.inv_last;
+  T.z_max = d.z_max;
+  const bool parts = dm_out != nullptr || mucorr_out != nullptr;
+  const double v100 = 100 * v;
+
   for (int i = threadIdx.x; i < d.n_pad; i += CF_TPB_A) {
     double res = 0.0;
     if (i < d.n_sn) {
       const double zc = d.z_cmb[i];
-      const double DM = hermite_lds(zc, cum, dh, G, d.step, inv_step, d.z_max);
       // sn/pantheon.py:43-49
-      const double v_km_s = 100 * v * d.sn_step[i];
+      const double v_km_s = v100 * d.sn_step[i];
       const double z_pec = v_km_s / d.c;
       const double z_cosmo = -1.0 + (1.0 + zc) / (1.0 + z_pec);
-      const double mu_corr = 5.0 * log10(hermite_lds(z_cosmo, cum, dh, G, d.step, inv_step, d.z_max) / DM);
-      // sn/pantheon.py:52-54
-      const double mu_th = 25.0 + 5 * log10((1.0 + d.z_hel[i]) * DM);
-      // sn/pantheon.py:59-60
-      res = d.obs[i] - off - mu_corr - mu_th;
-      if (dm_out) dm_out[w * d.n_sn + i] = DM;
-      if (mucorr_out) mucorr_out[w * d.n_sn + i] = mu_corr;
+      const double DMc = hermite_tab(T, z_cosmo);
+      if (!parts) {
+        res = d.obs[i] - off - (25.0 + 5 * log10((1.0 + d.z_hel[i]) * DMc));
+      } else {
+        const double DM = hermite_tab(T, zc);
+        const double mu_corr = 5.0 * log10(DMc / DM);
+        const double mu_th = 25.0 + 5 * log10((1.0 + d.z_hel[i]) * DM);  // sn/pantheon.py:52-54
+        res = d.obs[i] - off - mu_corr - mu_th;                          // sn/pantheon.py:59-60
+        if (dm_out) dm_out[w * d.n_sn + i] = DM;
+        if (mucorr_out) mucorr_out[w * d.n_sn + i] = mu_corr;
+      }
     }
     out[i] = res;  // rows >= n_sn are zero padding for the 16-row MFMA tiles
   }
@@ -226,14 +278,22 @@ __device__ double finalize_value(const cf_dev_desc& d, const double* __restrict_
 // C/D register r: row = (l>>4) + 4r, col = l&15.  Hence register r of a solved 16x16 tile IS the
 // B fragment of K-step r of that tile: Y tiles go back into the product with no lane movement.
 //
-// Packed factor (built once on the host, cf_pack.h): for block row b and wave w the fragments are
-// stored in the order the wave consumes them, two K-steps (8 columns) per 16-byte lane element:
-//   update stream  [s2 < 32b][slot j < nt][lane] -> {-L[row][8 s2 + k], -L[row][8 s2 + 4 + k]}
-//   diag stream    [sl2 <= 2 mlmax+1][slot j < nt][lane] -> the same for inv(L_bb)
-// with row = 16*(16b + w + 4j) + (l&15), k = l>>4.  Every load is one coalesced 1 KiB access.
+// One wave issues an independent f64 MFMA only every ~140 cycles while the pipe takes one per 64
+// (profiles/r01_mfma_f64_rate.txt), so the workgroup runs NW = 4*KS waves (KS = 2: two per SIMD):
+// in the update phase wave (wq = wave&3, g = wave>>2) owns the tiles wq, wq+4, wq+8, wq+12 of the
+// 256-row block row and the K range [g, g+1) * (r0/KS); the KS partial right-hand sides meet in
+// LDS, and the diagonal phase (rhs times the pre-inverted diagonal block) is spread over all NW
+// waves by tile pairs (v, 2NW-1-v) of equal triangular work.
+//
+// Packed factor (built once on the host, cf_pack.h), two K-steps (8 columns) per 16-byte lane
+// element, in the order the wave consumes it -- every load is one coalesced 1 KiB access:
+//   update stream (b, wq, g): [q < 32b/KS][slot j < nt][lane] -> {-L[row][8 s2 + k], -L[row][8 s2 + 4 + k]}
+//                             row = 16 (16b + wq + 4j) + (l&15), k = l>>4, s2 = g*32b/KS + q
+//   diag stream   (b, v)    : [sl2 <= 2 mlmax + 1][slot j < 16/NW][lane] -> the same for inv(L_bb),
+//                             tile of slot j = cf_diag_tile(NW, v, j)
 // ------------------------------------------------------------------------------------------------
-#define CF_TPB_B 256
 #define CF_PREFETCH 4
+#define CF_DIAG_PREFETCH 4
 
 __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
@@ -242,7 +302,7 @@ __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
 template <int NT>
 __device__ __forceinline__ void update_loop(d4 (&acc)[4], const d2* __restrict__ A, const d2* __restrict__ Yp,
                                             int n_s2, int lane) {
-  // Software pipeline of depth CF_PREFETCH over K-step pairs; n_s2 is a multiple of 32.
+  // Software pipeline of depth CF_PREFETCH over K-step pairs; n_s2 is a multiple of CF_PREFETCH.
   d2 a[CF_PREFETCH][NT];
   d2 yb[CF_PREFETCH];
 #pragma unroll
@@ -272,14 +332,19 @@ __device__ __forceinline__ void update_loop(d4 (&acc)[4], const d2* __restrict__
   }
 }
 
-extern "C" __global__ void __launch_bounds__(CF_TPB_B)
+template <int KS>
+__global__ void __launch_bounds__(256 * KS)
 trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* __restrict__ theta, int64_t W,
                  const double* __restrict__ delta, d2* __restrict__ ypk, const double* __restrict__ chi2_extra,
                  double* __restrict__ out, int out_kind, unsigned long long* nonfinite) {
-  __shared__ __align__(16) d2 ldsT[CF_BLOCK_ROWS / 8 * 64];  // one 256x16 block as B fragments: 32 KB
-  __shared__ double chi_part[4][16];
+  constexpr int NW = 4 * KS;
+  constexpr int NTD = CF_BLOCK_TILES / NW;
+  constexpr int PANEL_FRAGS = CF_BLOCK_ROWS / 8 * 64;  // one 256x16 block as B fragments: 2048 d2 = 32 KB
+  extern __shared__ __align__(16) d2 ldsP[];            // [KS][PANEL_FRAGS] partial right-hand sides
+  __shared__ double chi_part[NW][16];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wq = wave & 3, g = wave >> 2;
   const int col = lane & 15, kq = lane >> 4;
   const int64_t panel = blockIdx.x;
   const int64_t w0 = panel * 16;
@@ -291,79 +356,121 @@ trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* __restrict__ theta
 
   for (int b = 0; b < pk.n_blocks; ++b) {
     const int tiles_b = min(CF_BLOCK_TILES, T - b * CF_BLOCK_TILES);
-    const int nt = tiles_b > wave ? (tiles_b - wave + 3) / 4 : 0;
+    const int nt = tiles_b > wq ? (tiles_b - wq + 3) / 4 : 0;
     const int r0 = b * CF_BLOCK_ROWS;
-    // residual tile in C layout: row = 4r + kq inside the tile
+    // diagonal-phase stream of this wave: start its first loads now, they land during the update
+    int ml[NTD], ml_max = -1;
+#pragma unroll
+    for (int j = 0; j < NTD; ++j) {
+      const int t = cf_diag_tile(NW, wave, j);
+      ml[j] = (t >= 0 && t < tiles_b) ? t : -1;
+      ml_max = max(ml_max, ml[j]);
+    }
+    const d2* D = pk.frags + pk.diag_off[b * NW + wave] * 64;
+    d2 da[CF_DIAG_PREFETCH][NTD];
+    if (ml_max >= 0) {
+#pragma unroll
+      for (int p = 0; p < CF_DIAG_PREFETCH; ++p)
+#pragma unroll
+        for (int j = 0; j < NTD; ++j) da[p][j] = D[((int64_t)p * NTD + j) * 64 + lane];
+    }
+    // residual tile in C layout (row = 4r + kq inside the tile); K-split groups > 0 start from zero
     d4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
-      if (j < nt) {
-        const double* p = dcol + r0 + 16 * (wave + 4 * j) + kq;
+      if (j < nt && g == 0) {
+        const double* p = dcol + r0 + 16 * (wq + 4 * j) + kq;
         acc[j] = (d4){p[0], p[4], p[8], p[12]};
       }
     }
-    // ---- off-diagonal update: acc += (-L[b, 0:r0]) * Y[0:r0] ----
+    // ---- off-diagonal update: acc += (-L[b, K range of g]) * Y[K range of g] ----
     if (b > 0 && nt > 0) {
-      const d2* A = pk.frags + pk.upd_off[b * 4 + wave] * 64;
-      const int n_s2 = r0 / 8;
+      const d2* A = pk.frags + pk.upd_off[(b * 4 + wq) * KS + g] * 64;
+      const int n_s2 = r0 / 8 / KS;
+      const d2* Yg = Yp + (int64_t)g * n_s2 * 64;
       switch (nt) {
-        case 4: update_loop<4>(acc, A, Yp, n_s2, lane); break;
-        case 3: update_loop<3>(acc, A, Yp, n_s2, lane); break;
-        case 2: update_loop<2>(acc, A, Yp, n_s2, lane); break;
-        default: update_loop<1>(acc, A, Yp, n_s2, lane); break;
+        case 4: update_loop<4>(acc, A, Yg, n_s2, lane); break;
+        case 3: update_loop<3>(acc, A, Yg, n_s2, lane); break;
+        case 2: update_loop<2>(acc, A, Yg, n_s2, lane); break;
+        default: update_loop<1>(acc, A, Yg, n_s2, lane); break;
       }
     }
-    // ---- publish the updated right-hand side of this block as B fragments in LDS ----
+    // ---- publish this wave's partial right-hand side as B fragments in LDS ----
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (j < nt) {
-        const int ml = wave + 4 * j;
-        ldsT[(2 * ml) * 64 + lane] = (d2){acc[j][0], acc[j][1]};
-        ldsT[(2 * ml + 1) * 64 + lane] = (d2){acc[j][2], acc[j][3]};
+        const int t = wq + 4 * j;
+        ldsP[g * PANEL_FRAGS + (2 * t) * 64 + lane] = (d2){acc[j][0], acc[j][1]};
+        ldsP[g * PANEL_FRAGS + (2 * t + 1) * 64 + lane] = (d2){acc[j][2], acc[j][3]};
       }
     __syncthreads();
     // ---- diagonal block through its inverse: y = inv(L_bb) * rhs (lower triangular) ----
-    d4 y[4];
+    if (ml_max >= 0) {
+      d4 y[NTD];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) y[j] = (d4){0.0, 0.0, 0.0, 0.0};
-    if (nt > 0) {
-      const d2* D = pk.frags + pk.diag_off[b * 4 + wave] * 64;
-      const int ml_max = wave + 4 * (nt - 1);
-      for (int sl2 = 0; sl2 <= 2 * ml_max + 1; ++sl2) {
-        const d2 tb = ldsT[sl2 * 64 + lane];
+      for (int j = 0; j < NTD; ++j) y[j] = (d4){0.0, 0.0, 0.0, 0.0};
+      const int n_sl2 = 2 * ml_max + 2;
+      for (int s0 = 0; s0 < n_sl2; s0 += CF_DIAG_PREFETCH) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (j < nt && sl2 <= 2 * (wave + 4 * j) + 1) {
-            const d2 a = D[((int64_t)sl2 * nt + j) * 64 + lane];
-            y[j] = mfma_f64(a.x, tb.x, y[j]);
-            y[j] = mfma_f64(a.y, tb.y, y[j]);
+        for (int p = 0; p < CF_DIAG_PREFETCH; ++p) {
+          const int sl2 = s0 + p;
+          if (sl2 < n_sl2) {  // wave-uniform
+            d2 tb = ldsP[sl2 * 64 + lane];
+#pragma unroll
+            for (int k = 1; k < KS; ++k) {
+              const d2 o = ldsP[k * PANEL_FRAGS + sl2 * 64 + lane];
+              tb.x += o.x;
+              tb.y += o.y;
+            }
+            d2 ca[NTD];
+#pragma unroll
+            for (int j = 0; j < NTD; ++j) ca[j] = da[p][j];
+            // the packed stream carries 8*NTD fragments of slack, so this prefetch never leaves it
+#pragma unroll
+            for (int j = 0; j < NTD; ++j) da[p][j] = D[((int64_t)(sl2 + CF_DIAG_PREFETCH) * NTD + j) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < NTD; ++j)
+              if (sl2 <= 2 * ml[j] + 1) {
+                y[j] = mfma_f64(ca[j].x, tb.x, y[j]);
+                y[j] = mfma_f64(ca[j].y, tb.y, y[j]);
+              }
           }
+        }
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (j < nt) {
+      for (int j = 0; j < NTD; ++j)
+        if (ml[j] >= 0) {
           chi += y[j][0] * y[j][0] + y[j][1] * y[j][1] + y[j][2] * y[j][2] + y[j][3] * y[j][3];
-          const int mt = b * CF_BLOCK_TILES + wave + 4 * j;
+          const int mt = b * CF_BLOCK_TILES + ml[j];
           Yp[(int64_t)(2 * mt) * 64 + lane] = (d2){y[j][0], y[j][1]};
           Yp[(int64_t)(2 * mt + 1) * 64 + lane] = (d2){y[j][2], y[j][3]};
         }
     }
-    __syncthreads();  // Y of this block visible to the whole workgroup; ldsT reusable
+    __syncthreads();  // Y of this block visible to the whole workgroup; ldsP reusable
   }
 
-  // ---- chi^2 per walker column: over the 4 row groups of a wave, then over the 4 waves ----
+  // ---- chi^2 per walker column: over the 4 row groups of a wave, then over the NW waves ----
   chi += __shfl_xor(chi, 16, CF_WAVE);
   chi += __shfl_xor(chi, 32, CF_WAVE);
   if (lane < 16) chi_part[wave][lane] = chi;
   __syncthreads();
   if (tid < 16 && w0 + tid < W) {
     const int64_t w = w0 + tid;
-    double c2 = ((chi_part[0][tid] + chi_part[1][tid]) + chi_part[2][tid]) + chi_part[3][tid];
+    double c2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) c2 += chi_part[k][tid];
     if (chi2_extra) c2 += chi2_extra[w];
     out[w] = finalize_value(d, theta + w * d.ndim, c2, out_kind, nonfinite);
   }
 }
+
+template __global__ void trsm_chi2_kernel<1>(cf_dev_desc, cf_dev_pack, const double*, int64_t, const double*, d2*,
+                                             const double*, double*, int, unsigned long long*);
+template __global__ void trsm_chi2_kernel<2>(cf_dev_desc, cf_dev_pack, const double*, int64_t, const double*, d2*,
+                                             const double*, double*, int, unsigned long long*);
+template __global__ void trsm_chi2_kernel<4>(cf_dev_desc, cf_dev_pack, const double*, int64_t, const double*, d2*,
+                                             const double*, double*, int, unsigned long long*);
 
 // ------------------------------------------------------------------------------------------------
 // Likelihoods without an SN block: only the epilogue.
