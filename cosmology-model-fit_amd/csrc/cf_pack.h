@@ -14,7 +14,7 @@
 
 struct cf_host_pack {
   int64_t n = 0, n_pad = 0;
-  int32_t n_blocks = 0, ksplit = 1;
+  int32_t n_blocks = 0, ksplit = 1, tclasses = 4;
   std::vector<cf_d2> frags;        // 64 lane elements (1 KiB) per fragment
   std::vector<int64_t> upd_off;    // [n_blocks*4*ksplit] in fragments
   std::vector<int64_t> diag_off;   // [n_blocks*4*ksplit]
@@ -24,7 +24,7 @@ static inline int cf_tiles_in_block(int64_t T, int b) {
   int64_t left = T - (int64_t)b * CF_BLOCK_TILES;
   return (int)(left < CF_BLOCK_TILES ? left : CF_BLOCK_TILES);
 }
-static inline int cf_slots_of_wave(int tiles_b, int w) { return tiles_b > w ? (tiles_b - w + 3) / 4 : 0; }
+static inline int cf_slots_of_wave(int tiles_b, int tq, int TC) { return tiles_b > tq ? (tiles_b - tq + TC - 1) / TC : 0; }
 
 // Highest valid tile of wave v in the diagonal phase of a block with tiles_b tiles (-1: none).
 static inline int cf_diag_ml_max(int NW, int v, int tiles_b) {
@@ -36,13 +36,14 @@ static inline int cf_diag_ml_max(int NW, int v, int tiles_b) {
   return m;
 }
 
-// Returns 0, or -1 when a pivot is not finite-positive.  ksplit in {1, 2, 4}.
-static int cf_pack_cholesky(const double* L, int64_t n, int64_t ld, cf_host_pack& out, int ksplit = 2) {
+// Returns 0, or -1 when a pivot is not finite-positive.  (ksplit, tclasses) in {(1,4), (2,4), (4,4), (2,8)}.
+static int cf_pack_cholesky(const double* L, int64_t n, int64_t ld, cf_host_pack& out, int ksplit = 2, int tclasses = 4) {
   const int64_t n_pad = (n + 15) / 16 * 16;
   const int64_t T = n_pad / 16;
   const int n_blocks = (int)((T + CF_BLOCK_TILES - 1) / CF_BLOCK_TILES);
-  const int KS = ksplit, NW = 4 * KS, NTD = cf_diag_slots(NW);
+  const int KS = ksplit, TC = tclasses, NW = TC * KS, NTD = cf_diag_slots(NW);
   out.n = n;
+  out.tclasses = TC;
   out.n_pad = n_pad;
   out.n_blocks = n_blocks;
   out.ksplit = KS;
@@ -62,10 +63,10 @@ static int cf_pack_cholesky(const double* L, int64_t n, int64_t ld, cf_host_pack
   int64_t total = 0;
   for (int b = 0; b < n_blocks; ++b) {
     const int tiles_b = cf_tiles_in_block(T, b);
-    for (int wq = 0; wq < 4; ++wq)
+    for (int wq = 0; wq < TC; ++wq)
       for (int g = 0; g < KS; ++g) {
-        out.upd_off[(b * 4 + wq) * KS + g] = total;
-        total += (int64_t)(32 * b / KS) * cf_slots_of_wave(tiles_b, wq);
+        out.upd_off[(b * TC + wq) * KS + g] = total;
+        total += (int64_t)(32 * b / KS) * cf_slots_of_wave(tiles_b, wq, TC);
       }
     for (int v = 0; v < NW; ++v) {
       out.diag_off[b * NW + v] = total;
@@ -73,7 +74,7 @@ static int cf_pack_cholesky(const double* L, int64_t n, int64_t ld, cf_host_pack
       if (mlm >= 0) total += (int64_t)(2 * mlm + 2) * NTD;
     }
   }
-  total += 8 * NTD;  // slack so the kernel's diagonal prefetch may run past the last fragment
+  total += 32;  // slack: the kernel's software pipelines read up to 4 steps past a stream's end
   out.frags.assign((size_t)total * 64, cf_d2{0.0, 0.0});
 
   std::vector<long double> inv;  // inverse of the current diagonal block, row-major nb x nb
@@ -93,15 +94,15 @@ static int cf_pack_cholesky(const double* L, int64_t n, int64_t ld, cf_host_pack
       }
     }
     const int64_t n_s2g = 32 * b / KS;
-    for (int wq = 0; wq < 4; ++wq) {
-      const int nt = cf_slots_of_wave(tiles_b, wq);
+    for (int wq = 0; wq < TC; ++wq) {
+      const int nt = cf_slots_of_wave(tiles_b, wq, TC);
       for (int g = 0; g < KS && nt > 0; ++g) {
-        cf_d2* up = out.frags.data() + out.upd_off[(b * 4 + wq) * KS + g] * 64;
+        cf_d2* up = out.frags.data() + out.upd_off[(b * TC + wq) * KS + g] * 64;
         for (int64_t q = 0; q < n_s2g; ++q) {
           const int64_t s2 = g * n_s2g + q;
           for (int j = 0; j < nt; ++j)
             for (int lane = 0; lane < 64; ++lane) {
-              const int64_t row = r0 + 16 * (wq + 4 * j) + (lane & 15);
+              const int64_t row = r0 + 16 * (wq + TC * j) + (lane & 15);
               const int64_t c0 = 8 * s2 + (lane >> 4);
               cf_d2& f = up[(q * nt + j) * 64 + lane];
               f.x = -Lp(row, c0);
@@ -137,7 +138,7 @@ static int cf_pack_cholesky(const double* L, int64_t n, int64_t ld, cf_host_pack
 // cf_eval never calls it.
 static double cf_pack_replay_host(const cf_host_pack& pk, const double* b_in) {
   const int64_t n_pad = pk.n_pad, T = n_pad / 16;
-  const int KS = pk.ksplit, NW = 4 * KS, NTD = cf_diag_slots(NW);
+  const int KS = pk.ksplit, TC = pk.tclasses, NW = TC * KS, NTD = cf_diag_slots(NW);
   std::vector<double> y((size_t)n_pad, 0.0), rhs(CF_BLOCK_ROWS);
   double chi = 0.0;
   for (int b = 0; b < pk.n_blocks; ++b) {
@@ -145,14 +146,14 @@ static double cf_pack_replay_host(const cf_host_pack& pk, const double* b_in) {
     const int64_t r0 = (int64_t)b * CF_BLOCK_ROWS;
     const int64_t n_s2g = 32 * b / KS;
     for (int i = 0; i < tiles_b * 16; ++i) rhs[i] = (r0 + i < pk.n) ? b_in[r0 + i] : 0.0;
-    for (int wq = 0; wq < 4; ++wq) {
-      const int nt = cf_slots_of_wave(tiles_b, wq);
+    for (int wq = 0; wq < TC; ++wq) {
+      const int nt = cf_slots_of_wave(tiles_b, wq, TC);
       for (int g = 0; g < KS; ++g) {
-        const cf_d2* up = pk.frags.data() + pk.upd_off[(b * 4 + wq) * KS + g] * 64;
+        const cf_d2* up = pk.frags.data() + pk.upd_off[(b * TC + wq) * KS + g] * 64;
         for (int64_t q = 0; q < n_s2g; ++q)
           for (int j = 0; j < nt; ++j)
             for (int lane = 0; lane < 64; ++lane) {
-              const int rl = 16 * (wq + 4 * j) + (lane & 15);
+              const int rl = 16 * (wq + TC * j) + (lane & 15);
               const int64_t c0 = 8 * (g * n_s2g + q) + (lane >> 4);
               const cf_d2& f = up[(q * nt + j) * 64 + lane];
               rhs[rl] += f.x * y[c0] + f.y * y[c0 + 4];

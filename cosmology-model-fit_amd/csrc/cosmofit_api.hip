@@ -19,18 +19,23 @@
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
+// the solve kernel's prefetch reads up to 4 K-step pairs (4 KiB) past the end of a panel's Y range
+#define CF_YPK_SLACK 8192
+
 extern "C" __global__ void sn_residual_kernel(cf_dev_desc d, const double* theta, int64_t W, double* delta,
                                               double* dm_out, double* mucorr_out);
-template <int KS>
+template <int KS, int TC>
 __global__ void trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* theta, int64_t W, const double* delta,
                                  d2* ypk, const double* chi2_extra, double* out, int out_kind,
                                  unsigned long long* nonfinite);
-extern template __global__ void trsm_chi2_kernel<1>(cf_dev_desc, cf_dev_pack, const double*, int64_t, const double*,
-                                                    d2*, const double*, double*, int, unsigned long long*);
-extern template __global__ void trsm_chi2_kernel<2>(cf_dev_desc, cf_dev_pack, const double*, int64_t, const double*,
-                                                    d2*, const double*, double*, int, unsigned long long*);
-extern template __global__ void trsm_chi2_kernel<4>(cf_dev_desc, cf_dev_pack, const double*, int64_t, const double*,
-                                                    d2*, const double*, double*, int, unsigned long long*);
+#define CF_DECLARE_TRSM(KS, TC)                                                                                       \
+  extern template __global__ void trsm_chi2_kernel<KS, TC>(cf_dev_desc, cf_dev_pack, const double*, int64_t,          \
+                                                           const double*, d2*, const double*, double*, int,           \
+                                                           unsigned long long*);
+CF_DECLARE_TRSM(1, 4)
+CF_DECLARE_TRSM(2, 4)
+CF_DECLARE_TRSM(4, 4)
+CF_DECLARE_TRSM(2, 8)
 extern "C" __global__ void finalize_kernel(cf_dev_desc d, const double* theta, int64_t W, const double* chi2_extra,
                                            double* out, int out_kind, unsigned long long* nonfinite);
 extern "C" __global__ void interp_kernel(const double* xq, int64_t nq, const double* x, const double* y,
@@ -40,15 +45,29 @@ extern "C" __global__ void pad_rhs_kernel(const double* b, int64_t nrhs, int64_t
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
 
-// K-split of the solve kernel's workgroup (4*KS waves). 2 = two waves per SIMD, the default;
-// CF_KSPLIT=1|2|4 in the environment overrides it (tuning / tests).
-static int default_ksplit() {
-  const char* e = getenv("CF_KSPLIT");
+// Shape of the solve kernel's workgroup: ksplit x tclasses waves (see cf_dev_pack).  Default 2x4 =
+// 8 waves, two per SIMD; CF_SOLVE_SHAPE=1x4|2x4|4x4|2x8 in the environment overrides it (tuning / tests).
+static void default_shape(int& ks, int& tc) {
+  ks = 2;
+  tc = 4;
+  const char* e = getenv("CF_SOLVE_SHAPE");
   if (e) {
-    int k = atoi(e);
-    if (k == 1 || k == 2 || k == 4) return k;
+    int a = 0, b = 0;
+    if (sscanf(e, "%dx%d", &a, &b) == 2 && ((b == 4 && (a == 1 || a == 2 || a == 4)) || (a == 2 && b == 8))) {
+      ks = a;
+      tc = b;
+    }
   }
-  return 2;
+}
+static int pack_default(const double* L, int64_t n, int64_t ld, cf_host_pack& hp) {
+  int ks, tc;
+  default_shape(ks, tc);
+  int rc = cf_pack_cholesky(L, n, ld, hp, ks, tc);
+  // TIMING EXPERIMENT ONLY (wrong results): fold every update stream onto the first 64 KiB so that
+  // all factor loads hit L1/L2 -- tells an operand-delivery bound from an MFMA-issue bound.
+  if (rc == 0 && getenv("CF_DEBUG_ALIAS_STREAMS"))
+    for (auto& o : hp.upd_off) o = o % 32;
+  return rc;
 }
 
 static int fail(int code, const std::string& msg) {
@@ -96,6 +115,7 @@ struct PackedFactor {
     dev.diag_off = diag_off.as<const int64_t>();
     dev.n_blocks = hp.n_blocks;
     dev.ksplit = hp.ksplit;
+    dev.tclasses = hp.tclasses;
     return 0;
   }
 };
@@ -142,10 +162,10 @@ static int ensure_workspace(cf_handle* h, int64_t W) {
   if (h->out.ensure((size_t)w_pad * 8)) return CF_ERR_HIP;
   if (h->d.n_sn > 0) {
     if (h->delta.ensure((size_t)w_pad * n_pad * 8)) return CF_ERR_HIP;
-    if (h->ypk.ensure((size_t)w_pad * n_pad * 8)) return CF_ERR_HIP;
+    if (h->ypk.ensure((size_t)w_pad * n_pad * 8 + CF_YPK_SLACK)) return CF_ERR_HIP;
     // columns of a partly filled last panel must hold finite numbers
     HIP_TRY(hipMemsetAsync(h->delta.p, 0, (size_t)w_pad * n_pad * 8, h->stream));
-    HIP_TRY(hipMemsetAsync(h->ypk.p, 0, (size_t)w_pad * n_pad * 8, h->stream));
+    HIP_TRY(hipMemsetAsync(h->ypk.p, 0, (size_t)w_pad * n_pad * 8 + CF_YPK_SLACK, h->stream));
   }
   h->max_walkers = w_pad;
   return 0;
@@ -259,7 +279,7 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
     d.obs = h->obs.as<const double>();
     d.sn_step = h->sn_step.as<const double>();
     cf_host_pack hp;
-    if (cf_pack_cholesky(c->sn_chol, c->n_sn, c->sn_chol_ld, hp, default_ksplit()) != 0)
+    if (pack_default(c->sn_chol, c->n_sn, c->sn_chol_ld, hp) != 0)
       return bail(fail(CF_ERR_NOT_POSDEF, "cf_create: the Cholesky factor has a non-positive or non-finite pivot"));
     if ((rc = h->pack.upload(hp))) return bail(rc);
   }
@@ -333,7 +353,7 @@ extern "C" int cf_last_kernel_ms(cf_handle* h, float t[2]) {
   return cf_kernel_ms(h, h->timed_calls - 1, t);
 }
 
-template <int KS>
+template <int KS, int TC>
 static int launch_trsm_t(const cf_dev_desc& d, const cf_dev_pack& pk, const double* d_theta, int64_t W,
                          const double* delta, d2* ypk, double* d_out, int out_kind, unsigned long long* nf,
                          hipStream_t st) {
@@ -342,11 +362,11 @@ static int launch_trsm_t(const cf_dev_desc& d, const cf_dev_pack& pk, const doub
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   if (lds > 64 * 1024 && attr_device != dev) {
-    HIP_TRY(hipFuncSetAttribute((const void*)trsm_chi2_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)(&trsm_chi2_kernel<KS, TC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_device = dev;
   }
   const unsigned panels = (unsigned)((W + 15) / 16);
-  hipLaunchKernelGGL(trsm_chi2_kernel<KS>, dim3(panels), dim3(256 * KS), lds, st, d, pk, d_theta, W, delta, ypk,
+  hipLaunchKernelGGL((trsm_chi2_kernel<KS, TC>), dim3(panels), dim3(64 * KS * TC), lds, st, d, pk, d_theta, W, delta, ypk,
                      (const double*)nullptr, d_out, out_kind, nf);
   return 0;
 }
@@ -354,12 +374,13 @@ static int launch_trsm_t(const cf_dev_desc& d, const cf_dev_pack& pk, const doub
 static int launch_trsm(const cf_dev_desc& d, const cf_dev_pack& pk, const double* d_theta, int64_t W,
                        const double* delta, d2* ypk, double* d_out, int out_kind, unsigned long long* nf,
                        hipStream_t st) {
-  switch (pk.ksplit) {
-    case 1: return launch_trsm_t<1>(d, pk, d_theta, W, delta, ypk, d_out, out_kind, nf, st);
-    case 2: return launch_trsm_t<2>(d, pk, d_theta, W, delta, ypk, d_out, out_kind, nf, st);
-    case 4: return launch_trsm_t<4>(d, pk, d_theta, W, delta, ypk, d_out, out_kind, nf, st);
+  switch (pk.ksplit * 16 + pk.tclasses) {
+    case 1 * 16 + 4: return launch_trsm_t<1, 4>(d, pk, d_theta, W, delta, ypk, d_out, out_kind, nf, st);
+    case 2 * 16 + 4: return launch_trsm_t<2, 4>(d, pk, d_theta, W, delta, ypk, d_out, out_kind, nf, st);
+    case 4 * 16 + 4: return launch_trsm_t<4, 4>(d, pk, d_theta, W, delta, ypk, d_out, out_kind, nf, st);
+    case 2 * 16 + 8: return launch_trsm_t<2, 8>(d, pk, d_theta, W, delta, ypk, d_out, out_kind, nf, st);
   }
-  return fail(CF_ERR_INVALID, "bad ksplit");
+  return fail(CF_ERR_INVALID, "bad solve shape");
 }
 
 // Launch the path on `st`: residual kernel, then solve + chi^2 (+ epilogue).
@@ -502,14 +523,14 @@ extern "C" int cf_solve_triangular(const double* L, int64_t n, int64_t ld, const
     return fail(CF_ERR_NO_DEVICE, "cf_solve_triangular: no HIP device visible (this library has no CPU path)");
   if (nrhs == 0) return CF_OK;
   cf_host_pack hp;
-  if (cf_pack_cholesky(L, n, ld, hp, default_ksplit()) != 0)
+  if (pack_default(L, n, ld, hp) != 0)
     return fail(CF_ERR_NOT_POSDEF, "cf_solve_triangular: non-positive or non-finite diagonal entry");
   PackedFactor pf;
   int rc;
   if ((rc = pf.upload(hp))) return rc;
   const int64_t w_pad = (nrhs + 15) / 16 * 16, n_pad = hp.n_pad;
   DevBuf db, delta, ypk, dout, nf, dth;
-  if (db.ensure((size_t)nrhs * n * 8) || delta.ensure((size_t)w_pad * n_pad * 8) || ypk.ensure((size_t)w_pad * n_pad * 8) ||
+  if (db.ensure((size_t)nrhs * n * 8) || delta.ensure((size_t)w_pad * n_pad * 8) || ypk.ensure((size_t)w_pad * n_pad * 8 + CF_YPK_SLACK) ||
       dout.ensure((size_t)w_pad * 8) || nf.ensure(8) || dth.ensure(8))
     return CF_ERR_HIP;
   HIP_TRY(hipMemcpy(db.p, b, (size_t)nrhs * n * 8, hipMemcpyHostToDevice));
@@ -535,7 +556,7 @@ extern "C" int cf_selftest_pack_host(const double* L, int64_t n, int64_t ld, con
                                      int64_t* packed_bytes) {
   if (!L || !b || !chi2_out) return fail(CF_ERR_INVALID, "cf_selftest_pack_host: null argument");
   cf_host_pack hp;
-  if (cf_pack_cholesky(L, n, ld, hp, default_ksplit()) != 0) return fail(CF_ERR_NOT_POSDEF, "cf_selftest_pack_host: bad pivot");
+  if (pack_default(L, n, ld, hp) != 0) return fail(CF_ERR_NOT_POSDEF, "cf_selftest_pack_host: bad pivot");
   *chi2_out = cf_pack_replay_host(hp, b);
   if (packed_bytes) *packed_bytes = (int64_t)(hp.frags.size() * sizeof(cf_d2));
   return CF_OK;

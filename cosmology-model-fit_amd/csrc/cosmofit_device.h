@@ -70,15 +70,17 @@ typedef struct { double x, y; } cf_d2;
 #endif
 
 // Packed Cholesky factor: fragment streams per (block row, wave). Offsets in 1 KiB fragments.
-// ksplit = K-split of the update phase: the workgroup has 4*ksplit waves; wave (wq = wave&3,
-// g = wave>>2) updates the tiles wq, wq+4, .. of the block row with the K-step pairs
-// [g*n, (g+1)*n), n = 32 b / ksplit.
+// The solve workgroup has NW = tclasses*ksplit waves.  In the update phase wave
+// (tq = wave % tclasses, g = wave / tclasses) owns the tiles tq, tq+tclasses, .. of the block row
+// and the K-step pairs [g*n, (g+1)*n), n = 32 b / ksplit.
 struct cf_dev_pack {
   const cf_d2* frags;
-  const int64_t* upd_off;   // [n_blocks*4*ksplit]  index (b*4 + wq)*ksplit + g
-  const int64_t* diag_off;  // [n_blocks*4*ksplit]  index b*NW + wave
+  const int64_t* upd_off;   // [n_blocks*NW]  index (b*tclasses + tq)*ksplit + g
+  const int64_t* diag_off;  // [n_blocks*NW]  index b*NW + wave
   int32_t n_blocks;
   int32_t ksplit;
+  int32_t tclasses;
+  int32_t pad;
 };
 
 #ifdef __HIPCC__

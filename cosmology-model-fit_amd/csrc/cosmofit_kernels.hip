@@ -292,59 +292,67 @@ __device__ double finalize_value(const cf_dev_desc& d, const double* __restrict_
 //   diag stream   (b, v)    : [sl2 <= 2 mlmax + 1][slot j < 16/NW][lane] -> the same for inv(L_bb),
 //                             tile of slot j = cf_diag_tile(NW, v, j)
 // ------------------------------------------------------------------------------------------------
-#define CF_PREFETCH 4
-#define CF_DIAG_PREFETCH 4
 
 __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-template <int NT>
-__device__ __forceinline__ void update_loop(d4 (&acc)[4], const d2* __restrict__ A, const d2* __restrict__ Yp,
+template <int NT, int PF, int NTU>
+__device__ __forceinline__ void update_loop(d4 (&acc)[NTU], const d2* __restrict__ A, const d2* __restrict__ Yp,
                                             int n_s2, int lane) {
-  // Software pipeline of depth CF_PREFETCH over K-step pairs; n_s2 is a multiple of CF_PREFETCH.
-  d2 a[CF_PREFETCH][NT];
-  d2 yb[CF_PREFETCH];
+  // Software pipeline of depth PF over K-step pairs (n_s2 is a multiple of PF).  Branch-free body:
+  // stage p is consumed by its 2*NT MFMAs and then immediately refilled with the fragments of step
+  // s2+p+PF.  The refill of the last PF steps reads past the wave's range (the next stream / Y
+  // fragments that are not needed) -- both buffers carry slack for that, and the values are unused.
+  d2 a[PF][NT];
+  d2 yb[PF];
+  const d2* Ap = A + lane;
+  const d2* Yq = Yp + lane;
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int p = 0; p < CF_PREFETCH; ++p) {
+  for (int p = 0; p < PF; ++p) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) a[p][j] = A[((int64_t)p * NT + j) * 64 + lane];
-    yb[p] = Yp[(int64_t)p * 64 + lane];
+    for (int j = 0; j < NT; ++j) a[p][j] = Ap[(p * NT + j) * 64];
+    yb[p] = Yq[p * 64];
+    __builtin_amdgcn_sched_barrier(0);  // keep the fill in stage order: stage 0 must be the OLDEST load
   }
-  for (int s2 = 0; s2 < n_s2; s2 += CF_PREFETCH) {
+  Ap += PF * NT * 64;
+  Yq += PF * 64;
+  for (int s2 = 0; s2 < n_s2; s2 += PF) {
 #pragma unroll
-    for (int p = 0; p < CF_PREFETCH; ++p) {
-      d2 ca[NT];
+    for (int p = 0; p < PF; ++p) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) ca[j] = a[p][j];
-      d2 cy = yb[p];
-      const int nxt = s2 + p + CF_PREFETCH;
-      if (nxt < n_s2) {
+      for (int j = 0; j < NT; ++j) acc[j] = mfma_f64(a[p][j].x, yb[p].x, acc[j]);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) a[p][j] = A[((int64_t)nxt * NT + j) * 64 + lane];
-        yb[p] = Yp[(int64_t)nxt * 64 + lane];
-      }
+      for (int j = 0; j < NT; ++j) acc[j] = mfma_f64(a[p][j].y, yb[p].y, acc[j]);
+      // hipcc's scheduler otherwise hoists every refill to the top of the iteration and drains
+      // them with vmcnt(0) at its end, which exposes one full memory latency per iteration
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = mfma_f64(ca[j].x, cy.x, acc[j]);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = mfma_f64(ca[j].y, cy.y, acc[j]);
+      for (int j = 0; j < NT; ++j) a[p][j] = Ap[(p * NT + j) * 64];
+      yb[p] = Yq[p * 64];
+      __builtin_amdgcn_sched_barrier(0);
     }
+    Ap += PF * NT * 64;
+    Yq += PF * 64;
   }
 }
 
-template <int KS>
-__global__ void __launch_bounds__(256 * KS)
+template <int KS, int TC>
+__global__ void __launch_bounds__(64 * KS * TC)
 trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* __restrict__ theta, int64_t W,
                  const double* __restrict__ delta, d2* __restrict__ ypk, const double* __restrict__ chi2_extra,
                  double* __restrict__ out, int out_kind, unsigned long long* nonfinite) {
-  constexpr int NW = 4 * KS;
-  constexpr int NTD = CF_BLOCK_TILES / NW;
+  constexpr int NW = TC * KS;                  // waves per workgroup
+  constexpr int NTU = CF_BLOCK_TILES / TC;     // tiles per wave in the update phase
+  constexpr int NTD = CF_BLOCK_TILES / NW;     // tiles per wave in the diagonal phase
+  constexpr int CF_DIAG_PREFETCH = NW == 16 ? 2 : 4;
   constexpr int PANEL_FRAGS = CF_BLOCK_ROWS / 8 * 64;  // one 256x16 block as B fragments: 2048 d2 = 32 KB
   extern __shared__ __align__(16) d2 ldsP[];            // [KS][PANEL_FRAGS] partial right-hand sides
   __shared__ double chi_part[NW][16];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wq = wave & 3, g = wave >> 2;
+  const int wq = wave % TC, g = wave / TC;
   const int col = lane & 15, kq = lane >> 4;
   const int64_t panel = blockIdx.x;
   const int64_t w0 = panel * 16;
@@ -356,7 +364,7 @@ trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* __restrict__ theta
 
   for (int b = 0; b < pk.n_blocks; ++b) {
     const int tiles_b = min(CF_BLOCK_TILES, T - b * CF_BLOCK_TILES);
-    const int nt = tiles_b > wq ? (tiles_b - wq + 3) / 4 : 0;
+    const int nt = tiles_b > wq ? (tiles_b - wq + TC - 1) / TC : 0;
     const int r0 = b * CF_BLOCK_ROWS;
     // diagonal-phase stream of this wave: start its first loads now, they land during the update
     int ml[NTD], ml_max = -1;
@@ -375,41 +383,49 @@ trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* __restrict__ theta
         for (int j = 0; j < NTD; ++j) da[p][j] = D[((int64_t)p * NTD + j) * 64 + lane];
     }
     // residual tile in C layout (row = 4r + kq inside the tile); K-split groups > 0 start from zero
-    d4 acc[4];
+    d4 acc[NTU];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NTU; ++j) {
       acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
       if (j < nt && g == 0) {
-        const double* p = dcol + r0 + 16 * (wq + 4 * j) + kq;
+        const double* p = dcol + r0 + 16 * (wq + TC * j) + kq;
         acc[j] = (d4){p[0], p[4], p[8], p[12]};
       }
     }
     // ---- off-diagonal update: acc += (-L[b, K range of g]) * Y[K range of g] ----
     if (b > 0 && nt > 0) {
-      const d2* A = pk.frags + pk.upd_off[(b * 4 + wq) * KS + g] * 64;
+      const d2* A = pk.frags + pk.upd_off[(b * TC + wq) * KS + g] * 64;
       const int n_s2 = r0 / 8 / KS;
       const d2* Yg = Yp + (int64_t)g * n_s2 * 64;
-      switch (nt) {
-        case 4: update_loop<4>(acc, A, Yg, n_s2, lane); break;
-        case 3: update_loop<3>(acc, A, Yg, n_s2, lane); break;
-        case 2: update_loop<2>(acc, A, Yg, n_s2, lane); break;
-        default: update_loop<1>(acc, A, Yg, n_s2, lane); break;
+      constexpr int PF = (NW == 16 && NTU == 4) ? 2 : 4;  // 16 waves leave 128 VGPRs per lane
+      if constexpr (NTU == 4) {
+        switch (nt) {
+          case 4: update_loop<4, PF, NTU>(acc, A, Yg, n_s2, lane); break;
+          case 3: update_loop<3, PF, NTU>(acc, A, Yg, n_s2, lane); break;
+          case 2: update_loop<2, PF, NTU>(acc, A, Yg, n_s2, lane); break;
+          default: update_loop<1, PF, NTU>(acc, A, Yg, n_s2, lane); break;
+        }
+      } else {
+        if (nt == 2) update_loop<2, PF, NTU>(acc, A, Yg, n_s2, lane);
+        else update_loop<1, PF, NTU>(acc, A, Yg, n_s2, lane);
       }
     }
     // ---- publish this wave's partial right-hand side as B fragments in LDS ----
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NTU; ++j)
       if (j < nt) {
-        const int t = wq + 4 * j;
+        const int t = wq + TC * j;
         ldsP[g * PANEL_FRAGS + (2 * t) * 64 + lane] = (d2){acc[j][0], acc[j][1]};
         ldsP[g * PANEL_FRAGS + (2 * t + 1) * 64 + lane] = (d2){acc[j][2], acc[j][3]};
       }
     __syncthreads();
     // ---- diagonal block through its inverse: y = inv(L_bb) * rhs (lower triangular) ----
     if (ml_max >= 0) {
-      d4 y[NTD];
+      // two accumulation chains per tile (even / odd K-steps): the dependent-MFMA latency, not the
+      // issue rate, bounds this short loop
+      d4 y[NTD], y2[NTD];
 #pragma unroll
-      for (int j = 0; j < NTD; ++j) y[j] = (d4){0.0, 0.0, 0.0, 0.0};
+      for (int j = 0; j < NTD; ++j) y[j] = y2[j] = (d4){0.0, 0.0, 0.0, 0.0};
       const int n_sl2 = 2 * ml_max + 2;
       for (int s0 = 0; s0 < n_sl2; s0 += CF_DIAG_PREFETCH) {
 #pragma unroll
@@ -433,11 +449,13 @@ trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* __restrict__ theta
             for (int j = 0; j < NTD; ++j)
               if (sl2 <= 2 * ml[j] + 1) {
                 y[j] = mfma_f64(ca[j].x, tb.x, y[j]);
-                y[j] = mfma_f64(ca[j].y, tb.y, y[j]);
+                y2[j] = mfma_f64(ca[j].y, tb.y, y2[j]);
               }
           }
         }
       }
+#pragma unroll
+      for (int j = 0; j < NTD; ++j) y[j] += y2[j];
 #pragma unroll
       for (int j = 0; j < NTD; ++j)
         if (ml[j] >= 0) {
@@ -465,12 +483,13 @@ trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* __restrict__ theta
   }
 }
 
-template __global__ void trsm_chi2_kernel<1>(cf_dev_desc, cf_dev_pack, const double*, int64_t, const double*, d2*,
-                                             const double*, double*, int, unsigned long long*);
-template __global__ void trsm_chi2_kernel<2>(cf_dev_desc, cf_dev_pack, const double*, int64_t, const double*, d2*,
-                                             const double*, double*, int, unsigned long long*);
-template __global__ void trsm_chi2_kernel<4>(cf_dev_desc, cf_dev_pack, const double*, int64_t, const double*, d2*,
-                                             const double*, double*, int, unsigned long long*);
+#define CF_INSTANTIATE_TRSM(KS, TC)                                                                                  \
+  template __global__ void trsm_chi2_kernel<KS, TC>(cf_dev_desc, cf_dev_pack, const double*, int64_t, const double*, \
+                                                    d2*, const double*, double*, int, unsigned long long*);
+CF_INSTANTIATE_TRSM(1, 4)
+CF_INSTANTIATE_TRSM(2, 4)
+CF_INSTANTIATE_TRSM(4, 4)
+CF_INSTANTIATE_TRSM(2, 8)
 
 // ------------------------------------------------------------------------------------------------
 // Likelihoods without an SN block: only the epilogue.
