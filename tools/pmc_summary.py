@@ -17,3 +17,24 @@ for k, cs in acc.items():
 txt = "\n".join(lines)
 print(txt)
 open(os.path.join(out, "pmc_summary.txt"), "w").write(txt + "\n")
+
+# HBM-side traffic per launch, corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE (KB) counts
+# 128-B read requests at 64 B -> double it; WRITE_SIZE (KB) is exact for 16-B-per-lane streaming stores.
+import json
+traffic = {}
+for k, cs in acc.items():
+    if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        name = "trsm_chi2_kernel" if "trsm" in k else ("sn_residual_kernel" if "sn_residual" in k else None)
+        if name:
+            f = cs["FETCH_SIZE"][2:] or cs["FETCH_SIZE"]
+            w = cs["WRITE_SIZE"][2:] or cs["WRITE_SIZE"]
+            fk, wk = sum(f) / len(f), sum(w) / len(w)
+            traffic[name] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_bytes_per_launch": (2 * fk + wk) * 1024}
+cfg = {}
+try:
+    cfg = json.load(open(os.path.join(out, "pass1.json")))["config"]
+except Exception:
+    pass
+json.dump({"config": {k: cfg.get(k) for k in ("n_sn", "walkers_per_gpu", "n_grid")}, "kernels": traffic,
+           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE) KB (gfx950 correction)"},
+          open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
