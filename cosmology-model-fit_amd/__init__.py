@@ -11,5 +11,15 @@ from ._lib import (CF_FDE_CPL, CF_FDE_LCDM, CF_FDE_THAWING, CF_FDE_WCDM, CF_OUT_
 from .engine import C_KM_S, LikelihoodEngine, Param
 from . import interpolator, solve_triangular, sn_pantheon, synthetic
 
+
+
+def __getattr__(name):
+    # `ensemble` needs torch; import it lazily so that ctypes-only users do not pay for it
+    if name == "ensemble":
+        import importlib
+        return importlib.import_module(__name__ + ".ensemble")
+    raise AttributeError(name)
+
+
 __all__ = ["LikelihoodEngine", "Param", "CosmofitError", "build", "lib", "interpolator", "solve_triangular",
            "sn_pantheon", "C_KM_S"]

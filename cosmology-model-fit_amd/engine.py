@@ -135,6 +135,22 @@ class LikelihoodEngine:
         L.check(L.lib().cf_eval_device(self._h, C.c_void_p(theta_ptr), W, C.c_void_p(out_ptr), kind,
                                        C.c_void_p(stream)))
 
+    def torch_log_prob(self, kind: int = L.CF_OUT_LOGP):
+        """Callable ``f(theta: cuda float64 tensor [W, ndim]) -> tensor [W]`` evaluating on the tensor's device
+        with the HIP kernels, asynchronously on torch's current stream (for ``ensemble.ShardedEnsemble``)."""
+        import torch
+
+        def f(theta):
+            if not theta.is_cuda or theta.dtype != torch.float64 or not theta.is_contiguous():
+                raise ValueError("theta must be a contiguous float64 tensor on the engine's GPU")
+            out = torch.empty(theta.shape[0], dtype=torch.float64, device=theta.device)
+            if theta.shape[0]:
+                self.eval_device(theta.data_ptr(), theta.shape[0], out.data_ptr(), kind,
+                                 torch.cuda.current_stream(theta.device).cuda_stream)
+            return out
+
+        return f
+
     def parts(self, theta):
         """DM(z_cmb), mu_corr, residual and chi^2 blocks of a (small) batch — for plots and tests."""
         th = np.atleast_2d(_f64(theta))

@@ -1,0 +1,154 @@
+"""
+Walker ensemble sharded over the GPUs of one node.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests).
+Rank r owns a contiguous slice of the W walkers.  The log-probability of a walker depends only on its own
+theta, so the evaluation itself needs no collective; the ensemble MOVE does: a red/blue half-step draws the
+partner of every active walker from the complementary half, which lives on all ranks -> one all-gather of the
+walker positions per half-step (W_local x ndim doubles per rank; 128 KiB at 4096 x 4: latency-bound, so a
+single flat all-gather, no bucketing).
+
+The move implemented here is the Goodman & Weare stretch move (emcee's default, used by the reference's
+quasars/ scripts; sn/pantheon.py:114-117 mixes KDE and DE moves, which need the same gathered complementary
+set).  Random numbers come from a counter-based generator keyed on (seed, step, half, GLOBAL walker index,
+stream), so a chain is bit-identical for any number of ranks — that is what the gloo tests check.
+
+`log_prob_fn(theta[W, ndim] tensor) -> tensor[W]` is pluggable: on a GPU it is
+``LikelihoodEngine.torch_log_prob`` (HIP kernels through cf_eval_device on the current stream).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Optional, Tuple
+
+import torch
+
+try:
+    import torch.distributed as dist
+except Exception:  # pragma: no cover
+    dist = None
+
+
+def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, near-equal slices: the first (n_total % world) ranks own one walker more."""
+    base, extra = divmod(n_total, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+# ---- counter-based uniform random numbers (splitmix64 finaliser), identical on CPU and GPU -----------------
+_M1 = -7046029254386353131  # 0x9E3779B97F4A7C15 as int64
+_M2 = -4658895280553007687  # 0xBF58476D1CE4E5B9
+_M3 = -7723592293110705685  # 0x94D049BB133111EB
+
+
+def _lsr(x: torch.Tensor, s: int) -> torch.Tensor:
+    """Logical shift right of int64 (torch's >> is arithmetic)."""
+    return (x >> s) & ((1 << (64 - s)) - 1)
+
+
+def _mix(x: torch.Tensor) -> torch.Tensor:
+    x = (x ^ _lsr(x, 30)) * _M2
+    x = (x ^ _lsr(x, 27)) * _M3
+    return x ^ _lsr(x, 31)
+
+
+def uniform01(seed: int, step: int, half: int, walker_ids: torch.Tensor, stream: int) -> torch.Tensor:
+    """float64 uniforms in [0, 1), a pure function of its arguments (walker_ids: int64 tensor)."""
+    key = (seed * 1000003 + step) * 8 + half * 4 + stream
+    key = ((key + 0x5851F42D4C957F2D) & 0xFFFFFFFFFFFFFFFF)
+    key = key - (1 << 64) if key >= (1 << 63) else key  # as signed int64
+    x = _mix(walker_ids * _M1 + key)
+    x = _mix(x + _M1)
+    return _lsr(x, 11).to(torch.float64) * (1.0 / 9007199254740992.0)
+
+
+class ShardedEnsemble:
+    def __init__(self, log_prob_fn: Callable[[torch.Tensor], torch.Tensor], positions: torch.Tensor, *,
+                 seed: int = 42, a: float = 2.0, group=None):
+        """positions: [W_total, ndim] float64 initial ensemble, identical on every rank (it is sliced here)."""
+        self.group = group
+        self.distributed = dist is not None and dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.distributed else 1
+        self.rank = dist.get_rank(group) if self.distributed else 0
+        self.n_total, self.ndim = positions.shape
+        if self.n_total % 2:
+            raise ValueError("the ensemble needs an even number of walkers (two halves)")
+        self.start, self.stop = shard_bounds(self.n_total, self.world, self.rank)
+        self.log_prob_fn = log_prob_fn
+        self.x = positions[self.start:self.stop].clone().contiguous()
+        self.ids = torch.arange(self.start, self.stop, dtype=torch.int64, device=self.x.device)
+        self.seed, self.a, self.step_count = seed, a, 0
+        self.logp = self.log_prob_fn(self.x)
+        self.n_accepted = 0
+        self.n_proposed = 0
+        counts = [shard_bounds(self.n_total, self.world, r) for r in range(self.world)]
+        self._equal = len({b - a_ for a_, b in counts}) == 1
+        self._max_local = max(b - a_ for a_, b in counts)
+        self._counts = counts
+
+    # ---- the exchange step ---------------------------------------------------------------------------
+    def gather_positions(self) -> torch.Tensor:
+        """All walkers' positions [W_total, ndim] on every rank (one collective)."""
+        if self.world == 1:
+            return self.x
+        if self._equal:
+            out = torch.empty((self.n_total, self.ndim), dtype=self.x.dtype, device=self.x.device)
+            dist.all_gather_into_tensor(out, self.x, group=self.group)
+            return out
+        # ragged shards: pad to the largest shard, gather, strip
+        pad = torch.zeros((self._max_local, self.ndim), dtype=self.x.dtype, device=self.x.device)
+        pad[: self.x.shape[0]] = self.x
+        buf = torch.empty((self.world * self._max_local, self.ndim), dtype=self.x.dtype, device=self.x.device)
+        dist.all_gather_into_tensor(buf, pad, group=self.group)
+        return torch.cat([buf[r * self._max_local: r * self._max_local + (b - a_)] for r, (a_, b) in enumerate(self._counts)])
+
+    # ---- one stretch-move step = two half-steps ----------------------------------------------------------
+    def step(self):
+        half_size = self.n_total // 2
+        for half in (0, 1):
+            allpos = self.gather_positions()
+            # active set: walkers with global index parity == half; partners from the other parity
+            active = (self.ids % 2) == half
+            if bool(active.any()):
+                ids = self.ids[active]
+                u_partner = uniform01(self.seed, self.step_count, half, ids, 0)
+                u_z = uniform01(self.seed, self.step_count, half, ids, 1)
+                u_acc = uniform01(self.seed, self.step_count, half, ids, 2)
+                j = torch.clamp((u_partner * half_size).to(torch.int64), max=half_size - 1)
+                partner = allpos[2 * j + (1 - half)]
+                z = ((self.a - 1.0) * u_z + 1.0) ** 2 / self.a
+                xa = self.x[active]
+                y = partner + z[:, None] * (xa - partner)
+                lp_new = self.log_prob_fn(y.contiguous())
+                log_q = (self.ndim - 1) * torch.log(z) + lp_new - self.logp[active]
+                accept = torch.log(u_acc) < log_q
+                idx = torch.nonzero(active, as_tuple=False)[:, 0][accept]
+                self.x[idx] = y[accept]
+                self.logp[idx] = lp_new[accept]
+                self.n_accepted += int(accept.sum())
+                self.n_proposed += int(active.sum())
+        self.step_count += 1
+
+    def run(self, n_steps: int):
+        for _ in range(n_steps):
+            self.step()
+        return self
+
+    def acceptance_fraction(self) -> float:
+        acc = torch.tensor([self.n_accepted, self.n_proposed], dtype=torch.float64, device=self.x.device)
+        if self.world > 1:
+            dist.all_reduce(acc, group=self.group)
+        return float(acc[0] / torch.clamp(acc[1], min=1.0))
+
+    def full_state(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(positions [W_total, ndim], log-prob [W_total]) gathered on every rank (for tests / check-pointing)."""
+        pos = self.gather_positions()
+        if self.world == 1:
+            return pos, self.logp
+        pad = torch.zeros(self._max_local, dtype=self.logp.dtype, device=self.logp.device)
+        pad[: self.logp.shape[0]] = self.logp
+        buf = torch.empty(self.world * self._max_local, dtype=self.logp.dtype, device=self.logp.device)
+        dist.all_gather_into_tensor(buf, pad, group=self.group)
+        lp = torch.cat([buf[r * self._max_local: r * self._max_local + (b - a_)] for r, (a_, b) in enumerate(self._counts)])
+        return pos, lp

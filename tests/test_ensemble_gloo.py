@@ -1,0 +1,96 @@
+"""CPU: the multi-rank ensemble logic (sharding, all-gather of positions, counter-based RNG) on gloo."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import load_pkg
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+MU = torch.tensor([0.3, -1.0, 2.0], dtype=torch.float64)
+SIG = torch.tensor([0.5, 2.0, 0.1], dtype=torch.float64)
+
+
+def gauss_logp(theta):
+    return -0.5 * (((theta - MU) / SIG) ** 2).sum(dim=1)
+
+
+def _init_positions(W):
+    g = torch.Generator().manual_seed(7)
+    return MU + SIG * torch.randn(W, 3, generator=g, dtype=torch.float64)
+
+
+def _worker(rank, world, port, W, steps, path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ens = load_pkg().ensemble.ShardedEnsemble(gauss_logp, _init_positions(W), seed=11)
+    ens.run(steps)
+    pos, lp = ens.full_state()
+    acc = ens.acceptance_fraction()
+    if rank == 0:
+        torch.save({"pos": pos, "lp": lp, "acc": acc}, path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world, W, steps, tmp_path):
+    path = str(tmp_path / f"w{world}.pt")
+    if world == 1:
+        ens = load_pkg().ensemble.ShardedEnsemble(gauss_logp, _init_positions(W), seed=11)
+        ens.run(steps)
+        pos, lp = ens.full_state()
+        return {"pos": pos, "lp": lp, "acc": ens.acceptance_fraction()}
+    mp.spawn(_worker, args=(world, _free_port(), W, steps, path), nprocs=world, join=True)
+    return torch.load(path)
+
+
+def test_shard_bounds_partition():
+    ens = load_pkg().ensemble
+    for n, world in ((4096, 1), (4096, 8), (65536, 8), (10, 3), (7, 8)):
+        cuts = [ens.shard_bounds(n, world, r) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n
+        assert all(cuts[r][1] == cuts[r + 1][0] for r in range(world - 1))
+        sizes = [b - a for a, b in cuts]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_counter_rng_is_a_pure_function_and_uniform():
+    ens = load_pkg().ensemble
+    ids = torch.arange(0, 200000, dtype=torch.int64)
+    u = ens.uniform01(42, 3, 1, ids, 2)
+    assert torch.equal(u, ens.uniform01(42, 3, 1, ids, 2))
+    assert torch.equal(u[1000:2000], ens.uniform01(42, 3, 1, ids[1000:2000], 2)), "must not depend on the shard"
+    assert 0.0 <= float(u.min()) and float(u.max()) < 1.0
+    assert abs(float(u.mean()) - 0.5) < 3e-3 and abs(float(u.var()) - 1 / 12) < 2e-3
+    hist = torch.histc(u, bins=20, min=0, max=1) / len(u)
+    assert float((hist - 0.05).abs().max()) < 3e-3
+    v = ens.uniform01(42, 4, 1, ids, 2)
+    assert abs(float(((u - 0.5) * (v - 0.5)).mean())) < 1e-3  # consecutive steps uncorrelated
+
+
+@pytest.mark.parametrize("world,W", [(2, 64), (3, 50)])
+def test_chain_is_bit_identical_for_any_number_of_ranks(tmp_path, world, W):
+    """world_size 2 (equal shards) and 3 (ragged shards) reproduce the single-process chain exactly."""
+    ref = _run(1, W, 25, tmp_path)
+    got = _run(world, W, 25, tmp_path)
+    assert torch.equal(ref["pos"], got["pos"])
+    assert torch.equal(ref["lp"], got["lp"])
+    assert ref["acc"] == got["acc"] and 0.2 < ref["acc"] < 0.9
+
+
+def test_stretch_move_samples_the_target(tmp_path):
+    out = _run(1, 512, 300, tmp_path)
+    pos = out["pos"]
+    assert torch.allclose(pos.mean(0), MU, atol=float(4 * SIG.max() / np.sqrt(512)))
+    assert torch.allclose(pos.std(0), SIG, rtol=0.2)
+    assert torch.allclose(out["lp"], gauss_logp(pos))

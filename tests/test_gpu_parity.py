@@ -205,3 +205,26 @@ def test_nonfinite_is_minus_inf_and_counted(gpu):
     assert np.isfinite(lp[0]) and lp[1] == -np.inf
     assert lk.engine.info()["nonfinite_count"] == 1
     lk.engine.close()
+
+
+# ---- 8e / 8f-1: device-resident ensemble driving the HIP path through cf_eval_device -----------------------
+def test_device_ensemble_stretch_move_matches_oracle_driven_chain(gpu):
+    torch = pytest.importorskip("torch")
+    from oracle import oracle_c, oracle_np as onp
+
+    syn = gpu.synthetic.pantheon_like(n_sn=200, seed=5)
+    lk = gpu.sn_pantheon.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"])
+    co = oracle_c.COracle(onp.Likelihood(
+        ndim=4, z_max=lk.z_max, offset=onp.Slot(0), H0=onp.Slot(1), Om=onp.Slot(2), v=onp.Slot(3),
+        z_cmb=syn["z_cmb"], z_hel=syn["z_hel"], obs=syn["obs"], chol=syn["chol"],
+        bounds=gpu.sn_pantheon.bounds, gauss=[gpu.sn_pantheon.H0_PRIOR]))
+    start = gpu.synthetic.THETA_TRUE + 1e-2 * np.random.default_rng(1).standard_normal((96, 4))
+    ens_gpu = gpu.ensemble.ShardedEnsemble(lk.engine.torch_log_prob(), torch.from_numpy(start).to("cuda:0"), seed=3)
+    ens_cpu = gpu.ensemble.ShardedEnsemble(lambda t: torch.from_numpy(co.logp(t.numpy())), torch.from_numpy(start), seed=3)
+    ens_gpu.run(12)
+    ens_cpu.run(12)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(ens_gpu.x.cpu().numpy(), ens_cpu.x.numpy(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(ens_gpu.logp.cpu().numpy(), ens_cpu.logp.numpy(), rtol=1e-9)
+    assert ens_gpu.n_accepted == ens_cpu.n_accepted and 0 < ens_gpu.n_accepted < ens_gpu.n_proposed
+    lk.engine.close()
