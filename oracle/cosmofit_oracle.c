@@ -24,6 +24,7 @@
  *   forward substitution     solve_triangular.py:5-14
  *   prior / log_probability  sn/pantheon.py:80-97
  */
+#define _USE_MATH_DEFINES
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -53,6 +54,21 @@ typedef struct co_desc {
   const double* bounds; /* [ndim*2] or NULL */
   int32_t n_gauss, pad;
   const double* gauss; /* [n_gauss*3]: idx, mean, sigma */
+  /* --- physical-density E(z): cmb/data_planck_act_compression.py:29-66 --- */
+  int32_t has_vstep, cpl_wall;
+  double or_h2, omnu_h2, o_gamma_h2, nu_m0, nu_rho0;
+  double nu_qs_sq[5], nu_ws[5];
+  /* --- BAO block: bao/desi_cmb_des5y.py:69-100,132-135 --- */
+  int32_t n_bao, bao_dh_exact, rd_from_fit, pad2;
+  const double *bao_z, *bao_val, *bao_inv_cov;
+  const int32_t* bao_qty;
+  double rd_fit[11];
+  /* --- compressed CMB: cmb/data_planck_act_compression.py:86-212 --- */
+  int32_t cmb_mode, n_gl;
+  const double *gl_x, *gl_w;
+  double cmb_prior[3], cmb_inv_cov[9], zstar_fit[4];
+  int32_t n_chi2_gauss, pad3;
+  const double* chi2_gauss; /* [n*3] */
 } co_desc;
 
 static inline double slot_get(const co_slot* s, const double* th) {
@@ -155,12 +171,86 @@ static double f_de(const co_desc* d, double z, const double* th) {
   }
 }
 
+/* cmb/data_planck_act_compression.py:53-66 */
+static double omnu_z(const co_desc* d, double z) {
+  double zp1 = 1.0 + z;
+  double r = d->nu_m0 / zp1, mz_sq = r * r;
+  double f0 = sqrt(d->nu_qs_sq[0] + mz_sq), f1 = sqrt(d->nu_qs_sq[1] + mz_sq), f2 = sqrt(d->nu_qs_sq[2] + mz_sq);
+  double f3 = sqrt(d->nu_qs_sq[3] + mz_sq), f4 = sqrt(d->nu_qs_sq[4] + mz_sq);
+  double ws = f0 * d->nu_ws[0] + f1 * d->nu_ws[1] + f2 * d->nu_ws[2] + f3 * d->nu_ws[3] + f4 * d->nu_ws[4];
+  double zp1_2 = zp1 * zp1;
+  return zp1_2 * zp1_2 * ws / d->nu_rho0;
+}
+
 static double H_of_z(const co_desc* d, double z, const double* th) {
   double H0 = slot_get(&d->slot[CO_P_H0], th);
-  double Om = slot_get(&d->slot[CO_P_OM], th);
   double zp1 = 1.0 + z, cubed = zp1 * zp1 * zp1;
-  if (d->fde == CO_FDE_LCDM) return H0 * sqrt(Om * cubed + (1.0 - Om)); /* sn/pantheon.py:31 */
-  return H0 * sqrt(Om * cubed + (1.0 - Om) * f_de(d, z, th));             /* bao/desi.py:35 */
+  if (d->ez_model == 0) {
+    double Om = slot_get(&d->slot[CO_P_OM], th);
+    if (d->fde == CO_FDE_LCDM) return H0 * sqrt(Om * cubed + (1.0 - Om)); /* sn/pantheon.py:31 */
+    return H0 * sqrt(Om * cubed + (1.0 - Om) * f_de(d, z, th));             /* bao/desi.py:35 */
+  }
+  /* bao/desi_cmb_des5y.py:34-54 */
+  double h = H0 / 100;
+  double Onu = d->omnu_h2 / (h * h), Or = d->or_h2 / (h * h);
+  double Obc = (slot_get(&d->slot[CO_P_OBH2], th) + slot_get(&d->slot[CO_P_OCH2], th)) / (h * h);
+  double Ode = 1.0 - Obc - Or - Onu;
+  double rad = Or * (cubed * zp1), mat = Obc * cubed, nu = Onu * omnu_z(d, z);
+  double de = d->fde == CO_FDE_LCDM ? Ode : Ode * f_de(d, z, th);
+  return H0 * sqrt(rad + mat + de + nu);
+}
+
+/* cmb/data_planck_act_compression.py:86-99 */
+static double z_star_fit(const double* f, double wb, double wm) {
+  wb = pow(wb, f[2]);
+  wm = pow(wm, f[3]);
+  return pow(wm, -0.7316314841257655) + f[0] * 391.6723594873167 * pow(wb, 0.9368102670600895) * pow(wm, -0.35300106475765136) +
+         f[1] * 937.4224935298015 * pow(wm, 0.0192950634264157) * pow(wb, -0.04285000485853785);
+}
+
+/* cmb/data_planck_act_compression.py:102-124; f = b, m, a1..a9 */
+static double r_drag_fit(const double* f, double wb, double wm) {
+  wb = pow(wb, f[0]);
+  wm = pow(wm, f[1]);
+  double den = (f[2] * pow(wb, f[3])) + (f[4] * pow(wb, f[5]) * pow(wm, f[6])) + (f[7] * pow(wm, f[8]));
+  return 1.0 / den - f[9] / pow(wm, f[10]);
+}
+
+/* cmb/data_planck_act_compression.py:160-212 */
+static void cmb_distances(const co_desc* d, const double* th, double out[3]) {
+  double Ob = slot_get(&d->slot[CO_P_OBH2], th), Oc = slot_get(&d->slot[CO_P_OCH2], th);
+  double Om_h2 = Oc + Ob + d->omnu_h2;
+  double zstar = z_star_fit(d->zstar_fit, Ob, Om_h2);
+  double a_lim = 1.0 / (1.0 + zstar), half = a_lim / 2.0, integral = 0.0;
+  for (int i = 0; i < d->n_gl; i++) {
+    double a = half * d->gl_x[i] + half;
+    double z = (1.0 / a) - 1.0;
+    double Rb = (3.0 / 4.0) * (Ob / d->o_gamma_h2) * a;
+    integral += d->gl_w[i] * (d->c / (a * a * H_of_z(d, z, th) * sqrt(3.0 * (1.0 + Rb))));
+  }
+  double rs_star = half * integral;
+  half = zstar / 2.0;
+  integral = 0.0;
+  for (int i = 0; i < d->n_gl; i++) integral += d->gl_w[i] * (d->c / H_of_z(d, half * d->gl_x[i] + half, th));
+  double DM_star = half * integral;
+  if (d->cmb_mode == 3) { out[0] = rs_star / DM_star; out[1] = Ob; out[2] = Om_h2; return; }
+  out[0] = 100 * sqrt(Om_h2) * DM_star / d->c;
+  out[1] = M_PI * DM_star / rs_star;
+  out[2] = Ob;
+}
+
+static double chi2_cmb(const co_desc* d, const double* th) {
+  double v[3], dl[3];
+  cmb_distances(d, th, v);
+  for (int i = 0; i < 3; i++) dl[i] = d->cmb_prior[i] - v[i];
+  if (d->cmb_mode == 2) return dl[1] * dl[1] * d->cmb_inv_cov[4];
+  double acc = 0.0;
+  for (int j = 0; j < 3; j++) {
+    double t = 0.0;
+    for (int i = 0; i < 3; i++) t += dl[i] * d->cmb_inv_cov[3 * i + j];
+    acc += t * dl[j];
+  }
+  return acc;
 }
 
 /* Per-thread scratch */
@@ -195,18 +285,59 @@ static void dm_grid(const co_desc* d, const double* th, co_work* w) {
   }
 }
 
-/* sn/pantheon.py:43-61; dm_obs / mu_corr may be NULL */
+/* bao/desi_cmb_des5y.py:82-100 (tables already built in w) */
+static void bao_theory(const co_desc* d, const double* th, co_work* w, double* out) {
+  double rd;
+  if (d->rd_from_fit) {
+    double Ob = slot_get(&d->slot[CO_P_OBH2], th), Oc = slot_get(&d->slot[CO_P_OCH2], th);
+    rd = r_drag_fit(d->rd_fit, Ob, Ob + Oc + d->omnu_h2);
+  } else rd = slot_get(&d->slot[CO_P_RD], th);
+  double* slopes = NULL;
+  if (!d->bao_dh_exact) {
+    slopes = (double*)malloc(8 * (size_t)d->n_grid);
+    co_pchip_slopes(w->zg, w->dh, d->n_grid, slopes); /* interpolator.py:113: all 4000 slopes, like the reference */
+  }
+  for (int k = 0; k < d->n_bao; k++) {
+    double z = d->bao_z[k];
+    double DM = cubic_eval(z, w->zg, w->cum, w->dh, d->n_grid, 1);
+    double DH = d->bao_dh_exact ? d->c / H_of_z(d, z, th) : cubic_eval(z, w->zg, w->dh, slopes, d->n_grid, 0);
+    switch (d->bao_qty[k]) {
+      case 2: out[k] = DH / rd; break;
+      case 1: out[k] = DM / rd; break;
+      case 0: out[k] = pow(z * DH * (DM * DM), 1.0 / 3) / rd; break;
+      default: out[k] = DM / DH; break;
+    }
+  }
+  free(slopes);
+}
+
+static double chi2_bao(const co_desc* d, const double* th, co_work* w) {
+  double th_[64], dl[64];
+  bao_theory(d, th, w, th_);
+  for (int k = 0; k < d->n_bao; k++) dl[k] = d->bao_val[k] - th_[k];
+  double acc = 0.0;
+  for (int j = 0; j < d->n_bao; j++) {
+    double t = 0.0;
+    for (int i = 0; i < d->n_bao; i++) t += dl[i] * d->bao_inv_cov[i * d->n_bao + j];
+    acc += t * dl[j];
+  }
+  return acc;
+}
+
+/* sn/pantheon.py:43-61; dm_obs / mu_corr may be NULL.  The distance tables must be in w. */
 static void sn_delta(const co_desc* d, const double* th, co_work* w, double* dm_obs, double* mu_corr_out) {
-  dm_grid(d, th, w);
   double off = slot_get(&d->slot[CO_P_OFFSET], th);
   double v = slot_get(&d->slot[CO_P_V], th);
   for (int64_t i = 0; i < d->n_sn; i++) {
     double zc = d->z_cmb[i];
     double DM = cubic_eval(zc, w->zg, w->cum, w->dh, d->n_grid, 1);
-    double v_km_s = 100 * v * d->step[i];
-    double z_pec = v_km_s / d->c;
-    double z_cosmo = -1.0 + (1.0 + zc) / (1.0 + z_pec);
-    double mu_corr = 5.0 * log10(cubic_eval(z_cosmo, w->zg, w->cum, w->dh, d->n_grid, 1) / DM);
+    double mu_corr = 0.0;
+    if (d->has_vstep) {
+      double v_km_s = 100 * v * d->step[i];
+      double z_pec = v_km_s / d->c;
+      double z_cosmo = -1.0 + (1.0 + zc) / (1.0 + z_pec);
+      mu_corr = 5.0 * log10(cubic_eval(z_cosmo, w->zg, w->cum, w->dh, d->n_grid, 1) / DM);
+    }
     double mu_th = 25.0 + 5 * log10((1.0 + d->z_hel[i]) * DM);
     w->delta[i] = d->obs[i] - off - mu_corr - mu_th;
     if (dm_obs) dm_obs[i] = DM;
@@ -214,9 +345,29 @@ static void sn_delta(const co_desc* d, const double* th, co_work* w, double* dm_
   }
 }
 
-static double chi2_one(const co_desc* d, const double* th, co_work* w) {
-  sn_delta(d, th, w, NULL, NULL);
-  return co_solve_triangular(d->chol, d->n_sn, d->ld, w->delta, w->y);
+/* blocks[0..2] = sn, bao, cmb */
+static double chi2_one_blocks(const co_desc* d, const double* th, co_work* w, double* blocks) {
+  double sn = 0.0, bao = 0.0, cmb = 0.0;
+  if (d->n_sn > 0 || d->n_bao > 0) dm_grid(d, th, w);
+  if (d->n_sn > 0) {
+    sn_delta(d, th, w, NULL, NULL);
+    sn = co_solve_triangular(d->chol, d->n_sn, d->ld, w->delta, w->y);
+  }
+  if (d->n_bao > 0) bao = chi2_bao(d, th, w);
+  if (d->cmb_mode) cmb = chi2_cmb(d, th);
+  if (blocks) { blocks[0] = sn; blocks[1] = bao; blocks[2] = cmb; }
+  double total = cmb + bao + sn; /* bao/desi_cmb_des5y.py:141 */
+  for (int g = 0; g < d->n_chi2_gauss; g++) {
+    double diff = th[(int)d->chi2_gauss[3 * g]] - d->chi2_gauss[3 * g + 1], sg = d->chi2_gauss[3 * g + 2];
+    total += diff * diff / (sg * sg);
+  }
+  return total;
+}
+static double chi2_one(const co_desc* d, const double* th, co_work* w) { return chi2_one_blocks(d, th, w, NULL); }
+
+static double logl_one(const co_desc* d, const double* th, co_work* w) {
+  if (d->cpl_wall && slot_get(&d->slot[CO_P_W0], th) + slot_get(&d->slot[CO_P_WA], th) >= 0.0) return -1e8;
+  return -0.5 * chi2_one(d, th, w);
 }
 
 /* sn/pantheon.py:80-85 */
@@ -257,10 +408,11 @@ int co_eval_batch(const co_desc* d, const double* theta, int64_t W, double* out,
       const double* th = theta + k * d->ndim;
       if (out_kind == 2) {
         double lp = log_prior(d, th); /* likelihood not evaluated outside the box: sn/pantheon.py:90-92 */
-        out[k] = isinf(lp) ? -INFINITY : lp - 0.5 * chi2_one(d, th, &w);
+        out[k] = isinf(lp) ? -INFINITY : lp + logl_one(d, th, &w);
+      } else if (out_kind == 1) {
+        out[k] = logl_one(d, th, &w);
       } else {
-        double c2 = chi2_one(d, th, &w);
-        out[k] = out_kind == 1 ? -0.5 * c2 : c2;
+        out[k] = chi2_one(d, th, &w);
       }
     }
     work_free(&w);
@@ -272,10 +424,20 @@ int co_eval_batch(const co_desc* d, const double* theta, int64_t W, double* out,
 void co_sn_parts(const co_desc* d, const double* th, double* dm_obs, double* mu_corr, double* delta,
                  double* cum_dm, double* dh_grid) {
   co_work w = work_alloc(d);
+  dm_grid(d, th, &w);
   sn_delta(d, th, &w, dm_obs, mu_corr);
   if (delta) memcpy(delta, w.delta, 8 * (size_t)d->n_sn);
   if (cum_dm) memcpy(cum_dm, w.cum, 8 * (size_t)d->n_grid);
   if (dh_grid) memcpy(dh_grid, w.dh, 8 * (size_t)d->n_grid);
+  work_free(&w);
+}
+
+/* chi^2 blocks (sn, bao, cmb), BAO theory vector and CMB distance vector of one walker (pointers may be NULL). */
+void co_blocks(const co_desc* d, const double* th, double* blocks, double* bao_th, double* cmb_vec) {
+  co_work w = work_alloc(d);
+  chi2_one_blocks(d, th, &w, blocks);
+  if (bao_th && d->n_bao > 0) bao_theory(d, th, &w, bao_th);
+  if (cmb_vec && d->cmb_mode) cmb_distances(d, th, cmb_vec);
   work_free(&w);
 }
 

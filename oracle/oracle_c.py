@@ -33,6 +33,17 @@ class _Desc(C.Structure):
         ("bounds", C.c_void_p),
         ("n_gauss", C.c_int32), ("pad", C.c_int32),
         ("gauss", C.c_void_p),
+        ("has_vstep", C.c_int32), ("cpl_wall", C.c_int32),
+        ("or_h2", C.c_double), ("omnu_h2", C.c_double), ("o_gamma_h2", C.c_double), ("nu_m0", C.c_double),
+        ("nu_rho0", C.c_double), ("nu_qs_sq", C.c_double * 5), ("nu_ws", C.c_double * 5),
+        ("n_bao", C.c_int32), ("bao_dh_exact", C.c_int32), ("rd_from_fit", C.c_int32), ("pad2", C.c_int32),
+        ("bao_z", C.c_void_p), ("bao_val", C.c_void_p), ("bao_inv_cov", C.c_void_p), ("bao_qty", C.c_void_p),
+        ("rd_fit", C.c_double * 11),
+        ("cmb_mode", C.c_int32), ("n_gl", C.c_int32),
+        ("gl_x", C.c_void_p), ("gl_w", C.c_void_p),
+        ("cmb_prior", C.c_double * 3), ("cmb_inv_cov", C.c_double * 9), ("zstar_fit", C.c_double * 4),
+        ("n_chi2_gauss", C.c_int32), ("pad3", C.c_int32),
+        ("chi2_gauss", C.c_void_p),
     ]
 
 
@@ -87,6 +98,29 @@ class COracle:
         d.bounds = _p(k["bounds"])
         d.n_gauss = 0 if k["gauss"] is None else len(k["gauss"])
         d.gauss = _p(k["gauss"])
+        d.has_vstep, d.cpl_wall = int(lk.has_vstep), int(lk.cpl_wall)
+        d.or_h2, d.omnu_h2, d.o_gamma_h2, d.nu_m0, d.nu_rho0 = lk.or_h2, lk.omnu_h2, lk.o_gamma_h2, lk.nu_m0, lk.nu_rho0
+        if lk.nu_qs_sq is not None:
+            d.nu_qs_sq[:] = list(lk.nu_qs_sq)
+            d.nu_ws[:] = list(lk.nu_ws)
+        if lk.bao_z is not None:
+            k.update(bao_z=_f64(lk.bao_z), bao_val=_f64(lk.bao_val), bao_inv_cov=_f64(lk.bao_inv_cov),
+                     bao_qty=np.ascontiguousarray(lk.bao_qty, dtype=np.int32))
+            d.n_bao, d.bao_dh_exact = len(k["bao_z"]), int(lk.bao_dh_exact)
+            d.bao_z, d.bao_val, d.bao_inv_cov, d.bao_qty = _p(k["bao_z"]), _p(k["bao_val"]), _p(k["bao_inv_cov"]), _p(k["bao_qty"])
+            d.rd_from_fit = int(lk.rd_fit is not None)
+            if lk.rd_fit is not None:
+                d.rd_fit[:] = list(lk.rd_fit)
+        d.cmb_mode = lk.cmb_mode
+        if lk.cmb_mode:
+            k.update(gl_x=_f64(lk.gl_x), gl_w=_f64(lk.gl_w))
+            d.n_gl, d.gl_x, d.gl_w = len(k["gl_x"]), _p(k["gl_x"]), _p(k["gl_w"])
+            d.cmb_prior[:] = list(lk.cmb_prior)
+            d.cmb_inv_cov[:] = list(np.asarray(lk.cmb_inv_cov).ravel())
+            d.zstar_fit[:] = list(lk.zstar_fit)
+        k["chi2_gauss"] = _f64(np.array(lk.chi2_gauss, dtype=np.float64).reshape(-1, 3)) if len(lk.chi2_gauss) else None
+        d.n_chi2_gauss = 0 if k["chi2_gauss"] is None else len(k["chi2_gauss"])
+        d.chi2_gauss = _p(k["chi2_gauss"])
         self.d = d
         self.threads_used = 1
 
@@ -102,6 +136,16 @@ class COracle:
 
     def logp(self, thetas, nthreads=0):
         return self.eval(thetas, 2, nthreads)
+
+    def logl(self, thetas, nthreads=0):
+        return self.eval(thetas, 1, nthreads)
+
+    def blocks(self, theta):
+        """(chi2 blocks [sn, bao, cmb], bao theory vector, cmb distance vector) of one walker."""
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        b, bt, cv = np.zeros(3), np.zeros(max(self.d.n_bao, 1)), np.zeros(3)
+        lib().co_blocks(C.byref(self.d), _p(th), _p(b), _p(bt), _p(cv))
+        return b, bt[: self.d.n_bao], cv
 
     def sn_parts(self, theta):
         n, G = self.d.n_sn, self.d.n_grid

@@ -161,14 +161,41 @@ class Likelihood:
     step: Optional[np.ndarray] = None  # per-SN sign/weight; None -> from z_turn
     z_turn: float = 0.15
     chol: Optional[np.ndarray] = None
+    has_vstep: bool = True  # False: no peculiar-velocity step at all (z_cosmo = z_cmb, mu_corr = 0)
+    # radiation + massive-neutrino constants of a cmb.data_*_compression module (EZ_PHYSICAL)
+    or_h2: float = 0.0
+    omnu_h2: float = 0.0
+    o_gamma_h2: float = 0.0
+    nu_m0: float = 0.0
+    nu_rho0: float = 1.0
+    nu_qs_sq: Optional[np.ndarray] = None
+    nu_ws: Optional[np.ndarray] = None
+    # BAO block
+    bao_z: Optional[np.ndarray] = None
+    bao_val: Optional[np.ndarray] = None
+    bao_qty: Optional[np.ndarray] = None  # 0 DV/rd, 1 DM/rd, 2 DH/rd, 3 F_AP
+    bao_inv_cov: Optional[np.ndarray] = None
+    bao_dh_exact: bool = False  # False: PCHIP on the dh grid; True: c/H(z) at the datum
+    rd_fit: Optional[Sequence] = None  # (b, m, a1..a9) -> r_drag fitting formula; None -> slot `rd`
+    # compressed CMB block
+    cmb_mode: int = 0  # 0 none, 1 (R, lA, wb), 2 lA only, 3 (theta*, wb, wm)
+    cmb_prior: Optional[np.ndarray] = None
+    cmb_inv_cov: Optional[np.ndarray] = None  # 3x3 (mode 2: only [1,1] = 1/var is used)
+    zstar_fit: Optional[Sequence] = None  # (s1, s2, b, m)
+    gl_x: Optional[np.ndarray] = None
+    gl_w: Optional[np.ndarray] = None
     # priors
     bounds: Optional[np.ndarray] = None
     gauss: Sequence = ()  # (idx, mean, sigma) on the log-prior
+    chi2_gauss: Sequence = ()  # (idx, mean, sigma) added to chi^2
+    cpl_wall: bool = False  # w0 + wa >= 0 -> log L = -1e8   (bao/desi_fs_lya_cmb.py:118-121)
 
     def __post_init__(self):
         # z_grid / dz exactly as sn/pantheon.py:16-17
         self.z_grid = np.linspace(0, self.z_max, num=self.n_grid)
         self.dz = np.diff(self.z_grid)
+        if self.cmb_mode and self.gl_x is None:
+            self.gl_x, self.gl_w = np.polynomial.legendre.leggauss(100)  # cmb/...:150
         if self.z_cmb is not None and self.step is None:
             self.step = np.where(self.z_cmb <= self.z_turn, 1.0, -1.0)  # sn/pantheon.py:46
 
@@ -190,17 +217,122 @@ def f_de(lk: Likelihood, z, theta):
     raise ValueError(lk.fde)
 
 
+def Omnu_z(lk: Likelihood, z):
+    """5-node massive-neutrino density, cmb/data_planck_act_compression.py:53-66."""
+    zp1 = 1.0 + z
+    mz_sq = (lk.nu_m0 / zp1) ** 2
+    q, w = lk.nu_qs_sq, lk.nu_ws
+    f = [np.sqrt(q[i] + mz_sq) for i in range(5)]
+    weighted_sum = f[0] * w[0] + f[1] * w[1] + f[2] * w[2] + f[3] * w[3] + f[4] * w[4]
+    zp1_2 = zp1 * zp1
+    return zp1_2 * zp1_2 * weighted_sum / lk.nu_rho0
+
+
 def H_z(lk: Likelihood, z, theta):
-    """sn/pantheon.py:28-31 (late-time flat).  (1+z)**3 is evaluated as multiplies, as numba does."""
+    """Late-time flat: sn/pantheon.py:28-31.  Physical densities: bao/desi_cmb_des5y.py:34-54.
+    Integer powers are evaluated as multiplies, as numba does."""
     H0 = lk.H0.get(theta)
+    zp1 = 1.0 + z
+    cubed = zp1 * zp1 * zp1
     if lk.ez_model == EZ_LATE_FLAT:
         Om = lk.Om.get(theta)
-        zp1 = 1.0 + z
-        cubed = zp1 * zp1 * zp1
         if lk.fde == FDE_LCDM:
             return H0 * np.sqrt(Om * cubed + (1.0 - Om))
         return H0 * np.sqrt(Om * cubed + (1.0 - Om) * f_de(lk, z, theta))
-    raise NotImplementedError("EZ_PHYSICAL arrives with the CMB block")
+    h = H0 / 100
+    Onu = lk.omnu_h2 / (h * h)
+    Or = lk.or_h2 / (h * h)
+    Obc = (lk.obh2.get(theta) + lk.och2.get(theta)) / (h * h)
+    Ode = 1.0 - Obc - Or - Onu
+    radiation_term = Or * (cubed * zp1)
+    matter_term = Obc * cubed
+    neutrino_term = Onu * Omnu_z(lk, z)
+    dark_energy_term = Ode * f_de(lk, z, theta) if lk.fde != FDE_LCDM else Ode
+    return H0 * np.sqrt(radiation_term + matter_term + dark_energy_term + neutrino_term)
+
+
+# ---- fitting formulae, cmb/data_planck_act_compression.py:86-124 (arXiv:2106.00428) -------------------------
+def z_star(fit, wb, wm):
+    s1, s2, b, m = fit
+    wb = wb**b
+    wm = wm**m
+    return (
+        wm**-0.7316314841257655
+        + s1 * 391.6723594873167 * wb**0.9368102670600895 * wm**-0.35300106475765136
+        + s2 * 937.4224935298015 * wm**0.0192950634264157 * wb**-0.04285000485853785
+    )
+
+
+def r_drag(fit, wb, wm):
+    b, m, a1, a2, a3, a4, a5, a6, a7, a8, a9 = fit
+    wb = wb**b
+    wm = wm**m
+    term_A_denominator = (a1 * (wb**a2)) + (a3 * (wb**a4) * (wm**a5)) + (a6 * (wm**a7))
+    return 1.0 / term_A_denominator - a8 / (wm**a9)
+
+
+def cmb_distances(lk: Likelihood, theta):
+    """cmb/data_planck_act_compression.py:160-212 (100-node Gauss-Legendre in z and in a)."""
+    Ob_h2, Oc_h2 = lk.obh2.get(theta), lk.och2.get(theta)
+    Om_h2 = Oc_h2 + Ob_h2 + lk.omnu_h2
+    zstar = z_star(lk.zstar_fit, Ob_h2, Om_h2)
+    # rs_z
+    a_lim = 1.0 / (1.0 + zstar)
+    half = a_lim / 2.0
+    integral = 0.0
+    for i in range(len(lk.gl_x)):
+        a = half * lk.gl_x[i] + half
+        z = (1.0 / a) - 1.0
+        Rb = (3.0 / 4.0) * (Ob_h2 / lk.o_gamma_h2) * a
+        integral += lk.gl_w[i] * (lk.c / (a**2 * H_z(lk, z, theta) * np.sqrt(3.0 * (1.0 + Rb))))
+    rs_star = half * integral
+    # DM_z
+    half = zstar / 2.0
+    integral = 0.0
+    for i in range(len(lk.gl_x)):
+        integral += lk.gl_w[i] * (lk.c / H_z(lk, half * lk.gl_x[i] + half, theta))
+    DM_star = half * integral
+    if lk.cmb_mode == 3:  # cmb/data_early_lcdm_compression.py:206-207
+        return np.array([rs_star / DM_star, Ob_h2, Om_h2])
+    R = 100 * np.sqrt(Om_h2) * DM_star / lk.c
+    lA = np.pi * DM_star / rs_star
+    return np.array([R, lA, Ob_h2])
+
+
+def chi2_cmb(lk: Likelihood, theta) -> float:
+    delta = lk.cmb_prior - cmb_distances(lk, theta)
+    if lk.cmb_mode == 2:  # bao/desi_des5y_bbn_theta_star.py:110-111
+        return float(delta[1] ** 2 * lk.cmb_inv_cov[1, 1])
+    return float(delta @ lk.cmb_inv_cov @ delta)  # bao/desi_cmb_des5y.py:126-129
+
+
+def bao_theory(lk: Likelihood, theta, tables=None):
+    """bao/desi_cmb_des5y.py:82-100, bao/desi.py:38-56, bao/desi_cmb.py:79-91."""
+    cum_dm, dh_grid = tables if tables is not None else dm_grid(lk, theta)
+    z, qty = lk.bao_z, lk.bao_qty
+    if lk.rd_fit is not None:
+        Obh2, Och2 = lk.obh2.get(theta), lk.och2.get(theta)
+        rd = r_drag(lk.rd_fit, Obh2, Obh2 + Och2 + lk.omnu_h2)
+    else:
+        rd = lk.rd.get(theta)
+    DM = interp_hermite(z, lk.z_grid, cum_dm, dh_grid)
+    DH = lk.c / H_z(lk, z, theta) if lk.bao_dh_exact else interp_pchip(z, lk.z_grid, dh_grid)
+    out = np.empty(z.size)
+    for k in range(z.size):
+        if qty[k] == 2:
+            out[k] = DH[k] / rd
+        elif qty[k] == 1:
+            out[k] = DM[k] / rd
+        elif qty[k] == 0:
+            out[k] = (z[k] * DH[k] * DM[k] ** 2) ** (1 / 3) / rd
+        else:
+            out[k] = DM[k] / DH[k]
+    return out
+
+
+def chi2_bao(lk: Likelihood, theta, tables=None) -> float:
+    delta = lk.bao_val - bao_theory(lk, theta, tables)
+    return float(delta @ lk.bao_inv_cov @ delta)
 
 
 def dm_grid(lk: Likelihood, theta):
@@ -212,24 +344,52 @@ def dm_grid(lk: Likelihood, theta):
     return cum_dm, dh_grid
 
 
-def sn_parts(lk: Likelihood, theta):
+def sn_parts(lk: Likelihood, theta, tables=None):
     """DM(z_cmb), mu_corr, mu_theory, residual: sn/pantheon.py:43-61."""
-    cum_dm, dh_grid = dm_grid(lk, theta)
+    cum_dm, dh_grid = tables if tables is not None else dm_grid(lk, theta)
     DM = interp_hermite(lk.z_cmb, lk.z_grid, cum_dm, dh_grid)
-    v_km_s = 100 * lk.v.get(theta) * lk.step
-    z_pec = v_km_s / lk.c
-    z_cosmo = -1.0 + (1.0 + lk.z_cmb) / (1.0 + z_pec)
-    mu_corr = 5.0 * np.log10(interp_hermite(z_cosmo, lk.z_grid, cum_dm, dh_grid) / DM)
+    if lk.has_vstep:
+        v_km_s = 100 * lk.v.get(theta) * lk.step
+        z_pec = v_km_s / lk.c
+        z_cosmo = -1.0 + (1.0 + lk.z_cmb) / (1.0 + z_pec)
+        mu_corr = 5.0 * np.log10(interp_hermite(z_cosmo, lk.z_grid, cum_dm, dh_grid) / DM)
+    else:  # bao/desi_des5y_bbn_theta_star.py:94-97: no step term at all
+        mu_corr = np.zeros_like(DM)
     mu_theory = 25.0 + 5 * np.log10((1.0 + lk.z_hel) * DM)
     delta = lk.obs - lk.offset.get(theta) - mu_corr - mu_theory
     return DM, mu_corr, mu_theory, delta
 
 
-def chi_squared(lk: Likelihood, theta) -> float:
-    """sn/pantheon.py:57-61."""
+def chi2_blocks(lk: Likelihood, theta):
+    """(sn, bao, cmb) blocks + Gaussian chi^2 terms; bao/desi_cmb_des5y.py:138-141."""
     theta = np.asarray(theta, dtype=np.float64)
-    *_, delta = sn_parts(lk, theta)
-    return solve_triangular_chi2(lk.chol, delta)
+    tables = dm_grid(lk, theta) if (lk.z_cmb is not None or lk.bao_z is not None) else None
+    sn = bao = cmb = 0.0
+    if lk.z_cmb is not None:
+        *_, delta = sn_parts(lk, theta, tables)
+        sn = solve_triangular_chi2(lk.chol, delta)
+    if lk.bao_z is not None:
+        bao = chi2_bao(lk, theta, tables)
+    if lk.cmb_mode:
+        cmb = chi2_cmb(lk, theta)
+    return sn, bao, cmb
+
+
+def chi_squared(lk: Likelihood, theta) -> float:
+    """sn/pantheon.py:57-61; joint: bao/desi_cmb_des5y.py:138-141."""
+    theta = np.asarray(theta, dtype=np.float64)
+    sn, bao, cmb = chi2_blocks(lk, theta)
+    total = cmb + bao + sn
+    for idx, mean, sigma in lk.chi2_gauss:
+        total += (theta[idx] - mean) ** 2 / sigma**2
+    return total
+
+
+def log_likelihood(lk: Likelihood, theta) -> float:
+    theta = np.asarray(theta, dtype=np.float64)
+    if lk.cpl_wall and lk.w0.get(theta) + lk.wa.get(theta) >= 0.0:
+        return -1e8  # bao/desi_fs_lya_cmb.py:118-121
+    return -0.5 * chi_squared(lk, theta)
 
 
 def log_prior(lk: Likelihood, theta) -> float:
@@ -252,7 +412,7 @@ def log_probability(lk: Likelihood, theta) -> float:
     lp = log_prior(lk, theta)
     if np.isinf(lp):
         return -np.inf
-    return lp - 0.5 * chi_squared(lk, theta)
+    return lp + log_likelihood(lk, theta)
 
 
 def log_probs_vectorized(lk: Likelihood, batch) -> np.ndarray:

@@ -150,9 +150,169 @@ def case_sn_pantheon():
     print("sn_pantheon.npz chi2[:4] =", chi2[:4], "logp[-4:] =", logp[-4:])
 
 
+def _cmb_consts(cmb):
+    """Constants of a cmb.data_*_compression module (data, not code) + spot values of its formulae."""
+    z_probe = np.array([0.0, 0.5, 2.33, 1089.0, 5.0e4, 7.0e6])
+    return dict(
+        cmb_priors=cmb.DISTANCE_PRIORS, cmb_cov=cmb.covariance, cmb_inv_cov=cmb.inv_cov_mat,
+        or_h2=np.float64(cmb.Or_h2), omnu_h2=np.float64(cmb.Omnu_h2), o_gamma_h2=np.float64(cmb.O_GAMMA_H2),
+        nu_m0=np.float64(cmb.m0), nu_rho0=np.float64(cmb.rho0), nu_qs_sq=cmb.qs_sq, nu_ws=cmb.ws,
+        c=np.float64(cmb.c), gl_x=cmb.GL_X, gl_w=cmb.GL_W,
+        omnu_z_probe=z_probe, omnu_z_vals=cmb.Omnu_z(z_probe),
+        fit_wb=np.array([0.0224, 0.02, 0.0225]), fit_wm=np.array([0.14004483, 0.12, 0.16]),
+        zstar_vals=np.array([cmb.z_star(a, b) for a, b in ((0.0224, 0.14004483), (0.02, 0.12), (0.0225, 0.16))]),
+        rdrag_vals=np.array([cmb.r_drag(a, b) for a, b in ((0.0224, 0.14004483), (0.02, 0.12), (0.0225, 0.16))]),
+    )
+
+
+def _bao_inputs(bao, cov, qty, inv):
+    return dict(bao_z=np.array(bao["z"]), bao_val=np.array(bao["value"]), bao_qty=np.asarray(qty, dtype=np.int32),
+                bao_cov=cov, bao_inv_cov=inv)
+
+
+def _uniform(lo_hi, n, rng):
+    lo_hi = np.asarray(lo_hi, dtype=np.float64)
+    return rng.uniform(lo_hi[:, 0], lo_hi[:, 1], size=(n, len(lo_hi)))
+
+
+def case_bao_desi():
+    """bao/desi.py: BAO only, late-time flat + thawing f_DE, fixed r_d, PCHIP D_H, h as parameter."""
+    _enter_reference()
+    import bao.desi as m
+
+    rng = np.random.default_rng(3)
+    thetas = theta_batch(m.bounds, 16, rng)
+    thetas = np.vstack([thetas, [[0.691, 0.297, -1.0], [0.666, 0.312, -0.768]]])  # docstring medians (bao/desi.py:199,225)
+    out = _bao_inputs(m.data, m.cov_matrix, m.bao_qty, m.inv_cov_bao)
+    out.update(bounds=m.bounds, thetas=thetas, rd=np.float64(m.rd), z_max=np.float64(m.z_grid[-1]), c=np.float64(m.c),
+               chi2=np.array([m.chi_squared(t) for t in thetas]),
+               logp=np.array([m.log_probability(t) for t in thetas]),
+               logp_vec32=m.log_probs_vectorized(thetas),
+               theory=np.array([m.bao_theory(m.data["z"], m.bao_qty, t) for t in thetas[:4]]))
+    np.savez_compressed(os.path.join(HERE, "bao_desi.npz"), **out)
+    print("bao_desi.npz chi2 at docstring medians:", out["chi2"][-2:])
+
+
+def case_bao_desi_cmb():
+    """bao/desi_cmb.py: physical-density E(z) (radiation + massive nu) + thawing f_DE (a^3 form), BAO with exact
+    D_H and r_drag fit, early-LCDM (theta*, wb, wm) CMB compression."""
+    _enter_reference()
+    import bao.desi_cmb as m
+
+    cmb = m.cmb
+    rng = np.random.default_rng(4)
+    thetas = theta_batch(m.bounds, 16, rng)
+    thetas = np.vstack([thetas, [[68.40, 0.02237, 0.1172, -1.0 + 1e-9], [67.26, 0.02241, 0.1168, -0.912]]])
+    out = _bao_inputs(m.bao_data, m.bao_cov_matrix, m.quantities, m.inv_cov_bao)
+    out.update(_cmb_consts(cmb))
+    out.update(bounds=m.bounds, thetas=thetas, z_max=np.float64(m.z_grid[-1]),
+               chi2=np.array([m.chi_squared(t) for t in thetas]),
+               logp=np.array([m.log_probability(t) for t in thetas]),
+               theory=np.array([m.bao_theory(m.bao_data["z"], m.quantities, t) for t in thetas[:4]]),
+               cmb_dist=np.array([cmb.cmb_distances(t[1], t[2], t) for t in thetas[:4]]),
+               hz_probe=np.array([m.H_z(np.array([0.0, 0.7, 2.33, 1089.0, 1.0e5]), t) for t in thetas[:4]]))
+    np.savez_compressed(os.path.join(HERE, "bao_desi_cmb.npz"), **out)
+    print("bao_desi_cmb.npz chi2[-2:] =", out["chi2"][-2:])
+
+
+def case_bao_desi_fs_lya_cmb():
+    """bao/desi_fs_lya_cmb.py: CPL f_DE, F_AP data, PCHIP D_H, Planck+ACT (R, l_A, wb) compression, w0+wa wall."""
+    _enter_reference()
+    import bao.desi_fs_lya_cmb as m
+
+    cmb = m.cmb
+    rng = np.random.default_rng(5)
+    box = [(60.0, 75.0), (0.01, 0.03), (0.01, 0.25), (-3.0, 1.0), (-3.0, 2.0)]  # nautilus prior of main()
+    thetas = _uniform(box, 24, rng)
+    thetas[:8, 3] = rng.uniform(-1.2, -0.4, 8)
+    thetas[:8, 4] = rng.uniform(-1.5, 0.3, 8)
+    thetas = np.vstack([thetas, [[67.5, 0.0224, 0.119, -0.8, 0.9], [67.5, 0.0224, 0.119, -1.0, 0.0]]])  # wall / LCDM
+    with np.errstate(all="ignore"):
+        chi2 = np.array([m.chi_squared(t) for t in thetas])
+        logl = np.array([m.log_likelihood(t) for t in thetas])
+    out = _bao_inputs(m.bao, m.cov_mat, m.bao_qty, m.inv_cov)
+    out.update(_cmb_consts(cmb))
+    out.update(thetas=thetas, z_max=np.float64(m.z_grid[-1]), chi2=chi2, logl=logl,
+               chi2_cmb=np.array([m.chi2_cmb(t) for t in thetas[:8]]), chi2_bao=np.array([m.chi2_bao(t) for t in thetas[:8]]),
+               theory=np.array([m.bao_theory(m.bao["z"], m.bao_qty, t) for t in thetas[:4]]),
+               cmb_dist=np.array([cmb.cmb_distances(t[1], t[2], t) for t in thetas[:4]]))
+    np.savez_compressed(os.path.join(HERE, "bao_desi_fs_lya_cmb.npz"), **out)
+    print("bao_desi_fs_lya_cmb.npz logl[-2:] =", logl[-2:], " walls:", int(np.sum(logl == -1e8)))
+
+
+def _inject_dovekie():
+    import pandas as pd
+
+    df = pd.read_csv(os.path.join(REF, "y2025DESdovekie/raw-data/distances.csv"), sep=r"\s+")
+    z = df["zHD"].to_numpy(np.float64)
+    order = np.argsort(z)  # y2025DESdovekie/data.py:29
+    z, zh = z[order], df["zHEL"].to_numpy(np.float64)[order]
+    mu, sig = df["MU"].to_numpy(np.float64)[order], df["MUERR"].to_numpy(np.float64)[order]
+    cov = synthetic_cov(sig)
+    pkg = types.ModuleType("y2025DESdovekie")
+    pkg.__path__ = []
+    mod = types.ModuleType("y2025DESdovekie.data")
+    mod.get_data = lambda: ("DES-SN5YR Dovekie (synthetic cov)", z, zh, mu, cov)
+    mod.effective_sample_size = int(np.round(df["PROBIA_BEAMS"].sum()))
+    sys.modules["y2025DESdovekie"] = pkg
+    sys.modules["y2025DESdovekie.data"] = mod
+    return z, zh, mu, sig
+
+
+def case_bao_desi_cmb_des5y():
+    """bao/desi_cmb_des5y.py (BASELINE config 3 as shipped): SN (N=1820, velocity step) + BAO FS+Lya (PCHIP D_H,
+    F_AP) + Planck+ACT CMB, physical E(z) with thawing f_DE fixed... w0 is NOT a parameter: Ode_z is unused."""
+    _enter_reference()
+    z, zh, mu, sig = _inject_dovekie()
+    import bao.desi_cmb_des5y as m
+
+    cmb = m.cmb
+    rng = np.random.default_rng(6)
+    box = [(-0.5, 0.5), (60.0, 75.0), (0.010, 0.030), (0.01, 0.25), (-4.5, 4.5)]  # nautilus prior of main()
+    thetas = _uniform(box, 16, rng)
+    thetas = np.vstack([thetas, [[0.0, 67.5, 0.0224, 0.119, 0.0], [0.03, 68.0, 0.0225, 0.118, -1.2]]])
+    parts = np.array([[m.chi2_sn(t, m.DM_grid(t)), m.chi2_bao(t, m.DM_grid(t)), m.chi2_cmb(t)] for t in thetas])
+    out = _bao_inputs(m.bao, m.bao_cov_matrix, m.bao_qty, m.inv_cov_bao)
+    out.update(_cmb_consts(cmb))
+    out.update(z_cmb=z, z_hel=zh, obs=mu, sigma=sig, thetas=thetas, z_max=np.float64(m.z_grid[-1]),
+               chi2=np.array([m.chi_squared(t) for t in thetas]), logl=np.array([m.log_likelihood(t) for t in thetas]),
+               chi2_parts=parts,
+               theory=np.array([m.bao_theory(m.bao["z"], m.bao_qty, t, m.DM_grid(t)) for t in thetas[:4]]),
+               cmb_dist=np.array([cmb.cmb_distances(t[2], t[3], t) for t in thetas[:4]]))
+    np.savez_compressed(os.path.join(HERE, "bao_desi_cmb_des5y.npz"), **out)
+    print("bao_desi_cmb_des5y.npz chi2[:3] =", out["chi2"][:3])
+
+
+def case_bao_desi_des5y_bbn_theta_star():
+    """bao/desi_des5y_bbn_theta_star.py (BASELINE config 5 as shipped): SN (no velocity step) + BAO (exact D_H) +
+    l_A only + BBN prior on wb, thawing w0; scipy's solve_triangular."""
+    _enter_reference()
+    z, zh, mu, sig = _inject_dovekie()
+    import bao.desi_des5y_bbn_theta_star as m
+
+    cmb = m.cmb
+    rng = np.random.default_rng(7)
+    thetas = theta_batch(m.bounds, 14, rng)
+    out = _bao_inputs(m.bao_data, m.cov_matrix_bao, m.quantities, m.inv_cov_bao)
+    out.update(_cmb_consts(cmb))
+    with np.errstate(all="ignore"):
+        out.update(z_cmb=z, z_hel=zh, obs=mu, sigma=sig, bounds=m.bounds, thetas=thetas, z_max=np.float64(m.z_grid[-1]),
+                   bbn=np.array([m.bbn.Obh2, m.bbn.Obh2_sigma]),
+                   chi2=np.array([m.chi_squared(t) for t in thetas]),
+                   logp=np.array([m.log_probability(t) for t in thetas]),
+                   theory=np.array([m.bao_theory(m.bao_data["z"], m.quantities, t) for t in thetas[:4]]))
+    np.savez_compressed(os.path.join(HERE, "bao_desi_des5y_bbn_theta_star.npz"), **out)
+    print("bao_desi_des5y_bbn_theta_star.npz chi2[:3] =", out["chi2"][:3])
+
+
 CASES = {
     "interpolator": case_interpolator,
     "sn_pantheon": case_sn_pantheon,
+    "bao_desi": case_bao_desi,
+    "bao_desi_cmb": case_bao_desi_cmb,
+    "bao_desi_fs_lya_cmb": case_bao_desi_fs_lya_cmb,
+    "bao_desi_cmb_des5y": case_bao_desi_cmb_des5y,
+    "bao_desi_des5y_bbn_theta_star": case_bao_desi_des5y_bbn_theta_star,
 }
 
 if __name__ == "__main__":

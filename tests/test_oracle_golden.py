@@ -123,3 +123,199 @@ def test_c_oracle_sn_pantheon(pantheon_golden):
     assert np.all(logp[~finite] == -np.inf)
     # thread count must not change any value (walkers are independent)
     np.testing.assert_array_equal(co.chi2(g["thetas"][finite], nthreads=1), chi2)
+
+
+# ---- BAO / compressed-CMB / physical-density blocks ------------------------------------------------------
+from conftest import load_pkg
+
+
+def _cmbdata(name):
+    return getattr(load_pkg().cmb_data, name)
+
+
+@pytest.mark.parametrize("fixture,comp", [("bao_desi_cmb", "EARLY_LCDM"), ("bao_desi_fs_lya_cmb", "PLANCK_ACT")])
+def test_cmb_constants_match_the_reference_modules(fixture, comp):
+    g, d = golden(fixture), _cmbdata(comp)
+    for key in ("or_h2", "omnu_h2", "o_gamma_h2", "nu_m0", "nu_rho0"):
+        assert d[key] == pytest.approx(float(g[key]), rel=1e-15), key
+    np.testing.assert_allclose(d["nu_qs_sq"], g["nu_qs_sq"], rtol=1e-15)
+    np.testing.assert_allclose(d["nu_ws"], g["nu_ws"], rtol=0)
+    np.testing.assert_allclose(d["cmb_prior"], g["cmb_priors"], rtol=0)
+    np.testing.assert_allclose(d["cmb_inv_cov"], g["cmb_inv_cov"], rtol=1e-13)
+    lk = onp.Likelihood(ndim=1, z_max=1.0, **{k: d[k] for k in ("nu_m0", "nu_rho0", "nu_qs_sq", "nu_ws")})
+    np.testing.assert_allclose(onp.Omnu_z(lk, g["omnu_z_probe"]), g["omnu_z_vals"], rtol=1e-15)
+    for wb, wm, zs, rdv in zip(g["fit_wb"], g["fit_wm"], g["zstar_vals"], g["rdrag_vals"]):
+        assert onp.z_star(d["zstar_fit"], wb, wm) == pytest.approx(zs, rel=1e-15)
+        assert onp.r_drag(d["rd_fit"], wb, wm) == pytest.approx(rdv, rel=1e-14)
+    gx, gw = np.polynomial.legendre.leggauss(100)
+    np.testing.assert_array_equal(gx, g["gl_x"])
+    np.testing.assert_array_equal(gw, g["gl_w"])
+
+
+def _phys(d):
+    return {k: d[k] for k in ("or_h2", "omnu_h2", "o_gamma_h2", "nu_m0", "nu_rho0", "nu_qs_sq", "nu_ws")}
+
+
+def lk_bao_desi(g):
+    return onp.Likelihood(ndim=3, z_max=float(g["z_max"]), fde=onp.FDE_THAWING, H0=onp.Slot(0, 100.0), Om=onp.Slot(1),
+                          w0=onp.Slot(2), rd=onp.Slot(fixed=float(g["rd"])), bao_z=g["bao_z"], bao_val=g["bao_val"],
+                          bao_qty=g["bao_qty"], bao_inv_cov=g["bao_inv_cov"], bounds=g["bounds"])
+
+
+def lk_bao_desi_cmb(g):
+    d = _cmbdata("EARLY_LCDM")
+    return onp.Likelihood(ndim=4, z_max=float(g["z_max"]), ez_model=onp.EZ_PHYSICAL, fde=onp.FDE_THAWING, H0=onp.Slot(0),
+                          obh2=onp.Slot(1), och2=onp.Slot(2), w0=onp.Slot(3), bao_z=g["bao_z"], bao_val=g["bao_val"],
+                          bao_qty=g["bao_qty"], bao_inv_cov=g["bao_inv_cov"], bao_dh_exact=True, rd_fit=d["rd_fit"],
+                          cmb_mode=3, cmb_prior=d["cmb_prior"], cmb_inv_cov=d["cmb_inv_cov"], zstar_fit=d["zstar_fit"],
+                          bounds=g["bounds"], **_phys(d))
+
+
+def lk_bao_desi_fs_lya_cmb(g):
+    d = _cmbdata("PLANCK_ACT")
+    return onp.Likelihood(ndim=5, z_max=float(g["z_max"]), ez_model=onp.EZ_PHYSICAL, fde=onp.FDE_CPL, H0=onp.Slot(0),
+                          obh2=onp.Slot(1), och2=onp.Slot(2), w0=onp.Slot(3), wa=onp.Slot(4), bao_z=g["bao_z"],
+                          bao_val=g["bao_val"], bao_qty=g["bao_qty"], bao_inv_cov=g["bao_inv_cov"], rd_fit=d["rd_fit"],
+                          cmb_mode=1, cmb_prior=d["cmb_prior"], cmb_inv_cov=d["cmb_inv_cov"], zstar_fit=d["zstar_fit"],
+                          cpl_wall=True, **_phys(d))
+
+
+def lk_bao_desi_cmb_des5y(g, chol):
+    d = _cmbdata("PLANCK_ACT")
+    return onp.Likelihood(ndim=5, z_max=float(g["z_max"]), ez_model=onp.EZ_PHYSICAL, fde=onp.FDE_LCDM, offset=onp.Slot(0),
+                          H0=onp.Slot(1), obh2=onp.Slot(2), och2=onp.Slot(3), v=onp.Slot(4), z_cmb=g["z_cmb"],
+                          z_hel=g["z_hel"], obs=g["obs"], z_turn=0.10563, chol=chol, bao_z=g["bao_z"], bao_val=g["bao_val"],
+                          bao_qty=g["bao_qty"], bao_inv_cov=g["bao_inv_cov"], rd_fit=d["rd_fit"], cmb_mode=1,
+                          cmb_prior=d["cmb_prior"], cmb_inv_cov=d["cmb_inv_cov"], zstar_fit=d["zstar_fit"], **_phys(d))
+
+
+def lk_bao_desi_des5y_bbn_theta_star(g, chol):
+    d = _cmbdata("PLANCK_ACT")
+    inv = np.zeros((3, 3))
+    inv[1, 1] = 1.0 / d["cmb_cov"][1, 1]
+    return onp.Likelihood(ndim=5, z_max=float(g["z_max"]), ez_model=onp.EZ_PHYSICAL, fde=onp.FDE_THAWING, offset=onp.Slot(0),
+                          H0=onp.Slot(1), obh2=onp.Slot(2), och2=onp.Slot(3), w0=onp.Slot(4), z_cmb=g["z_cmb"],
+                          z_hel=g["z_hel"], obs=g["obs"], has_vstep=False, chol=chol, bao_z=g["bao_z"], bao_val=g["bao_val"],
+                          bao_qty=g["bao_qty"], bao_inv_cov=g["bao_inv_cov"], bao_dh_exact=True, rd_fit=d["rd_fit"],
+                          cmb_mode=2, cmb_prior=d["cmb_prior"], cmb_inv_cov=inv, zstar_fit=d["zstar_fit"],
+                          bounds=g["bounds"], gauss=[(2, float(g["bbn"][0]), float(g["bbn"][1]))], **_phys(d))
+
+
+def _chol_of(g):
+    from scipy.linalg import cho_factor
+    from conftest import synthetic_cov
+    return cho_factor(synthetic_cov(g["sigma"]), lower=True)[0]
+
+
+def test_oracle_bao_desi():
+    g = golden("bao_desi")
+    lk = lk_bao_desi(g)
+    for k in range(4):
+        np.testing.assert_allclose(onp.bao_theory(lk, g["thetas"][k]), g["theory"][k], rtol=1e-13)
+    fin = np.isfinite(g["logp"])
+    for th, c2, lp in zip(g["thetas"], g["chi2"], g["logp"]):
+        got = onp.log_probability(lk, th)
+        if np.isfinite(lp):
+            assert onp.chi_squared(lk, th) == pytest.approx(c2, rel=1e-11)
+            assert got == pytest.approx(lp, rel=1e-11)
+        else:
+            assert got == -np.inf
+    assert fin.sum() >= 18
+    # the reference's batch wrapper returns float32 (bao/desi.py:103): ours is the float64 superset
+    np.testing.assert_allclose(onp.log_probs_vectorized(lk, g["thetas"])[fin].astype(np.float32), g["logp_vec32"][fin], rtol=1e-6)
+
+
+def test_oracle_bao_desi_cmb():
+    g = golden("bao_desi_cmb")
+    lk = lk_bao_desi_cmb(g)
+    for k in range(4):
+        th = g["thetas"][k]
+        np.testing.assert_allclose(onp.H_z(lk, np.array([0.0, 0.7, 2.33, 1089.0, 1.0e5]), th), g["hz_probe"][k], rtol=1e-14)
+        np.testing.assert_allclose(onp.cmb_distances(lk, th), g["cmb_dist"][k], rtol=1e-13)
+        np.testing.assert_allclose(onp.bao_theory(lk, th), g["theory"][k], rtol=1e-13)
+    for th, c2, lp in zip(g["thetas"], g["chi2"], g["logp"]):
+        if np.isfinite(lp):
+            assert onp.chi_squared(lk, th) == pytest.approx(c2, rel=1e-10)
+            assert onp.log_probability(lk, th) == pytest.approx(lp, rel=1e-10)
+        else:
+            assert onp.log_probability(lk, th) == -np.inf
+
+
+def test_oracle_bao_desi_fs_lya_cmb():
+    g = golden("bao_desi_fs_lya_cmb")
+    lk = lk_bao_desi_fs_lya_cmb(g)
+    for k in range(4):
+        th = g["thetas"][k]
+        np.testing.assert_allclose(onp.cmb_distances(lk, th), g["cmb_dist"][k], rtol=1e-13)
+        np.testing.assert_allclose(onp.bao_theory(lk, th), g["theory"][k], rtol=1e-12)
+    for k in range(8):
+        th = g["thetas"][k]
+        assert onp.chi2_cmb(lk, th) == pytest.approx(g["chi2_cmb"][k], rel=1e-9)
+        assert onp.chi2_bao(lk, th) == pytest.approx(g["chi2_bao"][k], rel=1e-10)
+    with np.errstate(all="ignore"):
+        for th, ll in zip(g["thetas"], g["logl"]):
+            got = onp.log_likelihood(lk, th)
+            if ll == -1e8:
+                assert got == -1e8
+            elif np.isfinite(ll):
+                assert got == pytest.approx(ll, rel=1e-9)
+    assert (g["logl"] == -1e8).sum() >= 3
+
+
+def test_oracle_bao_desi_cmb_des5y():
+    g = golden("bao_desi_cmb_des5y")
+    lk = lk_bao_desi_cmb_des5y(g, _chol_of(g))
+    for k in range(4):
+        th = g["thetas"][k]
+        np.testing.assert_allclose(onp.cmb_distances(lk, th), g["cmb_dist"][k], rtol=1e-13)
+        np.testing.assert_allclose(onp.bao_theory(lk, th), g["theory"][k], rtol=1e-12)
+        np.testing.assert_allclose(onp.chi2_blocks(lk, th), g["chi2_parts"][k], rtol=1e-10)
+    for th, c2, ll in zip(g["thetas"][:8], g["chi2"][:8], g["logl"][:8]):
+        assert onp.chi_squared(lk, th) == pytest.approx(c2, rel=1e-11)
+        assert onp.log_likelihood(lk, th) == pytest.approx(ll, rel=1e-11)
+
+
+def test_oracle_bao_desi_des5y_bbn_theta_star():
+    g = golden("bao_desi_des5y_bbn_theta_star")
+    lk = lk_bao_desi_des5y_bbn_theta_star(g, _chol_of(g))
+    for k in range(4):
+        np.testing.assert_allclose(onp.bao_theory(lk, g["thetas"][k]), g["theory"][k], rtol=1e-12)
+    n = 0
+    for th, c2, lp in zip(g["thetas"], g["chi2"], g["logp"]):
+        if np.isfinite(lp):
+            if n < 6:
+                assert onp.chi_squared(lk, th) == pytest.approx(c2, rel=1e-11)
+                assert onp.log_probability(lk, th) == pytest.approx(lp, rel=1e-11)
+                n += 1
+        else:
+            assert onp.log_probability(lk, th) == -np.inf
+
+
+# ---- the C restatement on the joint likelihoods -----------------------------------------------------------
+@pytest.mark.parametrize("name", ["bao_desi", "bao_desi_cmb", "bao_desi_fs_lya_cmb", "bao_desi_cmb_des5y",
+                                  "bao_desi_des5y_bbn_theta_star"])
+def test_c_oracle_joint_likelihoods(name):
+    from oracle import oracle_c as oc
+
+    g = golden(name)
+    build = globals()["lk_" + name]
+    lk = build(g, _chol_of(g)) if "z_cmb" in g else build(g)
+    co = oc.COracle(lk)
+    for k in range(4):
+        blocks, theory, cmbv = co.blocks(g["thetas"][k])
+        np.testing.assert_allclose(theory, g["theory"][k], rtol=1e-12)
+        if "cmb_dist" in g:
+            np.testing.assert_allclose(cmbv, g["cmb_dist"][k], rtol=1e-13)
+        if "chi2_parts" in g:
+            np.testing.assert_allclose(blocks, g["chi2_parts"][k], rtol=1e-10)
+    with np.errstate(all="ignore"):
+        if "logp" in g:
+            fin = np.isfinite(g["logp"])
+            got = co.logp(g["thetas"])
+            np.testing.assert_allclose(got[fin], g["logp"][fin], rtol=1e-10)
+            assert np.all(got[~fin] == -np.inf)
+            np.testing.assert_allclose(co.chi2(g["thetas"][fin]), g["chi2"][fin], rtol=1e-10)
+        if "logl" in g:
+            fin = np.isfinite(g["logl"])
+            got = co.logl(g["thetas"])
+            np.testing.assert_allclose(got[fin], g["logl"][fin], rtol=1e-9)
