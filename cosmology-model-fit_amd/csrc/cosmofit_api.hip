@@ -22,8 +22,9 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // the solve kernel's prefetch reads up to 4 K-step pairs (4 KiB) past the end of a panel's Y range
 #define CF_YPK_SLACK 8192
 
-extern "C" __global__ void sn_residual_kernel(cf_dev_desc d, const double* theta, int64_t W, double* delta,
-                                              double* dm_out, double* mucorr_out);
+extern "C" __global__ void walker_kernel(cf_dev_desc d, const double* theta, int64_t W, double* delta,
+                                         double* chi2_extra, double* dm_out, double* mucorr_out, double* blocks_out,
+                                         double* bao_out);
 template <int KS, int TC>
 __global__ void trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* theta, int64_t W, const double* delta,
                                  d2* ypk, const double* chi2_extra, double* out, int out_kind,
@@ -130,7 +131,9 @@ struct cf_handle {
   cf_dev_desc d{};
   PackedFactor pack;
   DevBuf z_cmb, z_hel, obs, sn_step;
-  DevBuf theta, out, delta, ypk, nonfinite;
+  DevBuf bao_z, bao_val, bao_inv_cov, bao_qty, gl_x, gl_w;
+  DevBuf theta, out, delta, ypk, chi2_extra, nonfinite;
+  bool has_small_blocks = false;  // BAO and / or CMB block present
   int64_t max_walkers = 0;
   int cu_count = 0;
   char arch[64] = {0};
@@ -160,12 +163,15 @@ static int ensure_workspace(cf_handle* h, int64_t W) {
   const int64_t n_pad = h->d.n_pad > 0 ? h->d.n_pad : 16;
   if (h->theta.ensure((size_t)w_pad * (h->d.ndim > 0 ? h->d.ndim : 1) * 8)) return CF_ERR_HIP;
   if (h->out.ensure((size_t)w_pad * 8)) return CF_ERR_HIP;
+  if (h->chi2_extra.ensure((size_t)w_pad * 8)) return CF_ERR_HIP;
   if (h->d.n_sn > 0) {
     if (h->delta.ensure((size_t)w_pad * n_pad * 8)) return CF_ERR_HIP;
     if (h->ypk.ensure((size_t)w_pad * n_pad * 8 + CF_YPK_SLACK)) return CF_ERR_HIP;
     // columns of a partly filled last panel must hold finite numbers
     HIP_TRY(hipMemsetAsync(h->delta.p, 0, (size_t)w_pad * n_pad * 8, h->stream));
     HIP_TRY(hipMemsetAsync(h->ypk.p, 0, (size_t)w_pad * n_pad * 8 + CF_YPK_SLACK, h->stream));
+    // the evaluation may be launched on a caller's stream: the fills must have landed before it starts
+    HIP_TRY(hipStreamSynchronize(h->stream));
   }
   h->max_walkers = w_pad;
   return 0;
@@ -184,10 +190,28 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
     return fail(CF_ERR_INVALID, "cf_create: n_grid must be in 4..8192 (the {cum_dm, dh} table must fit the 160 KB LDS)");
   if (!(c->z_max > 0.0) || !std::isfinite(c->z_max)) return fail(CF_ERR_INVALID, "cf_create: z_max must be > 0");
   if (!(c->c_km_s > 0.0)) return fail(CF_ERR_INVALID, "cf_create: c_km_s must be > 0");
-  if (c->ez_model != CF_EZ_LATE_FLAT) return fail(CF_ERR_UNSUPPORTED, "cf_create: only CF_EZ_LATE_FLAT is built so far");
+  if (c->ez_model != CF_EZ_LATE_FLAT && c->ez_model != CF_EZ_PHYSICAL) return fail(CF_ERR_INVALID, "cf_create: bad ez_model");
   if (c->fde < CF_FDE_LCDM || c->fde > CF_FDE_CPL) return fail(CF_ERR_INVALID, "cf_create: bad fde");
-  if (c->n_bao != 0 || c->cmb_mode != CF_CMB_NONE)
-    return fail(CF_ERR_UNSUPPORTED, "cf_create: BAO / CMB blocks are not built yet");
+  if (c->n_bao < 0 || c->n_bao > CF_MAX_BAO) return fail(CF_ERR_INVALID, "cf_create: n_bao must be in 0..64");
+  if (c->n_bao > 0) {
+    if (!c->bao_z || !c->bao_val || !c->bao_qty || !c->bao_inv_cov)
+      return fail(CF_ERR_INVALID, "cf_create: BAO block arrays must not be null");
+    for (int k = 0; k < c->n_bao; ++k)
+      if (c->bao_qty[k] < CF_BAO_DV || c->bao_qty[k] > CF_BAO_FAP) return fail(CF_ERR_INVALID, "cf_create: bad bao_qty code");
+    if (c->rd_mode != CF_RD_PARAM && c->rd_mode != CF_RD_FIT) return fail(CF_ERR_INVALID, "cf_create: bad rd_mode");
+    if (c->bao_dh_mode != CF_BAO_DH_PCHIP && c->bao_dh_mode != CF_BAO_DH_EXACT)
+      return fail(CF_ERR_INVALID, "cf_create: bad bao_dh_mode");
+    if (c->bao_dh_mode == CF_BAO_DH_PCHIP && c->n_grid < 3) return fail(CF_ERR_INVALID, "cf_create: PCHIP needs >= 3 grid nodes");
+  }
+  if (c->cmb_mode < CF_CMB_NONE || c->cmb_mode > CF_CMB_THETA_WB_WM) return fail(CF_ERR_INVALID, "cf_create: bad cmb_mode");
+  if (c->cmb_mode != CF_CMB_NONE) {
+    if (c->ez_model != CF_EZ_PHYSICAL)
+      return fail(CF_ERR_INVALID, "cf_create: the CMB block needs CF_EZ_PHYSICAL (radiation + neutrinos up to z*)");
+    if (c->n_gl < 1 || c->n_gl > CF_MAX_GL || !c->gl_x || !c->gl_w)
+      return fail(CF_ERR_INVALID, "cf_create: the CMB block needs 1..256 Gauss-Legendre nodes");
+  }
+  if (c->ez_model == CF_EZ_PHYSICAL && !(c->nu_rho0 > 0.0))
+    return fail(CF_ERR_INVALID, "cf_create: CF_EZ_PHYSICAL needs the neutrino constants (nu_rho0 > 0)");
   if (c->n_gauss > CF_MAX_GAUSS || c->n_chi2_gauss > CF_MAX_GAUSS || c->n_gauss < 0 || c->n_chi2_gauss < 0)
     return fail(CF_ERR_INVALID, "cf_create: at most 8 Gaussian terms of each kind");
   for (int s = 0; s < CF_P_NSLOTS; ++s)
@@ -236,6 +260,29 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
   }
   d.n_sn = (int32_t)c->n_sn;
   d.n_pad = (int32_t)((c->n_sn + 15) / 16 * 16);
+  // a velocity step exists if its slot is a parameter or a non-zero constant
+  d.has_vstep = c->param[CF_P_V].idx >= 0 || c->param[CF_P_V].fixed != 0.0;
+  d.or_h2 = c->or_h2;
+  d.omnu_h2 = c->omnu_h2;
+  d.o_gamma_h2 = c->o_gamma_h2;
+  d.nu_m0 = c->nu_m0;
+  d.nu_rho0 = c->nu_rho0;
+  for (int i = 0; i < 5; ++i) {
+    d.nu_qs_sq[i] = c->nu_qs_sq[i];
+    d.nu_ws[i] = c->nu_ws[i];
+  }
+  d.n_bao = c->n_bao;
+  d.bao_dh_exact = c->bao_dh_mode == CF_BAO_DH_EXACT;
+  d.rd_from_fit = c->rd_mode == CF_RD_FIT;
+  for (int i = 0; i < 11; ++i) {
+    d.rd_fit[i] = c->rd_fit[i];
+    d.zstar_fit[i] = c->zstar_fit[i];
+  }
+  d.cmb_mode = c->cmb_mode;
+  d.n_gl = c->cmb_mode ? c->n_gl : 0;
+  for (int i = 0; i < 3; ++i) d.cmb_prior[i] = c->cmb_prior[i];
+  for (int i = 0; i < 9; ++i) d.cmb_inv_cov[i] = c->cmb_inv_cov[i];
+  h->has_small_blocks = c->n_bao > 0 || c->cmb_mode != CF_CMB_NONE;
   d.cpl_wall = c->cpl_wall;
   d.has_bounds = c->bounds != nullptr;
   d.log_norm = 0.0;
@@ -282,6 +329,26 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
     if (pack_default(c->sn_chol, c->n_sn, c->sn_chol_ld, hp) != 0)
       return bail(fail(CF_ERR_NOT_POSDEF, "cf_create: the Cholesky factor has a non-positive or non-finite pivot"));
     if ((rc = h->pack.upload(hp))) return bail(rc);
+  }
+  if (c->n_bao > 0) {
+    int rc;
+    if ((rc = upload_vec(h->bao_z, c->bao_z, c->n_bao))) return bail(rc);
+    if ((rc = upload_vec(h->bao_val, c->bao_val, c->n_bao))) return bail(rc);
+    if ((rc = upload_vec(h->bao_inv_cov, c->bao_inv_cov, (int64_t)c->n_bao * c->n_bao))) return bail(rc);
+    if (h->bao_qty.ensure((size_t)c->n_bao * 4)) return bail(CF_ERR_HIP);
+    if (hipMemcpy(h->bao_qty.p, c->bao_qty, (size_t)c->n_bao * 4, hipMemcpyHostToDevice) != hipSuccess)
+      return bail(fail(CF_ERR_HIP, "hipMemcpy(bao_qty) failed"));
+    d.bao_z = h->bao_z.as<const double>();
+    d.bao_val = h->bao_val.as<const double>();
+    d.bao_inv_cov = h->bao_inv_cov.as<const double>();
+    d.bao_qty = h->bao_qty.as<const int32_t>();
+  }
+  if (c->cmb_mode != CF_CMB_NONE) {
+    int rc;
+    if ((rc = upload_vec(h->gl_x, c->gl_x, c->n_gl))) return bail(rc);
+    if ((rc = upload_vec(h->gl_w, c->gl_w, c->n_gl))) return bail(rc);
+    d.gl_x = h->gl_x.as<const double>();
+    d.gl_w = h->gl_w.as<const double>();
   }
   if (h->nonfinite.ensure(8)) return bail(CF_ERR_HIP);
   if (hipMemset(h->nonfinite.p, 0, 8) != hipSuccess) return bail(fail(CF_ERR_HIP, "hipMemset failed"));
@@ -355,8 +422,8 @@ extern "C" int cf_last_kernel_ms(cf_handle* h, float t[2]) {
 
 template <int KS, int TC>
 static int launch_trsm_t(const cf_dev_desc& d, const cf_dev_pack& pk, const double* d_theta, int64_t W,
-                         const double* delta, d2* ypk, double* d_out, int out_kind, unsigned long long* nf,
-                         hipStream_t st) {
+                         const double* delta, d2* ypk, const double* chi2_extra, double* d_out, int out_kind,
+                         unsigned long long* nf, hipStream_t st) {
   const size_t lds = (size_t)KS * (CF_BLOCK_ROWS / 8 * 64) * sizeof(d2);
   static thread_local int attr_device = -1;  // > 64 KB of dynamic LDS must be allowed once per device
   int dev = 0;
@@ -367,41 +434,45 @@ static int launch_trsm_t(const cf_dev_desc& d, const cf_dev_pack& pk, const doub
   }
   const unsigned panels = (unsigned)((W + 15) / 16);
   hipLaunchKernelGGL((trsm_chi2_kernel<KS, TC>), dim3(panels), dim3(64 * KS * TC), lds, st, d, pk, d_theta, W, delta, ypk,
-                     (const double*)nullptr, d_out, out_kind, nf);
+                     chi2_extra, d_out, out_kind, nf);
   return 0;
 }
 
 static int launch_trsm(const cf_dev_desc& d, const cf_dev_pack& pk, const double* d_theta, int64_t W,
-                       const double* delta, d2* ypk, double* d_out, int out_kind, unsigned long long* nf,
-                       hipStream_t st) {
+                       const double* delta, d2* ypk, const double* chi2_extra, double* d_out, int out_kind,
+                       unsigned long long* nf, hipStream_t st) {
   switch (pk.ksplit * 16 + pk.tclasses) {
-    case 1 * 16 + 4: return launch_trsm_t<1, 4>(d, pk, d_theta, W, delta, ypk, d_out, out_kind, nf, st);
-    case 2 * 16 + 4: return launch_trsm_t<2, 4>(d, pk, d_theta, W, delta, ypk, d_out, out_kind, nf, st);
-    case 4 * 16 + 4: return launch_trsm_t<4, 4>(d, pk, d_theta, W, delta, ypk, d_out, out_kind, nf, st);
-    case 2 * 16 + 8: return launch_trsm_t<2, 8>(d, pk, d_theta, W, delta, ypk, d_out, out_kind, nf, st);
+    case 1 * 16 + 4: return launch_trsm_t<1, 4>(d, pk, d_theta, W, delta, ypk, chi2_extra, d_out, out_kind, nf, st);
+    case 2 * 16 + 4: return launch_trsm_t<2, 4>(d, pk, d_theta, W, delta, ypk, chi2_extra, d_out, out_kind, nf, st);
+    case 4 * 16 + 4: return launch_trsm_t<4, 4>(d, pk, d_theta, W, delta, ypk, chi2_extra, d_out, out_kind, nf, st);
+    case 2 * 16 + 8: return launch_trsm_t<2, 8>(d, pk, d_theta, W, delta, ypk, chi2_extra, d_out, out_kind, nf, st);
   }
   return fail(CF_ERR_INVALID, "bad solve shape");
 }
 
-// Launch the path on `st`: residual kernel, then solve + chi^2 (+ epilogue).
+// Launch the path on `st`: per-walker kernel (distance table, residuals, BAO / CMB blocks), then the
+// blocked solve + chi^2 + epilogue (or the bare epilogue for likelihoods without an SN block).
 static int launch_path(cf_handle* h, const double* d_theta, int64_t W, double* d_out, int out_kind, hipStream_t st,
-                       double* dm_out, double* mucorr_out) {
+                       double* dm_out, double* mucorr_out, double* blocks_out, double* bao_out) {
   const cf_dev_desc& d = h->d;
   unsigned long long* nf = h->nonfinite.as<unsigned long long>();
   hipEvent_t* ev = h->timing_slots ? &h->ev[3 * (h->timed_calls % h->timing_slots)] : nullptr;
   if (ev) HIP_TRY(hipEventRecord(ev[0], st));
-  if (d.n_sn > 0) {
+  const bool walker_work = d.n_sn > 0 || h->has_small_blocks;
+  double* extra = h->has_small_blocks ? h->chi2_extra.as<double>() : nullptr;
+  if (walker_work) {
     // skewed {cum, dh} table: one spare 16-byte slot per 2^chunk_shift nodes
     const size_t lds = ((size_t)d.n_grid + (d.n_grid >> d.chunk_shift) + 2) * 16;
-    hipLaunchKernelGGL(sn_residual_kernel, dim3((unsigned)W), dim3(512), lds, st, d, d_theta, W, h->delta.as<double>(),
-                       dm_out, mucorr_out);
-    if (ev) HIP_TRY(hipEventRecord(ev[1], st));
-    int rc = launch_trsm(d, h->pack.dev, d_theta, W, h->delta.as<const double>(), h->ypk.as<d2>(), d_out, out_kind, nf, st);
+    hipLaunchKernelGGL(walker_kernel, dim3((unsigned)W), dim3(512), lds, st, d, d_theta, W, h->delta.as<double>(), extra,
+                       dm_out, mucorr_out, blocks_out, bao_out);
+  }
+  if (ev) HIP_TRY(hipEventRecord(ev[1], st));
+  if (d.n_sn > 0) {
+    int rc = launch_trsm(d, h->pack.dev, d_theta, W, h->delta.as<const double>(), h->ypk.as<d2>(), extra, d_out, out_kind, nf, st);
     if (rc) return rc;
   } else {
-    if (ev) HIP_TRY(hipEventRecord(ev[1], st));
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, d, d_theta, W,
-                       (const double*)nullptr, d_out, out_kind, nf);
+                       (const double*)extra, d_out, out_kind, nf);
   }
   if (ev) {
     HIP_TRY(hipEventRecord(ev[2], st));
@@ -426,8 +497,8 @@ extern "C" int cf_eval_device(cf_handle* h, const double* d_theta, int64_t W, do
   std::lock_guard<std::mutex> lk(h->mu);
   HIP_TRY(hipSetDevice(h->device));
   if ((rc = ensure_workspace(h, W))) return rc;
-  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
-  return launch_path(h, d_theta, W, d_out, out_kind, st, nullptr, nullptr);
+  // exactly the caller's stream; NULL is HIP's default (null) stream, which is what torch reports as 0
+  return launch_path(h, d_theta, W, d_out, out_kind, (hipStream_t)hip_stream, nullptr, nullptr, nullptr, nullptr);
 }
 
 extern "C" int cf_eval(cf_handle* h, const double* theta, int64_t W, double* out, int32_t out_kind) {
@@ -438,7 +509,8 @@ extern "C" int cf_eval(cf_handle* h, const double* theta, int64_t W, double* out
   HIP_TRY(hipSetDevice(h->device));
   if ((rc = ensure_workspace(h, W))) return rc;
   HIP_TRY(hipMemcpyAsync(h->theta.p, theta, (size_t)W * h->d.ndim * 8, hipMemcpyHostToDevice, h->stream));
-  if ((rc = launch_path(h, h->theta.as<const double>(), W, h->out.as<double>(), out_kind, h->stream, nullptr, nullptr)))
+  if ((rc = launch_path(h, h->theta.as<const double>(), W, h->out.as<double>(), out_kind, h->stream, nullptr, nullptr,
+                        nullptr, nullptr)))
     return rc;
   HIP_TRY(hipMemcpyAsync(out, h->out.p, (size_t)W * 8, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -449,18 +521,23 @@ extern "C" int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, doubl
                              double* delta, double* chi2_blocks, double* bao_theory) {
   if (!h || !theta) return fail(CF_ERR_INVALID, "cf_eval_parts: null argument");
   if (W <= 0 || W > (1 << 20)) return fail(CF_ERR_INVALID, "cf_eval_parts: W out of range");
-  if (bao_theory) return fail(CF_ERR_UNSUPPORTED, "cf_eval_parts: no BAO block");
+  if (bao_theory && h->d.n_bao == 0) return fail(CF_ERR_INVALID, "cf_eval_parts: this likelihood has no BAO block");
+  if ((dm_obs || mu_corr || delta) && h->d.n_sn == 0) return fail(CF_ERR_INVALID, "cf_eval_parts: this likelihood has no SN block");
   std::lock_guard<std::mutex> lk(h->mu);
   HIP_TRY(hipSetDevice(h->device));
   int rc;
   if ((rc = ensure_workspace(h, W))) return rc;
-  const int64_t n = h->d.n_sn, n_pad = h->d.n_pad;
-  DevBuf dm, mc;
-  if (dm_obs && dm.ensure((size_t)W * n * 8)) return CF_ERR_HIP;
-  if (mu_corr && mc.ensure((size_t)W * n * 8)) return CF_ERR_HIP;
+  const int64_t n = h->d.n_sn, n_pad = h->d.n_pad, nb = h->d.n_bao;
+  DevBuf dm, mc, blk, bt;
+  // the SN accessor path (reference-order mu_corr / mu_theory) is selected by a non-null dm / mu_corr buffer
+  if (n > 0 && dm.ensure((size_t)W * n * 8)) return CF_ERR_HIP;
+  if (n > 0 && mu_corr && mc.ensure((size_t)W * n * 8)) return CF_ERR_HIP;
+  if (blk.ensure((size_t)W * 5 * 8)) return CF_ERR_HIP;
+  HIP_TRY(hipMemsetAsync(blk.p, 0, (size_t)W * 5 * 8, h->stream));
+  if (nb > 0 && bt.ensure((size_t)W * nb * 8)) return CF_ERR_HIP;
   HIP_TRY(hipMemcpyAsync(h->theta.p, theta, (size_t)W * h->d.ndim * 8, hipMemcpyHostToDevice, h->stream));
   if ((rc = launch_path(h, h->theta.as<const double>(), W, h->out.as<double>(), CF_OUT_CHI2, h->stream,
-                        dm.as<double>(), mc.as<double>())))
+                        dm.as<double>(), mc.as<double>(), blk.as<double>(), bt.as<double>())))
     return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (dm_obs) HIP_TRY(hipMemcpy(dm_obs, dm.p, (size_t)W * n * 8, hipMemcpyDeviceToHost));
@@ -468,13 +545,24 @@ extern "C" int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, doubl
   if (delta && n > 0)
     HIP_TRY(hipMemcpy2D(delta, (size_t)n * 8, h->delta.p, (size_t)n_pad * 8, (size_t)n * 8, (size_t)W,
                         hipMemcpyDeviceToHost));
+  if (bao_theory) HIP_TRY(hipMemcpy(bao_theory, bt.p, (size_t)W * nb * 8, hipMemcpyDeviceToHost));
   if (chi2_blocks) {
-    std::vector<double> c2((size_t)W);
-    HIP_TRY(hipMemcpy(c2.data(), h->out.p, (size_t)W * 8, hipMemcpyDeviceToHost));
+    std::vector<double> tot((size_t)W), b5((size_t)W * 5);
+    HIP_TRY(hipMemcpy(tot.data(), h->out.p, (size_t)W * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(b5.data(), blk.p, (size_t)W * 5 * 8, hipMemcpyDeviceToHost));
     for (int64_t w = 0; w < W; ++w) {
-      chi2_blocks[3 * w + 0] = c2[w];
-      chi2_blocks[3 * w + 1] = 0.0;
-      chi2_blocks[3 * w + 2] = 0.0;
+      double gauss = 0.0;
+      for (int g = 0; g < h->d.n_chi2_gauss; ++g) {
+        double diff = theta[w * h->d.ndim + h->d.chi2_gauss_idx[g]] - h->d.chi2_gauss_mean[g];
+        gauss += diff * diff / (h->d.chi2_gauss_sigma[g] * h->d.chi2_gauss_sigma[g]);
+      }
+      // sn = total - bao - cmb - Gaussian terms; then bao, cmb, and the CMB distance vector
+      chi2_blocks[6 * w + 0] = tot[w] - b5[5 * w + 0] - b5[5 * w + 1] - gauss;
+      chi2_blocks[6 * w + 1] = b5[5 * w + 0];
+      chi2_blocks[6 * w + 2] = b5[5 * w + 1];
+      chi2_blocks[6 * w + 3] = b5[5 * w + 2];
+      chi2_blocks[6 * w + 4] = b5[5 * w + 3];
+      chi2_blocks[6 * w + 5] = b5[5 * w + 4];
     }
   }
   return CF_OK;
@@ -540,7 +628,7 @@ extern "C" int cf_solve_triangular(const double* L, int64_t n, int64_t ld, const
   cf_dev_desc d{};
   d.n_sn = (int32_t)n;
   d.n_pad = (int32_t)n_pad;
-  if ((rc = launch_trsm(d, pf.dev, dth.as<const double>(), nrhs, delta.as<const double>(), ypk.as<d2>(),
+  if ((rc = launch_trsm(d, pf.dev, dth.as<const double>(), nrhs, delta.as<const double>(), ypk.as<d2>(), nullptr,
                         dout.as<double>(), (int)CF_OUT_CHI2, nf.as<unsigned long long>(), (hipStream_t)0)))
     return rc;
   HIP_TRY(hipGetLastError());

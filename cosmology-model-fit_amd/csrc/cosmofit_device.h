@@ -8,6 +8,8 @@
 
 #define CF_MAX_NDIM 16
 #define CF_MAX_GAUSS 8
+#define CF_MAX_BAO 64
+#define CF_MAX_GL 256
 #define CF_N_SLOTS 9
 
 // One block row of the blocked solve = 16 MFMA tiles of 16 rows.
@@ -19,6 +21,9 @@
 #define CF_FDE_WCDM_D 1
 #define CF_FDE_THAWING_D 2
 #define CF_FDE_CPL_D 3
+
+#define CF_EZ_LATE_FLAT_D 0
+#define CF_EZ_PHYSICAL_D 1
 
 #define CF_P_OFFSET_D 0
 #define CF_P_H0_D 1
@@ -53,6 +58,22 @@ struct cf_dev_desc {
   const double* z_hel;
   const double* obs;
   const double* sn_step;
+  int32_t has_vstep, pad1;  // 0: the likelihood has no peculiar-velocity step (z_cosmo = z_cmb)
+  // radiation + massive neutrinos (CF_EZ_PHYSICAL)   cmb/data_planck_act_compression.py:29-66
+  double or_h2, omnu_h2, o_gamma_h2, nu_m0, nu_rho0;
+  double nu_qs_sq[5], nu_ws[5];
+  // BAO block
+  int32_t n_bao, bao_dh_exact, rd_from_fit, pad2;
+  const double* bao_z;
+  const double* bao_val;
+  const double* bao_inv_cov;
+  const int32_t* bao_qty;
+  double rd_fit[11];
+  // compressed-CMB block
+  int32_t cmb_mode, n_gl;
+  const double* gl_x;
+  const double* gl_w;
+  double cmb_prior[3], cmb_inv_cov[9], zstar_fit[11];
   // priors
   int32_t has_bounds, n_gauss, n_chi2_gauss, cpl_wall;
   double log_norm;  // -sum(log(hi-lo))

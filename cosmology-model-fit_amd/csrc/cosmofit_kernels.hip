@@ -2,7 +2,7 @@
 //
 // Two kernels make the hot path:
 //
-//   sn_residual_kernel  (a1-a10)  one 256-thread workgroup per walker.  E(z) on the G-point grid,
+//   walker_kernel       (a1-a10, a12-a16)  one 512-thread workgroup per walker.  E(z) on the G-point grid,
 //        cumulative trapezoid as chunk-sequential sums + a wave64 shuffle scan + LDS carry, the
 //        two tables (cum_dm, dh) staged in LDS (2*G*8 B = 64 KB), cubic-Hermite at the N data
 //        redshifts and at z_cosmo(theta), mu_corr, mu_theory, residual -> Delta[w][0..Npad).
@@ -38,8 +38,30 @@ __device__ __forceinline__ double slot_get(const cf_dev_desc& d, int s, const do
 // ------------------------------------------------------------------------------------------------
 struct WalkerCosmo {
   double H0, Om, w0, wa, c;
-  int fde;
+  double Or, Obc, Ode, Onu;  // CF_EZ_PHYSICAL densities (omega / h^2)
+  int fde, model;
 };
+
+__device__ __forceinline__ WalkerCosmo make_cosmo(const cf_dev_desc& d, const double* __restrict__ th) {
+  WalkerCosmo wc;
+  wc.H0 = slot_get(d, CF_P_H0_D, th);
+  wc.Om = slot_get(d, CF_P_OM_D, th);
+  wc.w0 = slot_get(d, CF_P_W0_D, th);
+  wc.wa = slot_get(d, CF_P_WA_D, th);
+  wc.c = d.c;
+  wc.fde = d.fde;
+  wc.model = d.ez_model;
+  wc.Or = wc.Obc = wc.Ode = wc.Onu = 0.0;
+  if (d.ez_model == CF_EZ_PHYSICAL_D) {  // bao/desi_cmb_des5y.py:35-39
+    const double h = wc.H0 / 100;
+    const double h2 = h * h;
+    wc.Onu = d.omnu_h2 / h2;
+    wc.Or = d.or_h2 / h2;
+    wc.Obc = (slot_get(d, CF_P_OBH2_D, th) + slot_get(d, CF_P_OCH2_D, th)) / h2;
+    wc.Ode = 1.0 - wc.Obc - wc.Or - wc.Onu;
+  }
+  return wc;
+}
 
 __device__ __forceinline__ double f_de(const WalkerCosmo& wc, double z, double zp1, double cubed) {
   switch (wc.fde) {
@@ -53,21 +75,35 @@ __device__ __forceinline__ double f_de(const WalkerCosmo& wc, double z, double z
   }
 }
 
-__device__ __forceinline__ double dh_of_z(const WalkerCosmo& wc, double z) {
-  double zp1 = 1.0 + z;
-  double cubed = zp1 * zp1 * zp1;
-  double e2 = (wc.fde == CF_FDE_LCDM_D) ? wc.Om * cubed + (1.0 - wc.Om)
-                                        : wc.Om * cubed + (1.0 - wc.Om) * f_de(wc, z, zp1, cubed);
-  return wc.c / (wc.H0 * sqrt(e2));
+// 5-node massive-neutrino density, cmb/data_planck_act_compression.py:53-66
+__device__ __forceinline__ double omnu_z(const cf_dev_desc& d, double zp1) {
+  const double r = d.nu_m0 / zp1, mz_sq = r * r;
+  const double ws = sqrt(d.nu_qs_sq[0] + mz_sq) * d.nu_ws[0] + sqrt(d.nu_qs_sq[1] + mz_sq) * d.nu_ws[1] +
+                    sqrt(d.nu_qs_sq[2] + mz_sq) * d.nu_ws[2] + sqrt(d.nu_qs_sq[3] + mz_sq) * d.nu_ws[3] +
+                    sqrt(d.nu_qs_sq[4] + mz_sq) * d.nu_ws[4];
+  const double zp1_2 = zp1 * zp1;
+  return zp1_2 * zp1_2 * ws / d.nu_rho0;
 }
 
-// dh(z) without the sqrt + divide pair: (c/H0) * rsqrt(E^2).  <= 2 ulp from c/(H0*sqrt(E^2)).
-__device__ __forceinline__ double dh_of_z_fast(const WalkerCosmo& wc, double c_over_H0, double z) {
-  double zp1 = 1.0 + z;
-  double cubed = zp1 * zp1 * zp1;
-  double e2 = (wc.fde == CF_FDE_LCDM_D) ? wc.Om * cubed + (1.0 - wc.Om)
-                                        : wc.Om * cubed + (1.0 - wc.Om) * f_de(wc, z, zp1, cubed);
-  return c_over_H0 * rsqrt(e2);
+// E^2(z) of both families.
+__device__ __forceinline__ double e2_of_z(const cf_dev_desc& d, const WalkerCosmo& wc, double z) {
+  const double zp1 = 1.0 + z;
+  const double cubed = zp1 * zp1 * zp1;
+  if (wc.model == CF_EZ_LATE_FLAT_D)
+    return (wc.fde == CF_FDE_LCDM_D) ? wc.Om * cubed + (1.0 - wc.Om)
+                                     : wc.Om * cubed + (1.0 - wc.Om) * f_de(wc, z, zp1, cubed);
+  const double de = (wc.fde == CF_FDE_LCDM_D) ? wc.Ode : wc.Ode * f_de(wc, z, zp1, cubed);
+  return wc.Or * (cubed * zp1) + wc.Obc * cubed + de + wc.Onu * omnu_z(d, zp1);  // bao/desi_cmb_des5y.py:43-48
+}
+
+// H(z) in the reference's form H0 * sqrt(E^2) (used where only a few values are needed).
+__device__ __forceinline__ double H_of_z(const cf_dev_desc& d, const WalkerCosmo& wc, double z) {
+  return wc.H0 * sqrt(e2_of_z(d, wc, z));
+}
+
+// dh(z) = c/H(z) on the grid without the sqrt + divide pair: (c/H0) * rsqrt(E^2), <= 2 ulp away.
+__device__ __forceinline__ double dh_of_z_fast(const cf_dev_desc& d, const WalkerCosmo& wc, double c_over_H0, double z) {
+  return c_over_H0 * rsqrt(e2_of_z(d, wc, z));
 }
 
 // Grid node i of np.linspace(0, z_max, G): i*step, last node forced to z_max (sn/pantheon.py:16).
@@ -145,7 +181,7 @@ __device__ __forceinline__ void build_distance_table(const cf_dev_desc& d, const
   const int n_own = max(0, min(CH, G - g0));
   const double c_over_H0 = wc.c / wc.H0;
   for (int k = 0; k < n_own; ++k)
-    tab[base + k].y = dh_of_z_fast(wc, c_over_H0, grid_z(g0 + k, G, d.step, d.z_max));
+    tab[base + k].y = dh_of_z_fast(d, wc, c_over_H0, grid_z(g0 + k, G, d.step, d.z_max));
   __syncthreads();
   // chunk-local inclusive prefix of the trapezoid terms (node g needs dh[g-1]: the last node of
   // the previous thread's chunk sits at skewed position base-2)
@@ -171,37 +207,100 @@ __device__ __forceinline__ void build_distance_table(const cf_dev_desc& d, const
 }
 
 // ------------------------------------------------------------------------------------------------
-// Kernel A: distance + residual, one 512-thread workgroup per walker.
+// PCHIP of the dh grid at xq (BAO D_H, bao/desi_cmb_des5y.py:88 -> interpolator.py:111-114): the
+// reference builds all G Fritsch-Carlson slopes per walker; only the two at the bracketing nodes
+// are needed, each from a 3-point stencil, with the exact branch logic of interpolator.py:25-66.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double sgn_d(double v) { return (double)((v > 0) - (v < 0)); }
+
+__device__ double pchip_slope_tab(const DistTable& T, int i) {
+  const int n = T.G;
+  auto X = [&](int k) { return grid_z(k, n, T.step, T.z_max); };
+  auto Y = [&](int k) { return T.at(k).y; };
+  if (i > 0 && i < n - 1) {
+    const double hl = X(i) - X(i - 1), hr = X(i + 1) - X(i);
+    const double dl = (Y(i) - Y(i - 1)) / hl, dr = (Y(i + 1) - Y(i)) / hr;
+    if (dl != 0.0 && dr != 0.0 && dl * dr > 0.0) {
+      const double w1 = 2.0 * hr + hl, w2 = hr + 2.0 * hl;
+      return (w1 + w2) / (w1 / dl + w2 / dr);
+    }
+    return 0.0;
+  }
+  double h0, h1, d0, d1;
+  if (i == 0) {
+    h0 = X(1) - X(0); h1 = X(2) - X(1);
+    d0 = (Y(1) - Y(0)) / h0; d1 = (Y(2) - Y(1)) / h1;
+  } else {
+    h0 = X(n - 1) - X(n - 2); h1 = X(n - 2) - X(n - 3);
+    d0 = (Y(n - 1) - Y(n - 2)) / h0; d1 = (Y(n - 2) - Y(n - 3)) / h1;
+  }
+  const double e = ((2 * h0 + h1) * d0 - h0 * d1) / (h0 + h1);
+  if (d0 == 0.0 || sgn_d(e) != sgn_d(d0)) return 0.0;
+  if (sgn_d(d0) != sgn_d(d1) && fabs(e) > fabs(3 * d0)) return 3 * d0;
+  return e;
+}
+
+__device__ double pchip_dh_tab(const DistTable& T, double xi) {
+  const int G = T.G;
+  if (xi <= 0.0) return T.at(0).y;            // clamped outside (exact=False), interpolator.py:80-85
+  if (xi >= T.z_max) return T.at(G - 1).y;
+  int i = (int)(xi * T.inv_step);
+  i = i > G - 2 ? G - 2 : i;
+  if (i > 0 && grid_z(i, G, T.step, T.z_max) >= xi) --i;
+  if (i < G - 2 && grid_z(i + 1, G, T.step, T.z_max) < xi) ++i;
+  const double x0 = grid_z(i, G, T.step, T.z_max);
+  const double h_i = grid_z(i + 1, G, T.step, T.z_max) - x0;
+  const double t = (xi - x0) / h_i;
+  const double t2 = t * t, t3 = t2 * t;
+  const double h00 = 2 * t3 - 3 * t2 + 1, h10 = t3 - 2 * t2 + t, h01 = -2 * t3 + 3 * t2, h11 = t3 - t2;
+  return h00 * T.at(i).y + h10 * h_i * pchip_slope_tab(T, i) + h01 * T.at(i + 1).y + h11 * h_i * pchip_slope_tab(T, i + 1);
+}
+
+// Fitting formulae of arXiv:2106.00428 with the reference's coefficients.
+// zstar_fit = s1, s2, b, m, e0, c1, e1, e2, c2, e3, e4     cmb/data_planck_act_compression.py:86-99
+__device__ double z_star_fit(const double* f, double wb, double wm) {
+  wb = pow(wb, f[2]);
+  wm = pow(wm, f[3]);
+  return pow(wm, f[4]) + f[0] * f[5] * pow(wb, f[6]) * pow(wm, f[7]) + f[1] * f[8] * pow(wm, f[9]) * pow(wb, f[10]);
+}
+// rd_fit = b, m, a1..a9                                    cmb/data_planck_act_compression.py:102-124
+__device__ double r_drag_fit(const double* f, double wb, double wm) {
+  wb = pow(wb, f[0]);
+  wm = pow(wm, f[1]);
+  const double den = (f[2] * pow(wb, f[3])) + (f[4] * pow(wb, f[5]) * pow(wm, f[6])) + (f[7] * pow(wm, f[8]));
+  return 1.0 / den - f[9] / pow(wm, f[10]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Kernel A: one 512-thread workgroup per walker: distance table, SN residual vector, and the small
+// BAO / compressed-CMB blocks of the joint likelihoods.
 //
-// Fast path (dm_out == mucorr_out == NULL): the two magnitude terms of the reference,
+// SN fast path (dm_out == mucorr_out == NULL): the two magnitude terms of the reference,
 //   mu_corr + mu_theory = 5 log10(DM(z_cosmo)/DM(z_cmb)) + 25 + 5 log10((1+z_hel) DM(z_cmb)),
 // are evaluated as the algebraically identical 25 + 5 log10((1+z_hel) DM(z_cosmo)): one Hermite
 // and one log10 per SN instead of two and two (difference ~1e-15 mag, tests/test_gpu_parity.py).
 // The accessor path (cf_eval_parts) keeps the reference's exact sequence  sn/pantheon.py:43-61.
+//
+// BAO (bao/desi_cmb_des5y.py:82-100,132-135): thread k < n_bao evaluates datum k; thread 0 forms
+// the quadratic form with the explicit inverse covariance.  CMB (cmb/data_planck_act_compression.py
+// :160-212): thread t < n_gl evaluates node t of the sound-horizon integral, thread n_gl + t node t
+// of the distance integral; thread 0 adds them in node order like the reference's loop.
+// chi2_extra[w] = chi2_bao + chi2_cmb;  blocks_out[w] = (bao, cmb, cmb vector[3]), bao_out[w][k] optional.
 // ------------------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(CF_TPB_A, 4)
-sn_residual_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double* __restrict__ delta,
-                   double* __restrict__ dm_out, double* __restrict__ mucorr_out) {
+walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double* __restrict__ delta,
+              double* __restrict__ chi2_extra, double* __restrict__ dm_out, double* __restrict__ mucorr_out,
+              double* __restrict__ blocks_out, double* __restrict__ bao_out) {
   extern __shared__ __align__(16) d2 lds_tab[];
   __shared__ double wave_tot[16];
+  __shared__ double scratch[2 * CF_MAX_GL + CF_MAX_BAO + 8];
 
   const int64_t w = blockIdx.x;
   if (w >= W) return;
   const double* th = theta + w * d.ndim;
-  double* out = delta + w * d.n_pad;
+  const int tid = threadIdx.x;
 
-  WalkerCosmo wc;
-  wc.H0 = slot_get(d, CF_P_H0_D, th);
-  wc.Om = slot_get(d, CF_P_OM_D, th);
-  wc.w0 = slot_get(d, CF_P_W0_D, th);
-  wc.wa = slot_get(d, CF_P_WA_D, th);
-  wc.c = d.c;
-  wc.fde = d.fde;
-  const double off = slot_get(d, CF_P_OFFSET_D, th);
-  const double v = slot_get(d, CF_P_V_D, th);
-
-  build_distance_table(d, wc, lds_tab, wave_tot);
-
+  const WalkerCosmo wc = make_cosmo(d, th);
   DistTable T;
   T.tab = lds_tab;
   T.G = d.n_grid;
@@ -210,30 +309,125 @@ sn_residual_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, d
   T.inv_step = d.inv_step;
   T.inv_last = d.inv_last;
   T.z_max = d.z_max;
-  const bool parts = dm_out != nullptr || mucorr_out != nullptr;
-  const double v100 = 100 * v;
 
-  for (int i = threadIdx.x; i < d.n_pad; i += CF_TPB_A) {
-    double res = 0.0;
-    if (i < d.n_sn) {
-      const double zc = d.z_cmb[i];
-      // sn/pantheon.py:43-49
-      const double v_km_s = v100 * d.sn_step[i];
-      const double z_pec = v_km_s / d.c;
-      const double z_cosmo = -1.0 + (1.0 + zc) / (1.0 + z_pec);
-      const double DMc = hermite_tab(T, z_cosmo);
-      if (!parts) {
-        res = d.obs[i] - off - (25.0 + 5 * log10((1.0 + d.z_hel[i]) * DMc));
-      } else {
-        const double DM = hermite_tab(T, zc);
-        const double mu_corr = 5.0 * log10(DMc / DM);
-        const double mu_th = 25.0 + 5 * log10((1.0 + d.z_hel[i]) * DM);  // sn/pantheon.py:52-54
-        res = d.obs[i] - off - mu_corr - mu_th;                          // sn/pantheon.py:59-60
-        if (dm_out) dm_out[w * d.n_sn + i] = DM;
-        if (mucorr_out) mucorr_out[w * d.n_sn + i] = mu_corr;
+  if (d.n_sn > 0 || d.n_bao > 0) build_distance_table(d, wc, lds_tab, wave_tot);
+
+  // ---- SN residual vector ----
+  if (d.n_sn > 0) {
+    double* out = delta + w * d.n_pad;
+    const double off = slot_get(d, CF_P_OFFSET_D, th);
+    const double v100 = 100 * slot_get(d, CF_P_V_D, th);
+    const bool parts = dm_out != nullptr || mucorr_out != nullptr;
+    for (int i = tid; i < d.n_pad; i += CF_TPB_A) {
+      double res = 0.0;
+      if (i < d.n_sn) {
+        const double zc = d.z_cmb[i];
+        double z_cosmo = zc;
+        if (d.has_vstep) {  // sn/pantheon.py:43-49
+          const double v_km_s = v100 * d.sn_step[i];
+          const double z_pec = v_km_s / d.c;
+          z_cosmo = -1.0 + (1.0 + zc) / (1.0 + z_pec);
+        }
+        const double DMc = hermite_tab(T, z_cosmo);
+        if (!parts) {
+          res = d.obs[i] - off - (25.0 + 5 * log10((1.0 + d.z_hel[i]) * DMc));
+        } else {
+          const double DM = hermite_tab(T, zc);
+          const double mu_corr = d.has_vstep ? 5.0 * log10(DMc / DM) : 0.0;
+          const double mu_th = 25.0 + 5 * log10((1.0 + d.z_hel[i]) * DM);  // sn/pantheon.py:52-54
+          res = d.obs[i] - off - mu_corr - mu_th;                          // sn/pantheon.py:59-60
+          if (dm_out) dm_out[w * d.n_sn + i] = DM;
+          if (mucorr_out) mucorr_out[w * d.n_sn + i] = mu_corr;
+        }
+      }
+      out[i] = res;  // rows >= n_sn are zero padding for the 16-row MFMA tiles
+    }
+  }
+  if (d.n_bao == 0 && d.cmb_mode == 0) {
+    if (tid == 0 && chi2_extra) chi2_extra[w] = 0.0;
+    return;
+  }
+
+  // ---- scalars shared by the two small blocks ----
+  double* gl_terms = scratch;                   // [2*n_gl]
+  double* bao_delta = scratch + 2 * CF_MAX_GL;  // [n_bao]
+  double* shared = bao_delta + CF_MAX_BAO;      // [0] = z_star, [1] = r_d
+  const double Ob = slot_get(d, CF_P_OBH2_D, th), Oc = slot_get(d, CF_P_OCH2_D, th);
+  if (tid == 0) {
+    if (d.cmb_mode) shared[0] = z_star_fit(d.zstar_fit, Ob, Oc + Ob + d.omnu_h2);
+    shared[1] = d.rd_from_fit ? r_drag_fit(d.rd_fit, Ob, Ob + Oc + d.omnu_h2) : slot_get(d, CF_P_RD_D, th);
+  }
+  __syncthreads();
+
+  // ---- BAO theory vector ----
+  if (tid < d.n_bao) {
+    const double z = d.bao_z[tid], rd = shared[1];
+    const double DM = hermite_tab(T, z);
+    const double DH = d.bao_dh_exact ? d.c / H_of_z(d, wc, z) : pchip_dh_tab(T, z);
+    double t;
+    switch (d.bao_qty[tid]) {
+      case 2: t = DH / rd; break;
+      case 1: t = DM / rd; break;
+      case 0: t = pow(z * DH * (DM * DM), 1.0 / 3) / rd; break;
+      default: t = DM / DH; break;
+    }
+    bao_delta[tid] = d.bao_val[tid] - t;
+    if (bao_out) bao_out[w * d.n_bao + tid] = t;
+  }
+  // ---- Gauss-Legendre terms of r_s(z*) (in a) and D_M(z*) (in z) ----
+  if (d.cmb_mode && tid < 2 * d.n_gl) {
+    const double zstar = shared[0];
+    if (tid < d.n_gl) {
+      const double half = (1.0 / (1.0 + zstar)) / 2.0;
+      const double a = half * d.gl_x[tid] + half;
+      const double z = (1.0 / a) - 1.0;
+      const double Rb = (3.0 / 4.0) * (Ob / d.o_gamma_h2) * a;
+      gl_terms[tid] = d.gl_w[tid] * (d.c / (a * a * H_of_z(d, wc, z) * sqrt(3.0 * (1.0 + Rb))));
+    } else {
+      const int k = tid - d.n_gl;
+      const double half = zstar / 2.0;
+      gl_terms[tid] = d.gl_w[k] * (d.c / H_of_z(d, wc, half * d.gl_x[k] + half));
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double c_bao = 0.0, c_cmb = 0.0;
+    if (d.n_bao > 0) {  // delta @ inv_cov @ delta
+      for (int j = 0; j < d.n_bao; ++j) {
+        double t = 0.0;
+        for (int i = 0; i < d.n_bao; ++i) t += bao_delta[i] * d.bao_inv_cov[i * d.n_bao + j];
+        c_bao += t * bao_delta[j];
       }
     }
-    out[i] = res;  // rows >= n_sn are zero padding for the 16-row MFMA tiles
+    if (d.cmb_mode) {
+      const double zstar = shared[0];
+      double i_rs = 0.0, i_dm = 0.0;
+      for (int k = 0; k < d.n_gl; ++k) i_rs += gl_terms[k];
+      for (int k = 0; k < d.n_gl; ++k) i_dm += gl_terms[d.n_gl + k];
+      const double rs_star = ((1.0 / (1.0 + zstar)) / 2.0) * i_rs;
+      const double DM_star = (zstar / 2.0) * i_dm;
+      const double Om_h2 = Oc + Ob + d.omnu_h2;
+      double vec[3];
+      if (d.cmb_mode == 3) {  // (theta*, wb, wm)  cmb/data_early_lcdm_compression.py:206-207
+        vec[0] = rs_star / DM_star; vec[1] = Ob; vec[2] = Om_h2;
+      } else {                // (R, lA, wb)       cmb/data_planck_act_compression.py:209-212
+        vec[0] = 100 * sqrt(Om_h2) * DM_star / d.c; vec[1] = 3.14159265358979323846 * DM_star / rs_star; vec[2] = Ob;
+      }
+      double dl[3];
+      for (int i = 0; i < 3; ++i) dl[i] = d.cmb_prior[i] - vec[i];
+      if (d.cmb_mode == 2) {
+        c_cmb = dl[1] * dl[1] * d.cmb_inv_cov[4];  // bao/desi_des5y_bbn_theta_star.py:110-111
+      } else {
+        for (int j = 0; j < 3; ++j) {
+          double t = 0.0;
+          for (int i = 0; i < 3; ++i) t += dl[i] * d.cmb_inv_cov[3 * i + j];
+          c_cmb += t * dl[j];
+        }
+      }
+      if (blocks_out) { blocks_out[5 * w + 2] = vec[0]; blocks_out[5 * w + 3] = vec[1]; blocks_out[5 * w + 4] = vec[2]; }
+    }
+    if (chi2_extra) chi2_extra[w] = c_cmb + c_bao;
+    if (blocks_out) { blocks_out[5 * w + 0] = c_bao; blocks_out[5 * w + 1] = c_cmb; }
   }
 }
 
@@ -247,28 +441,26 @@ __device__ double finalize_value(const cf_dev_desc& d, const double* __restrict_
     chi2 += diff * diff / (d.chi2_gauss_sigma[g] * d.chi2_gauss_sigma[g]);
   }
   if (out_kind == CF_OUT_CHI2_D) return chi2;
-  bool inbox = true;
   double lp = 0.0;
   if (out_kind == CF_OUT_LOGP_D) {
     if (d.has_bounds) {
+      bool inbox = true;
       for (int k = 0; k < d.ndim; ++k) inbox = inbox && (d.lo[k] < th[k]) && (th[k] < d.hi[k]);
+      if (!inbox) return -INFINITY;  // the likelihood is not consulted outside the box, sn/pantheon.py:90-92
       lp = d.log_norm;
     }
-    if (!inbox) return -INFINITY;
-    if (d.cpl_wall && d.fde == CF_FDE_CPL_D &&
-        slot_get(d, CF_P_W0_D, th) + slot_get(d, CF_P_WA_D, th) >= 0.0)
-      return -1e8;
     for (int g = 0; g < d.n_gauss; ++g) {
       double diff = th[d.gauss_idx[g]] - d.gauss_mean[g];
       lp = lp - 0.5 * (diff * diff) / (d.gauss_sigma[g] * d.gauss_sigma[g]);
     }
   }
-  double val = lp - 0.5 * chi2;
+  // hard wall of the CPL scripts, part of log L itself: bao/desi_fs_lya_cmb.py:118-121
+  if (d.cpl_wall && slot_get(d, CF_P_W0_D, th) + slot_get(d, CF_P_WA_D, th) >= 0.0) return lp + -1e8;
   if (!isfinite(chi2)) {  // emcee aborts on NaN: map to -inf and count it
     atomicAdd(nonfinite, 1ull);
     return -INFINITY;
   }
-  return val;
+  return lp - 0.5 * chi2;
 }
 
 // ------------------------------------------------------------------------------------------------

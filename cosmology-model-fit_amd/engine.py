@@ -40,12 +40,18 @@ def _ptr(a):
 class LikelihoodEngine:
     def __init__(self, *, ndim: int, z_max: float, n_grid: int = 4000, fde: int = L.CF_FDE_LCDM,
                  ez_model: int = L.CF_EZ_LATE_FLAT, params: dict, sn: Optional[dict] = None,
+                 bao: Optional[dict] = None, cmb: Optional[dict] = None, physical: Optional[dict] = None,
                  bounds=None, gauss: Sequence = (), chi2_gauss: Sequence = (), cpl_wall: bool = False,
                  device: int = 0, c_km_s: float = C_KM_S):
         """
         params: {"H0": Param(1), "Om": Param(2), ...} for the slots of include/cosmofit.h (cf_param_slot).
         sn: dict(z_cmb, z_hel, obs, chol[, step | z_turn]) — chol is cho_factor(cov, lower=True)[0];
             the strict upper triangle is never read.
+        bao: dict(z, val, qty (0 DV/rd, 1 DM/rd, 2 DH/rd, 3 F_AP), inv_cov[, dh_exact=False, rd_fit=None]);
+            rd_fit = (b, m, a1..a9) selects the r_drag fitting formula, otherwise the "rd" slot is used.
+        cmb: dict(mode (1 R-lA-wb, 2 lA only, 3 theta*-wb-wm), prior[3], inv_cov[3,3], zstar_fit (s1,s2,b,m)[, n_gl=100]).
+        physical: dict(or_h2, omnu_h2, o_gamma_h2, nu_m0, nu_rho0, nu_qs_sq[5], nu_ws[5]) — required by
+            ez_model=CF_EZ_PHYSICAL (see cmb_data.PLANCK_ACT / EARLY_LCDM).
         gauss / chi2_gauss: sequences of (idx, mean, sigma).
         """
         lib = L.lib()
@@ -72,6 +78,33 @@ class LikelihoodEngine:
             d.sn_z_cmb, d.sn_z_hel, d.sn_obs, d.sn_step = _ptr(z_cmb), _ptr(z_hel), _ptr(obs), _ptr(step)
             d.sn_z_turn = float(sn.get("z_turn", 0.15))
             d.sn_chol, d.sn_chol_ld = _ptr(chol), chol.shape[1]
+        self.n_bao = 0
+        if physical is not None:
+            d.or_h2, d.omnu_h2, d.o_gamma_h2 = physical["or_h2"], physical["omnu_h2"], physical["o_gamma_h2"]
+            d.nu_m0, d.nu_rho0 = physical["nu_m0"], physical["nu_rho0"]
+            d.nu_qs_sq[:] = [float(x) for x in physical["nu_qs_sq"]]
+            d.nu_ws[:] = [float(x) for x in physical["nu_ws"]]
+        if bao is not None:
+            bz, bv, binv = _f64(bao["z"]), _f64(bao["val"]), _f64(bao["inv_cov"])
+            bq = np.ascontiguousarray(bao["qty"], dtype=np.int32)
+            if not (bz.size == bv.size == bq.size) or binv.shape != (bz.size, bz.size):
+                raise ValueError("bao: z, val, qty must have n entries and inv_cov must be (n, n)")
+            keep += [bz, bv, binv, bq]
+            d.n_bao, d.bao_z, d.bao_val, d.bao_qty, d.bao_inv_cov = bz.size, _ptr(bz), _ptr(bv), _ptr(bq), _ptr(binv)
+            d.bao_dh_mode = 1 if bao.get("dh_exact", False) else 0
+            if bao.get("rd_fit") is not None:
+                d.rd_mode = 1
+                d.rd_fit[:] = [float(x) for x in bao["rd_fit"]]
+            self.n_bao = int(bz.size)
+        if cmb is not None:
+            from .cmb_data import ZSTAR_CONSTS
+            gx, gw = np.polynomial.legendre.leggauss(int(cmb.get("n_gl", 100)))  # cmb/data_planck_act_compression.py:150
+            gx, gw = _f64(gx), _f64(gw)
+            keep += [gx, gw]
+            d.cmb_mode, d.n_gl, d.gl_x, d.gl_w = int(cmb["mode"]), gx.size, _ptr(gx), _ptr(gw)
+            d.cmb_prior[:] = [float(x) for x in cmb["prior"]]
+            d.cmb_inv_cov[:] = [float(x) for x in np.asarray(cmb["inv_cov"], dtype=np.float64).ravel()]
+            d.zstar_fit[:] = [float(x) for x in tuple(cmb["zstar_fit"]) + ZSTAR_CONSTS]
         self.bounds = None if bounds is None else _f64(bounds).reshape(ndim, 2)
         d.bounds = _ptr(self.bounds)
         g = (L.cf_gauss_prior * max(len(gauss), 1))()
@@ -152,13 +185,17 @@ class LikelihoodEngine:
         return f
 
     def parts(self, theta):
-        """DM(z_cmb), mu_corr, residual and chi^2 blocks of a (small) batch — for plots and tests."""
+        """Intermediates of a (small) batch — for plots and tests: DM(z_cmb), mu_corr, residual (SN block);
+        chi2_blocks[:, 0:3] = (sn, bao, cmb), cmb_vector = the compressed-CMB theory 3-vector, bao_theory."""
         th = np.atleast_2d(_f64(theta))
-        W, n = th.shape[0], self.n_sn
-        dm, mc, dl = np.empty((W, n)), np.empty((W, n)), np.empty((W, n))
-        blocks = np.empty((W, 3))
-        L.check(L.lib().cf_eval_parts(self._h, _ptr(th), W, _ptr(dm), _ptr(mc), _ptr(dl), _ptr(blocks), None))
-        return dict(dm=dm, mu_corr=mc, delta=dl, chi2_blocks=blocks)
+        W, n, nb = th.shape[0], self.n_sn, self.n_bao
+        dm = np.empty((W, n)) if n else None
+        mc = np.empty((W, n)) if n else None
+        dl = np.empty((W, n)) if n else None
+        bt = np.empty((W, nb)) if nb else None
+        blocks = np.empty((W, 6))
+        L.check(L.lib().cf_eval_parts(self._h, _ptr(th), W, _ptr(dm), _ptr(mc), _ptr(dl), _ptr(blocks), _ptr(bt)))
+        return dict(dm=dm, mu_corr=mc, delta=dl, chi2_blocks=blocks[:, :3], cmb_vector=blocks[:, 3:], bao_theory=bt)
 
     def enable_timing(self, slots=1):
         """Keep HIP-event timings of the last `slots` evaluations (0 = off)."""

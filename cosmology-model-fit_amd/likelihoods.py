@@ -1,0 +1,140 @@
+"""
+Host-side mirrors of the reference's joint-likelihood scripts: the same quantities under the same names
+(``chi_squared``, ``log_likelihood``, ``log_probability``, ``bounds``, ``bao_theory`` ...) bound to a GPU engine.
+The caller passes the data arrays the reference's own loaders return (``get_data()`` tuples); nothing is loaded
+from disk here.
+
+    bao/desi.py                         -> DesiBao              (BAO only, late-time flat, thawing w0, fixed r_d)
+    bao/desi_cmb.py                     -> DesiCmb              (BAO + early-LCDM theta* compression, thawing w0)
+    bao/desi_fs_lya_cmb.py              -> DesiFsLyaCmb         (BAO FS+Lya incl. F_AP + Planck/ACT, CPL, w0+wa wall)
+    bao/desi_cmb_des5y.py               -> DesiCmbDes5y         (SN + BAO + CMB, BASELINE config 3 as shipped)
+    bao/desi_des5y_bbn_theta_star.py    -> DesiDes5yBbnThetaStar(SN + BAO + l_A + BBN prior, BASELINE config 5)
+"""
+import numpy as np
+from scipy.linalg import cho_factor
+
+from . import _lib as L
+from . import cmb_data
+from .engine import LikelihoodEngine, Param
+
+N_GRID = 4000
+QTY_MAP = {"DV_over_rs": 0, "DM_over_rs": 1, "DH_over_rs": 2, "F_AP": 3}  # bao/desi_cmb_des5y.py:69-78
+
+
+def bao_arrays(bao_data, cov):
+    """(z, value, qty codes, inverse covariance) from the reference's structured BAO array + covariance."""
+    qty = np.array([QTY_MAP[str(q)] for q in bao_data["quantity"]], dtype=np.int32)
+    return np.asarray(bao_data["z"], float), np.asarray(bao_data["value"], float), qty, np.linalg.inv(cov)
+
+
+def _physical(comp):
+    return {k: comp[k] for k in ("or_h2", "omnu_h2", "o_gamma_h2", "nu_m0", "nu_rho0", "nu_qs_sq", "nu_ws")}
+
+
+class _Base:
+    bounds = None
+
+    def chi_squared(self, params):
+        return self.engine.chi_squared(params)
+
+    def log_likelihood(self, params):
+        return self.engine.log_likelihood(params)
+
+    def log_probability(self, params):
+        return self.engine.log_probability(params)
+
+    def log_probs_vectorized(self, batch):
+        return self.engine.log_probability(np.atleast_2d(batch))
+
+    log_probability_vect = log_probs_vectorized  # bao/desi_cmb.py:137
+
+    def bao_theory(self, params):
+        return self.engine.parts(params)["bao_theory"][0]
+
+    def cmb_distances(self, params):
+        return self.engine.parts(params)["cmb_vector"][0]
+
+
+class DesiBao(_Base):
+    """bao/desi.py: theta = (h, Om, w0); bounds bao/desi.py:69-75; r_d = 147.09 Mpc fixed (:10)."""
+    bounds = np.array([(0.50, 0.80), (0.1, 0.5), (-1.0, 0.0)])
+
+    def __init__(self, z, val, qty, inv_cov, *, rd=147.09, device=0, bounds=None):
+        self.bounds = self.bounds if bounds is None else np.asarray(bounds, float)
+        self.z_max = float(np.max(z) + 0.1)  # bao/desi.py:19
+        self.engine = LikelihoodEngine(
+            ndim=3, z_max=self.z_max, n_grid=N_GRID, fde=L.CF_FDE_THAWING,
+            params=dict(H0=Param(0, scale=100.0), Om=Param(1), w0=Param(2), rd=Param(fixed=rd)),
+            bao=dict(z=z, val=val, qty=qty, inv_cov=inv_cov), bounds=self.bounds, device=device)
+
+
+class DesiCmb(_Base):
+    """bao/desi_cmb.py: theta = (H0, wb, wc, w0); exact D_H, r_drag fit, (theta*, wb, wm) compression."""
+    bounds = np.array([(50.0, 80.0), (0.020, 0.024), (0.05, 0.30), (-1.0, 0.0)])
+
+    def __init__(self, z, val, qty, inv_cov, *, comp=None, device=0, bounds=None):
+        comp = cmb_data.EARLY_LCDM if comp is None else comp
+        self.bounds = self.bounds if bounds is None else np.asarray(bounds, float)
+        self.z_max = float(np.max(z) + 0.1)
+        self.engine = LikelihoodEngine(
+            ndim=4, z_max=self.z_max, n_grid=N_GRID, ez_model=L.CF_EZ_PHYSICAL, fde=L.CF_FDE_THAWING,
+            params=dict(H0=Param(0), obh2=Param(1), och2=Param(2), w0=Param(3)),
+            bao=dict(z=z, val=val, qty=qty, inv_cov=inv_cov, dh_exact=True, rd_fit=comp["rd_fit"]),
+            cmb=dict(mode=comp["cmb_mode"], prior=comp["cmb_prior"], inv_cov=comp["cmb_inv_cov"], zstar_fit=comp["zstar_fit"]),
+            physical=_physical(comp), bounds=self.bounds, device=device)
+
+
+class DesiFsLyaCmb(_Base):
+    """bao/desi_fs_lya_cmb.py: theta = (H0, wb, wc, w0, wa); CPL; log L = -1e8 when w0 + wa >= 0 (:118-121)."""
+
+    def __init__(self, z, val, qty, inv_cov, *, comp=None, device=0):
+        comp = cmb_data.PLANCK_ACT if comp is None else comp
+        self.z_max = float(np.max(z) + 0.1)
+        self.engine = LikelihoodEngine(
+            ndim=5, z_max=self.z_max, n_grid=N_GRID, ez_model=L.CF_EZ_PHYSICAL, fde=L.CF_FDE_CPL,
+            params=dict(H0=Param(0), obh2=Param(1), och2=Param(2), w0=Param(3), wa=Param(4)),
+            bao=dict(z=z, val=val, qty=qty, inv_cov=inv_cov, rd_fit=comp["rd_fit"]),
+            cmb=dict(mode=comp["cmb_mode"], prior=comp["cmb_prior"], inv_cov=comp["cmb_inv_cov"], zstar_fit=comp["zstar_fit"]),
+            physical=_physical(comp), cpl_wall=True, device=device)
+
+
+class DesiCmbDes5y(_Base):
+    """bao/desi_cmb_des5y.py: theta = (dM, H0, wb, wc, v); SN with velocity step at z = 0.10563 (:105), BAO with
+    PCHIP D_H and F_AP, Planck+ACT (R, l_A, wb); dark energy = Lambda as shipped (:46)."""
+
+    def __init__(self, z_cmb, z_hel, mu_values, cov_sn, bao_z, bao_val, bao_qty, bao_inv_cov, *, chol=None, comp=None,
+                 device=0):
+        comp = cmb_data.PLANCK_ACT if comp is None else comp
+        if chol is None:
+            chol = cho_factor(cov_sn, lower=True)[0]  # bao/desi_cmb_des5y.py:17
+        self.z_max = float(max(np.max(z_cmb), np.max(bao_z)) + 0.1)  # :20
+        self.engine = LikelihoodEngine(
+            ndim=5, z_max=self.z_max, n_grid=N_GRID, ez_model=L.CF_EZ_PHYSICAL, fde=L.CF_FDE_LCDM,
+            params=dict(offset=Param(0), H0=Param(1), obh2=Param(2), och2=Param(3), v=Param(4)),
+            sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=mu_values, chol=chol, z_turn=0.10563),
+            bao=dict(z=bao_z, val=bao_val, qty=bao_qty, inv_cov=bao_inv_cov, rd_fit=comp["rd_fit"]),
+            cmb=dict(mode=comp["cmb_mode"], prior=comp["cmb_prior"], inv_cov=comp["cmb_inv_cov"], zstar_fit=comp["zstar_fit"]),
+            physical=_physical(comp), device=device)
+
+
+class DesiDes5yBbnThetaStar(_Base):
+    """bao/desi_des5y_bbn_theta_star.py: theta = (dM, H0, wb, wc, w0); no velocity step, exact D_H, l_A only
+    (delta^2 / covariance[1,1], :110-111), BBN prior on wb (:139); bounds :122-130."""
+    bounds = np.array([(-0.5, 0.5), (50.0, 90.0), (0.010, 0.030), (0.05, 0.30), (-1.0, -1 / 3)])
+
+    def __init__(self, z_cmb, z_hel, mu_values, cov_sn, bao_z, bao_val, bao_qty, bao_inv_cov, *, chol=None, comp=None,
+                 bbn=cmb_data.BBN_SCHONEBERG, device=0, bounds=None):
+        comp = cmb_data.PLANCK_ACT if comp is None else comp
+        self.bounds = self.bounds if bounds is None else np.asarray(bounds, float)
+        if chol is None:
+            chol = cho_factor(cov_sn, lower=True)[0]
+        inv = np.zeros((3, 3))
+        inv[1, 1] = 1.0 / comp["cmb_cov"][1, 1]
+        self.z_max = float(max(np.max(z_cmb), np.max(bao_z)) + 0.1)
+        self.engine = LikelihoodEngine(
+            ndim=5, z_max=self.z_max, n_grid=N_GRID, ez_model=L.CF_EZ_PHYSICAL, fde=L.CF_FDE_THAWING,
+            params=dict(offset=Param(0), H0=Param(1), obh2=Param(2), och2=Param(3), w0=Param(4)),
+            sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=mu_values, chol=chol),
+            bao=dict(z=bao_z, val=bao_val, qty=bao_qty, inv_cov=bao_inv_cov, dh_exact=True, rd_fit=comp["rd_fit"]),
+            cmb=dict(mode=2, prior=comp["cmb_prior"], inv_cov=inv, zstar_fit=comp["zstar_fit"]),
+            physical=_physical(comp), bounds=self.bounds, gauss=[(2, bbn[0], bbn[1])], device=device)

@@ -170,7 +170,9 @@ typedef struct cf_desc {
   const double* gl_w;       /* [n_gl] weights */
   double cmb_prior[3];
   double cmb_inv_cov[9];
-  double zstar_fit[11];     /* z_star coefficients s1,s2,b,m + 7 numeric constants  cmb/...:86-99 */
+  double zstar_fit[11];     /* z_star: s1, s2, b, m, then e0, c1, e1, e2, c2, e3, e4 of
+                               wm^e0 + s1 c1 wb^e1 wm^e2 + s2 c2 wm^e3 wb^e4 (wb, wm raised to b, m first)
+                               cmb/data_planck_act_compression.py:86-99 */
   double o_gamma_h2;        /* photon density for R_b                 cmb/...:29 */
 
   /* ---- radiation + massive neutrino constants (CF_EZ_PHYSICAL) ---- */
@@ -215,8 +217,9 @@ int cf_get_info(cf_handle* h, cf_info* info);
 /* Host buffers. theta: [W*ndim] C-order float64; out: [W] float64. Synchronous. */
 int cf_eval(cf_handle* h, const double* theta, int64_t W, double* out, int32_t out_kind);
 
-/* Device buffers on the handle's device; asynchronous on `hip_stream` (a hipStream_t, NULL =
- * the handle's own stream). Grows the workspace if needed (then it synchronises once). */
+/* Device buffers on the handle's device; asynchronous on `hip_stream` (a hipStream_t; NULL = HIP's
+ * default stream, which is what torch.cuda.current_stream().cuda_stream reports as 0), ordered like any
+ * other work on that stream. Grows the workspace if needed (then it synchronises once). */
 int cf_eval_device(cf_handle* h, const double* d_theta, int64_t W, double* d_out,
                    int32_t out_kind, void* hip_stream);
 
@@ -224,7 +227,8 @@ int cf_eval_device(cf_handle* h, const double* d_theta, int64_t W, double* d_out
  *   dm_obs [W*n_sn]  DM(z_cmb)           sn/pantheon.py:58
  *   mu_corr[W*n_sn]                      sn/pantheon.py:43-49
  *   delta  [W*n_sn]  residual vector     sn/pantheon.py:59-60
- *   chi2_blocks[W*3] (sn, bao, cmb)      bao/desi_cmb_des5y.py:138-141
+ *   chi2_blocks[W*6] (chi2_sn, chi2_bao, chi2_cmb, cmb distance vector[3])
+ *                                        bao/desi_cmb_des5y.py:126-141, cmb/data_planck_act_compression.py:200-212
  *   bao_theory[W*n_bao]                  bao/desi_cmb_des5y.py:82-100 */
 int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, double* dm_obs, double* mu_corr,
                   double* delta, double* chi2_blocks, double* bao_theory);

@@ -1,0 +1,150 @@
+"""
+GPU (-m gpu): the BAO / compressed-CMB / physical-density blocks and the joint likelihoods of the reference's
+bao/*.py scripts, through the C-ABI, against the golden vectors generated from the reference and the C oracle.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden
+from test_oracle_golden import (_chol_of, lk_bao_desi, lk_bao_desi_cmb, lk_bao_desi_cmb_des5y,
+                                lk_bao_desi_des5y_bbn_theta_star, lk_bao_desi_fs_lya_cmb)
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def gpu(pkg):
+    if pkg.lib().cf_device_count() < 1:
+        pytest.fail("GPU tests need an MI355X; no HIP device visible (there is no fallback path)")
+    return pkg
+
+
+def _bao_args(g):
+    return g["bao_z"], g["bao_val"], g["bao_qty"], g["bao_inv_cov"]
+
+
+def test_bao_desi_golden(gpu):
+    g = golden("bao_desi")
+    lk = gpu.likelihoods.DesiBao(*_bao_args(g), rd=float(g["rd"]), bounds=g["bounds"])
+    assert lk.z_max == float(g["z_max"])
+    fin = np.isfinite(g["logp"])
+    np.testing.assert_allclose(lk.chi_squared(g["thetas"])[fin], g["chi2"][fin], rtol=RTOL)
+    logp = lk.log_probs_vectorized(g["thetas"])
+    np.testing.assert_allclose(logp[fin], g["logp"][fin], rtol=RTOL)
+    assert np.all(logp[~fin] == -np.inf)
+    np.testing.assert_allclose(logp[fin].astype(np.float32), g["logp_vec32"][fin], rtol=1e-6)  # reference batch API is f32
+    for k in range(4):
+        np.testing.assert_allclose(lk.bao_theory(g["thetas"][k]), g["theory"][k], rtol=1e-12)
+    # docstring chi^2 of the reference at its posterior medians (bao/desi.py:199,225): 10.79 / 8.81
+    assert lk.chi_squared(np.array([0.691, 0.297, -1.0])) == pytest.approx(10.79, abs=0.05)
+    assert lk.chi_squared(np.array([0.666, 0.312, -0.768])) == pytest.approx(8.81, abs=0.05)
+    lk.engine.close()
+
+
+def test_bao_desi_cmb_golden(gpu):
+    g = golden("bao_desi_cmb")
+    lk = gpu.likelihoods.DesiCmb(*_bao_args(g), bounds=g["bounds"])
+    fin = np.isfinite(g["logp"])
+    np.testing.assert_allclose(lk.chi_squared(g["thetas"])[fin], g["chi2"][fin], rtol=RTOL)
+    logp = lk.log_probability_vect(g["thetas"])
+    np.testing.assert_allclose(logp[fin], g["logp"][fin], rtol=RTOL)
+    assert np.all(logp[~fin] == -np.inf)
+    for k in range(4):
+        np.testing.assert_allclose(lk.bao_theory(g["thetas"][k]), g["theory"][k], rtol=1e-12)
+        np.testing.assert_allclose(lk.cmb_distances(g["thetas"][k]), g["cmb_dist"][k], rtol=1e-12)
+    # docstring chi^2 (bao/desi_cmb.py:252,286): 13.49 / 14.00 at medians printed to 3-4 digits
+    assert lk.chi_squared(np.array([68.40, 0.02237, 0.1172, -1.0 + 1e-9])) == pytest.approx(13.49, abs=0.2)
+    lk.engine.close()
+
+
+def test_bao_desi_fs_lya_cmb_golden(gpu):
+    g = golden("bao_desi_fs_lya_cmb")
+    lk = gpu.likelihoods.DesiFsLyaCmb(*_bao_args(g))
+    parts = lk.engine.parts(g["thetas"][:8])
+    np.testing.assert_allclose(parts["chi2_blocks"][:, 2], g["chi2_cmb"], rtol=1e-9)
+    np.testing.assert_allclose(parts["chi2_blocks"][:, 1], g["chi2_bao"], rtol=RTOL)
+    np.testing.assert_allclose(parts["bao_theory"][:4], g["theory"], rtol=1e-12)
+    np.testing.assert_allclose(parts["cmb_vector"][:4], g["cmb_dist"], rtol=1e-12)
+    logl = lk.log_likelihood(g["thetas"])
+    wall = g["logl"] == -1e8
+    assert wall.sum() >= 3 and np.all(logl[wall] == -1e8), "w0 + wa >= 0 is a hard wall of log L"
+    ok = np.isfinite(g["logl"]) & ~wall
+    np.testing.assert_allclose(logl[ok], g["logl"][ok], rtol=1e-9)
+    assert not np.any(np.isnan(logl))
+    lk.engine.close()
+
+
+@pytest.fixture(scope="module")
+def des5y(gpu):
+    g = dict(golden("bao_desi_cmb_des5y"))
+    g["chol"] = _chol_of(g)
+    lk = gpu.likelihoods.DesiCmbDes5y(g["z_cmb"], g["z_hel"], g["obs"], None, *_bao_args(g), chol=g["chol"])
+    yield g, lk
+    lk.engine.close()
+
+
+def test_config3_desi_cmb_des5y_golden(des5y):
+    g, lk = des5y
+    assert lk.z_max == float(g["z_max"])
+    np.testing.assert_allclose(lk.chi_squared(g["thetas"]), g["chi2"], rtol=RTOL)
+    np.testing.assert_allclose(lk.log_likelihood(g["thetas"]), g["logl"], rtol=RTOL)
+    parts = lk.engine.parts(g["thetas"])
+    np.testing.assert_allclose(parts["chi2_blocks"], g["chi2_parts"], rtol=1e-9)
+    np.testing.assert_allclose(parts["bao_theory"][:4], g["theory"], rtol=1e-12)
+    np.testing.assert_allclose(parts["cmb_vector"][:4], g["cmb_dist"], rtol=1e-12)
+
+
+def test_config3_full_batch_vs_c_oracle(gpu, des5y):
+    """BASELINE config 3 shape at full size: N = 1820 SNe + 14 BAO + CMB, 4096 walkers."""
+    from oracle import oracle_c as oc
+
+    g, lk = des5y
+    co = oc.COracle(lk_bao_desi_cmb_des5y(g, g["chol"]))
+    box = np.array([(-0.5, 0.5), (60.0, 75.0), (0.010, 0.030), (0.01, 0.25), (-4.5, 4.5)])
+    theta = gpu.synthetic.walkers(box, 4096, seed=3)
+    got = lk.log_likelihood(theta)
+    want = co.logl(theta)
+    rel = np.abs(got - want) / np.abs(want)
+    assert rel.max() < RTOL, f"max rel diff {rel.max():.3e}"
+    np.testing.assert_array_equal(lk.log_likelihood(theta[:777]), got[:777])  # batch-size invariance
+
+
+def test_config5_desi_des5y_bbn_theta_star_golden(gpu):
+    g = dict(golden("bao_desi_des5y_bbn_theta_star"))
+    chol = _chol_of(g)
+    lk = gpu.likelihoods.DesiDes5yBbnThetaStar(g["z_cmb"], g["z_hel"], g["obs"], None, *_bao_args(g), chol=chol,
+                                               bbn=(float(g["bbn"][0]), float(g["bbn"][1])), bounds=g["bounds"])
+    fin = np.isfinite(g["logp"])
+    np.testing.assert_allclose(lk.chi_squared(g["thetas"])[fin], g["chi2"][fin], rtol=RTOL)
+    logp = lk.log_probs_vectorized(g["thetas"])
+    np.testing.assert_allclose(logp[fin], g["logp"][fin], rtol=RTOL)
+    assert np.all(logp[~fin] == -np.inf)
+    for k in range(4):
+        np.testing.assert_allclose(lk.bao_theory(g["thetas"][k]), g["theory"][k], rtol=1e-12)
+    # nautilus live-point batch (config 5): log L only, 2048 points vs the C oracle
+    from oracle import oracle_c as oc
+    co = oc.COracle(lk_bao_desi_des5y_bbn_theta_star(g, chol))
+    theta = gpu.synthetic.walkers(g["bounds"], 2048, seed=9)
+    np.testing.assert_allclose(lk.log_likelihood(theta), co.logl(theta), rtol=RTOL)
+    lk.engine.close()
+
+
+def test_f_de_variants_with_sn_block_vs_oracle(gpu):
+    """wCDM / thawing / CPL on the SN path (sn/pantheon_and_sh0es.py:26-28 etc.) against the C oracle."""
+    from oracle import oracle_c as oc, oracle_np as onp
+
+    syn = gpu.synthetic.pantheon_like(n_sn=400, seed=2)
+    rng = np.random.default_rng(8)
+    for fde, ofde in ((gpu.CF_FDE_WCDM, onp.FDE_WCDM), (gpu.CF_FDE_THAWING, onp.FDE_THAWING), (gpu.CF_FDE_CPL, onp.FDE_CPL)):
+        eng = gpu.LikelihoodEngine(
+            ndim=6, z_max=syn["z_max"], fde=fde,
+            params=dict(offset=gpu.Param(0), H0=gpu.Param(1), Om=gpu.Param(2), v=gpu.Param(3), w0=gpu.Param(4), wa=gpu.Param(5)),
+            sn=dict(z_cmb=syn["z_cmb"], z_hel=syn["z_hel"], obs=syn["obs"], chol=syn["chol"]))
+        co = oc.COracle(onp.Likelihood(ndim=6, z_max=syn["z_max"], fde=ofde, offset=onp.Slot(0), H0=onp.Slot(1), Om=onp.Slot(2),
+                                       v=onp.Slot(3), w0=onp.Slot(4), wa=onp.Slot(5), z_cmb=syn["z_cmb"], z_hel=syn["z_hel"],
+                                       obs=syn["obs"], chol=syn["chol"]))
+        th = np.column_stack([rng.uniform(-19.6, -19.1, 64), rng.uniform(60, 80, 64), rng.uniform(0.1, 0.5, 64),
+                              rng.uniform(-2, 2, 64), rng.uniform(-1.2, -0.5, 64), rng.uniform(-1.0, 0.4, 64)])
+        np.testing.assert_allclose(eng.chi_squared(th), co.chi2(th), rtol=RTOL)
+        eng.close()
