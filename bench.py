@@ -60,12 +60,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no HIP device visible); there is no CPU path to time instead")
+    # one GPU per rank; the modulo only matters for a rehearsal of several ranks on a 1-GPU box
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # "gloo": rehearsal only (ranks sharing one GPU)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     pkg = importlib.import_module("cosmology-model-fit_amd")
     sn = pkg.sn_pantheon
@@ -86,7 +92,12 @@ def main():
     def step():
         if world > 1:
             # exchange step of an ensemble move: every rank needs the complementary walkers' positions
-            dist.all_gather_into_tensor(theta_all, theta_local)
+            if backend == "nccl":
+                dist.all_gather_into_tensor(theta_all, theta_local)
+            else:  # rehearsal backend without device collectives: stage through the host
+                host = torch.empty((W_total, 4), dtype=torch.float64)
+                dist.all_gather_into_tensor(host, theta_local.cpu())
+                theta_all.copy_(host)
         eng.eval_device(theta_local.data_ptr(), Wl, logp.data_ptr(), pkg.CF_OUT_LOGP, stream)
 
     def fence():
@@ -107,7 +118,7 @@ def main():
     kms = eng.kernel_ms()
     eng.enable_timing(0)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         got = theta_all.cpu().numpy()

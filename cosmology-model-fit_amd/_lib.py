@@ -95,6 +95,7 @@ EXPORTS = {
     "cf_interp_hermite": (C.c_int, [_VP, _I64, _VP, _VP, _VP, _I64, _VP]),
     "cf_interp_pchip": (C.c_int, [_VP, _I64, _VP, _VP, _I64, _VP]),
     "cf_solve_triangular": (C.c_int, [_VP, _I64, _I64, _VP, _I64, _VP]),
+    "cf_selftest_log10": (C.c_int, [_VP, _I64, _VP]),
     "cf_selftest_pack_host": (C.c_int, [_VP, _I64, _I64, _VP, C.POINTER(C.c_double), C.POINTER(_I64)]),
 }
 

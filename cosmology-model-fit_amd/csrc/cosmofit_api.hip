@@ -41,6 +41,7 @@ extern "C" __global__ void finalize_kernel(cf_dev_desc d, const double* theta, i
                                            double* out, int out_kind, unsigned long long* nonfinite);
 extern "C" __global__ void interp_kernel(const double* xq, int64_t nq, const double* x, const double* y,
                                          const double* yp, int64_t n, double* out, int mode);
+extern "C" __global__ void log10_selftest_kernel(const double* x, int64_t n, double* out);
 extern "C" __global__ void pad_rhs_kernel(const double* b, int64_t nrhs, int64_t n, int64_t n_pad, double* delta);
 
 // ------------------------------------------------------------------------------------------------
@@ -633,6 +634,21 @@ extern "C" int cf_solve_triangular(const double* L, int64_t n, int64_t ld, const
     return rc;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, dout.p, (size_t)nrhs * 8, hipMemcpyDeviceToHost));
+  return CF_OK;
+}
+
+// Self-test of the in-kernel log10 (device): out[k] = log10_pos(x[k]).
+extern "C" int cf_selftest_log10(const double* x, int64_t n, double* out) {
+  if (!x || !out || n < 0) return fail(CF_ERR_INVALID, "cf_selftest_log10: bad argument");
+  if (cf_device_count() == 0) return fail(CF_ERR_NO_DEVICE, "cf_selftest_log10: no HIP device visible");
+  if (n == 0) return CF_OK;
+  DevBuf dx, dout;
+  if (dx.ensure((size_t)n * 8) || dout.ensure((size_t)n * 8)) return CF_ERR_HIP;
+  HIP_TRY(hipMemcpy(dx.p, x, (size_t)n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(log10_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dx.as<const double>(), n,
+                     dout.as<double>());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * 8, hipMemcpyDeviceToHost));
   return CF_OK;
 }
 

@@ -260,6 +260,9 @@ int cf_solve_triangular(const double* L, int64_t n, int64_t ld, const double* b,
 int cf_selftest_pack_host(const double* L, int64_t n, int64_t ld, const double* b, double* chi2_out,
                           int64_t* packed_bytes);
 
+/* Device self-test of the in-kernel log10 used for the distance moduli: out[k] = log10(x[k]). */
+int cf_selftest_log10(const double* x, int64_t n, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -228,3 +228,21 @@ def test_device_ensemble_stretch_move_matches_oracle_driven_chain(gpu):
     np.testing.assert_allclose(ens_gpu.logp.cpu().numpy(), ens_cpu.logp.numpy(), rtol=1e-9)
     assert ens_gpu.n_accepted == ens_cpu.n_accepted and 0 < ens_gpu.n_accepted < ens_gpu.n_proposed
     lk.engine.close()
+
+
+def test_in_kernel_log10_is_within_one_ulp(gpu):
+    import ctypes as C
+    rng = np.random.default_rng(0)
+    x = np.concatenate([np.exp(rng.uniform(np.log(1e-3), np.log(1e6), 400000)),  # the range distances live in
+                        np.exp(rng.uniform(-700, 700, 100000)), [1.0, 10.0, 1e5, 0.5, 2.0, np.sqrt(0.5), np.sqrt(2.0)],
+                        [0.0, -1.0, np.inf, np.nan, 5e-324]])
+    out = np.empty_like(x)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    gpu._lib.check(gpu.lib().cf_selftest_log10(p(x), x.size, p(out)))
+    with np.errstate(all="ignore"):
+        ref = np.log10(x)
+    fin = np.isfinite(ref)
+    ulp = np.abs(out[fin] - ref[fin]) / np.spacing(np.abs(ref[fin]) + 5e-324)
+    assert ulp.max() <= 1.0, f"max error {ulp.max()} ulp"
+    assert out[x == 1.0][0] == 0.0 and out[x == 10.0][0] == 1.0
+    assert out[-5] == -np.inf and np.isnan(out[-4]) and out[-3] == np.inf and np.isnan(out[-2])

@@ -8,7 +8,7 @@ for f in sorted(glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 lines = []
 for k, cs in acc.items():
-    if not ("trsm" in k or "sn_residual" in k):
+    if not ("trsm" in k or "sn_residual" in k or "walker" in k):
         continue
     lines.append(f"== {k[:60]}  (dispatches: {max(len(v) for v in cs.values())})")
     for c, v in sorted(cs.items()):
@@ -24,7 +24,7 @@ import json
 traffic = {}
 for k, cs in acc.items():
     if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
-        name = "trsm_chi2_kernel" if "trsm" in k else ("sn_residual_kernel" if "sn_residual" in k else None)
+        name = "trsm_chi2_kernel" if "trsm" in k else ("walker_kernel" if ("sn_residual" in k or "walker" in k) else None)
         if name:
             f = cs["FETCH_SIZE"][2:] or cs["FETCH_SIZE"]
             w = cs["WRITE_SIZE"][2:] or cs["WRITE_SIZE"]
