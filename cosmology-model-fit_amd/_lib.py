@@ -24,7 +24,7 @@ CF_FDE_LCDM, CF_FDE_WCDM, CF_FDE_THAWING, CF_FDE_CPL = 0, 1, 2, 3
 CF_OUT_CHI2, CF_OUT_LOGL, CF_OUT_LOGP = 0, 1, 2
 CF_CMB_NONE = 0
 STATUS = {0: "CF_OK", -1: "CF_ERR_INVALID", -2: "CF_ERR_NO_DEVICE", -3: "CF_ERR_HIP", -4: "CF_ERR_NOT_POSDEF",
-          -5: "CF_ERR_UNSUPPORTED"}
+          -5: "CF_ERR_UNSUPPORTED", -6: "CF_ERR_ILL_CONDITIONED"}
 
 
 class CosmofitError(RuntimeError):
@@ -73,6 +73,7 @@ class cf_info(C.Structure):
         ("n_sn", C.c_int64), ("n_sn_pad", C.c_int64), ("packed_chol_bytes", C.c_int64),
         ("workspace_bytes", C.c_int64), ("max_walkers", C.c_int64), ("nonfinite_count", C.c_int64),
         ("device", C.c_int32), ("cu_count", C.c_int32), ("gcn_arch", C.c_char * 64),
+        ("pack_probe_rel", C.c_double),
     ]
 
 

@@ -183,4 +183,32 @@ static double cf_pack_replay_host(const cf_host_pack& pk, const double* b_in) {
   return chi;
 }
 
+// Accuracy probe of a packed factor: || L^-1 b ||^2 for a fixed pseudo-random b through the fragment
+// streams (blocked, diagonal blocks through their inverses) against plain row-by-row forward
+// substitution (solve_triangular.py:12-14).  Returns the relative difference; an ill-conditioned
+// diagonal block shows up here (cond(L_bb) * eps) before any walker is evaluated.
+static double cf_pack_probe(const cf_host_pack& pk, const double* L, int64_t ld) {
+  const int64_t n = pk.n;
+  std::vector<double> b((size_t)n), y((size_t)n);
+  uint64_t s = 0x9E3779B97F4A7C15ull;
+  for (int64_t i = 0; i < n; ++i) {  // splitmix64 -> uniform in [-1, 1)
+    s += 0x9E3779B97F4A7C15ull;
+    uint64_t z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    b[i] = (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+  }
+  double ref = 0.0;
+  for (int64_t i = 0; i < n; ++i) {
+    const double* row = L + i * ld;
+    double acc = 0.0;
+    for (int64_t j = 0; j < i; ++j) acc += row[j] * y[j];
+    y[i] = (b[i] - acc) / row[i];
+    ref += y[i] * y[i];
+  }
+  const double got = cf_pack_replay_host(pk, b.data());
+  return std::fabs(got - ref) / (std::fabs(ref) > 0 ? std::fabs(ref) : 1.0);
+}
+
 #endif

@@ -61,10 +61,13 @@ static void default_shape(int& ks, int& tc) {
     }
   }
 }
-static int pack_default(const double* L, int64_t n, int64_t ld, cf_host_pack& hp) {
+#define CF_PROBE_LIMIT 1e-11
+
+static int pack_default(const double* L, int64_t n, int64_t ld, cf_host_pack& hp, double* probe_rel = nullptr) {
   int ks, tc;
   default_shape(ks, tc);
   int rc = cf_pack_cholesky(L, n, ld, hp, ks, tc);
+  if (rc == 0 && probe_rel) *probe_rel = cf_pack_probe(hp, L, ld);
   // TIMING EXPERIMENT ONLY (wrong results): fold every update stream onto the first 64 KiB so that
   // all factor loads hit L1/L2 -- tells an operand-delivery bound from an MFMA-issue bound.
   if (rc == 0 && getenv("CF_DEBUG_ALIAS_STREAMS"))
@@ -136,6 +139,7 @@ struct cf_handle {
   DevBuf theta, out, delta, ypk, chi2_extra, nonfinite;
   bool has_small_blocks = false;  // BAO and / or CMB block present
   int64_t max_walkers = 0;
+  double pack_probe_rel = 0.0;
   int cu_count = 0;
   char arch[64] = {0};
   std::mutex mu;
@@ -327,8 +331,12 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
     d.obs = h->obs.as<const double>();
     d.sn_step = h->sn_step.as<const double>();
     cf_host_pack hp;
-    if (pack_default(c->sn_chol, c->n_sn, c->sn_chol_ld, hp) != 0)
+    if (pack_default(c->sn_chol, c->n_sn, c->sn_chol_ld, hp, &h->pack_probe_rel) != 0)
       return bail(fail(CF_ERR_NOT_POSDEF, "cf_create: the Cholesky factor has a non-positive or non-finite pivot"));
+    if (!(h->pack_probe_rel <= CF_PROBE_LIMIT))
+      return bail(fail(CF_ERR_ILL_CONDITIONED, "cf_create: the blocked solve disagrees with row-by-row forward substitution by " +
+                                                   std::to_string(h->pack_probe_rel) + " relative on a probe vector (limit 1e-11): "
+                                                   "the factor's diagonal blocks are too ill-conditioned for 256-row block inverses"));
     if ((rc = h->pack.upload(hp))) return bail(rc);
   }
   if (c->n_bao > 0) {
@@ -378,6 +386,7 @@ extern "C" int cf_get_info(cf_handle* h, cf_info* info) {
   info->max_walkers = h->max_walkers;
   info->device = h->device;
   info->cu_count = h->cu_count;
+  info->pack_probe_rel = h->pack_probe_rel;
   snprintf(info->gcn_arch, sizeof(info->gcn_arch), "%s", h->arch);
   unsigned long long nf = 0;
   HIP_TRY(hipSetDevice(h->device));
@@ -612,8 +621,11 @@ extern "C" int cf_solve_triangular(const double* L, int64_t n, int64_t ld, const
     return fail(CF_ERR_NO_DEVICE, "cf_solve_triangular: no HIP device visible (this library has no CPU path)");
   if (nrhs == 0) return CF_OK;
   cf_host_pack hp;
-  if (pack_default(L, n, ld, hp) != 0)
+  double probe = 0.0;
+  if (pack_default(L, n, ld, hp, &probe) != 0)
     return fail(CF_ERR_NOT_POSDEF, "cf_solve_triangular: non-positive or non-finite diagonal entry");
+  if (!(probe <= CF_PROBE_LIMIT))
+    return fail(CF_ERR_ILL_CONDITIONED, "cf_solve_triangular: blocked solve loses " + std::to_string(probe) + " relative on this factor");
   PackedFactor pf;
   int rc;
   if ((rc = pf.upload(hp))) return rc;

@@ -47,7 +47,8 @@ enum cf_status {
   CF_ERR_NO_DEVICE = -2, /* no HIP device visible */
   CF_ERR_HIP = -3,       /* a HIP runtime call failed */
   CF_ERR_NOT_POSDEF = -4,/* a zero / negative / non-finite pivot in L */
-  CF_ERR_UNSUPPORTED = -5
+  CF_ERR_UNSUPPORTED = -5,
+  CF_ERR_ILL_CONDITIONED = -6 /* the blocked solve would lose more than 1e-11 relative on this factor */
 };
 
 /* Expansion-rate family (a2-a4). */
@@ -204,6 +205,8 @@ typedef struct cf_info {
   int32_t device;
   int32_t cu_count;
   char gcn_arch[64];
+  double pack_probe_rel;   /* |chi2(blocked streams) - chi2(row-by-row substitution)| / chi2 on a probe vector,
+                              measured on the host at cf_create (refused above 1e-11) */
 } cf_info;
 
 int cf_device_count(void);

@@ -89,6 +89,25 @@ def test_packed_factor_replay_matches_forward_substitution(pkg, n):
     assert nbytes.value > 0
 
 
+def test_pack_probe_flags_ill_conditioned_blocks(pkg):
+    """The create-time probe compares the blocked streams with row-by-row substitution; the self-test entry
+    exposes the same replay, so an ill-conditioned diagonal block must show a large discrepancy here."""
+    from oracle import oracle_c as oc
+
+    n = 200
+    rng = np.random.default_rng(0)
+    good = np.linalg.cholesky(np.diag(rng.uniform(0.01, 0.09, n)) + 1e-4 * np.ones((n, n)))
+    bad = np.tril(rng.standard_normal((n, n)), -1) * 3.0 + np.diag(np.full(n, 1e-3))  # cond ~ 1e40: hopeless
+    b = rng.standard_normal(n)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    chi2 = C.c_double()
+    pkg._lib.check(pkg.lib().cf_selftest_pack_host(p(good), n, n, p(b), C.byref(chi2), None))
+    assert chi2.value == pytest.approx(oc.solve_triangular(good, b), rel=1e-12)
+    pkg._lib.check(pkg.lib().cf_selftest_pack_host(p(bad), n, n, p(b), C.byref(chi2), None))
+    ref = oc.solve_triangular(bad, b)
+    assert not np.isfinite(chi2.value) or abs(chi2.value - ref) > 1e-11 * abs(ref)
+
+
 def test_packed_factor_rejects_bad_pivot(pkg):
     Lm = np.eye(20)
     Lm[7, 7] = 0.0

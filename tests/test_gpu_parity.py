@@ -246,3 +246,16 @@ def test_in_kernel_log10_is_within_one_ulp(gpu):
     assert ulp.max() <= 1.0, f"max error {ulp.max()} ulp"
     assert out[x == 1.0][0] == 0.0 and out[x == 10.0][0] == 1.0
     assert out[-5] == -np.inf and np.isnan(out[-4]) and out[-3] == np.inf and np.isnan(out[-2])
+
+
+def test_ill_conditioned_factor_is_refused_not_silently_wrong(gpu, config2):
+    lk, _, _ = config2
+    assert lk.engine.info()["pack_probe_rel"] < 1e-13  # well-conditioned synthetic Pantheon+ factor
+    n = 300
+    rng = np.random.default_rng(0)
+    bad = np.tril(rng.standard_normal((n, n)), -1) * 3.0 + np.diag(np.full(n, 1e-3))
+    with pytest.raises(gpu.CosmofitError, match="CF_ERR_ILL_CONDITIONED"):
+        gpu.solve_triangular.solve_triangular(bad, rng.standard_normal(n))
+    z = np.sort(rng.uniform(0.01, 1.0, n))
+    with pytest.raises(gpu.CosmofitError, match="CF_ERR_ILL_CONDITIONED"):
+        gpu.sn_pantheon.PantheonLikelihood(z, z, 40 + 0 * z, chol=bad)
