@@ -8,10 +8,14 @@ partner of every active walker from the complementary half, which lives on all r
 walker positions per half-step (W_local x ndim doubles per rank; 128 KiB at 4096 x 4: latency-bound, so a
 single flat all-gather, no bucketing).
 
-The move implemented here is the Goodman & Weare stretch move (emcee's default, used by the reference's
-quasars/ scripts; sn/pantheon.py:114-117 mixes KDE and DE moves, which need the same gathered complementary
-set).  Random numbers come from a counter-based generator keyed on (seed, step, half, GLOBAL walker index,
-stream), so a chain is bit-identical for any number of ranks — that is what the gloo tests check.
+Moves (the ones the reference's scripts configure on emcee): the Goodman & Weare stretch move (emcee's
+default, used by the reference's quasars/ scripts), the differential-evolution move and the KDE move with
+Silverman's bandwidth (``moves = [(KDEMove(bw_method="silverman"), 0.30), (DEMove(), 0.70)]``,
+sn/pantheon.py:114-117).  One move is drawn per step with the configured weights, as emcee does.
+Random numbers come from a counter-based generator keyed on (seed, step, half, GLOBAL walker index,
+stream), and every quantity a proposal uses is computed from the gathered (global) ensemble with
+per-element arithmetic, so a chain is bit-identical for any number of ranks — that is what the gloo
+tests check.
 
 `log_prob_fn(theta[W, ndim] tensor) -> tensor[W]` is pluggable: on a GPU it is
 ``LikelihoodEngine.torch_log_prob`` (HIP kernels through cf_eval_device on the current stream).
@@ -63,10 +67,28 @@ def uniform01(seed: int, step: int, half: int, walker_ids: torch.Tensor, stream:
     return _lsr(x, 11).to(torch.float64) * (1.0 / 9007199254740992.0)
 
 
+def normal01(seed: int, step: int, half: int, walker_ids: torch.Tensor, stream: int) -> torch.Tensor:
+    """Standard normals by Box-Muller from two counter-based uniforms (streams `stream`, `stream + 1`)."""
+    u1 = 1.0 - uniform01(seed, step, half, walker_ids, stream)  # (0, 1]
+    u2 = uniform01(seed, step, half, walker_ids, stream + 1)
+    return torch.sqrt(-2.0 * torch.log(u1)) * torch.cos((2.0 * math.pi) * u2)
+
+
+REFERENCE_MOVES = (("kde", 0.30), ("de", 0.70))  # sn/pantheon.py:114-117
+STRETCH_ONLY = (("stretch", 1.0),)
+
+
 class ShardedEnsemble:
     def __init__(self, log_prob_fn: Callable[[torch.Tensor], torch.Tensor], positions: torch.Tensor, *,
-                 seed: int = 42, a: float = 2.0, group=None):
-        """positions: [W_total, ndim] float64 initial ensemble, identical on every rank (it is sliced here)."""
+                 seed: int = 42, a: float = 2.0, moves=STRETCH_ONLY, de_sigma: float = 1e-5, group=None):
+        """positions: [W_total, ndim] float64 initial ensemble, identical on every rank (it is sliced here).
+        moves: sequence of (name, weight), name in {"stretch", "de", "kde"}; one is drawn per step."""
+        names = {"stretch", "de", "kde"}
+        if not moves or any(m not in names or w <= 0 for m, w in moves):
+            raise ValueError(f"moves must be a non-empty sequence of (name in {sorted(names)}, weight > 0)")
+        tot = float(sum(w for _, w in moves))
+        self.moves = [(m, w / tot) for m, w in moves]
+        self.de_sigma = de_sigma
         self.group = group
         self.distributed = dist is not None and dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.distributed else 1
@@ -103,25 +125,74 @@ class ShardedEnsemble:
         dist.all_gather_into_tensor(buf, pad, group=self.group)
         return torch.cat([buf[r * self._max_local: r * self._max_local + (b - a_)] for r, (a_, b) in enumerate(self._counts)])
 
-    # ---- one stretch-move step = two half-steps ----------------------------------------------------------
+    # ---- proposals: (y [n, ndim], log of the Hastings factor [n]) for the active walkers ----------------
+    def _propose_stretch(self, xa, ids, comp, half):
+        nc = comp.shape[0]
+        j = torch.clamp((uniform01(self.seed, self.step_count, half, ids, 0) * nc).to(torch.int64), max=nc - 1)
+        z = ((self.a - 1.0) * uniform01(self.seed, self.step_count, half, ids, 1) + 1.0) ** 2 / self.a
+        partner = comp[j]
+        return partner + z[:, None] * (xa - partner), (self.ndim - 1) * torch.log(z)
+
+    def _propose_de(self, xa, ids, comp, half):
+        """emcee DEMove: q = s + g0 (1 + sigma N(0,1)) (c_j - c_k), j != k, g0 = 2.38 / sqrt(2 ndim); symmetric."""
+        nc = comp.shape[0]
+        j = torch.clamp((uniform01(self.seed, self.step_count, half, ids, 0) * nc).to(torch.int64), max=nc - 1)
+        k = torch.clamp((uniform01(self.seed, self.step_count, half, ids, 1) * (nc - 1)).to(torch.int64), max=nc - 2)
+        k = k + (k >= j).to(torch.int64)
+        gamma = (2.38 / math.sqrt(2 * self.ndim)) * (1.0 + self.de_sigma * normal01(self.seed, self.step_count, half, ids, 3))
+        return xa + gamma[:, None] * (comp[j] - comp[k]), torch.zeros_like(gamma)
+
+    def _kde_logpdf(self, pts, comp, chol_inv_t, log_norm):
+        """log of the Gaussian-KDE density of `comp` at `pts`; per-element arithmetic only (rank-count invariant)."""
+        out = torch.empty(pts.shape[0], dtype=pts.dtype, device=pts.device)
+        wc = comp @ chol_inv_t  # whitened data, same on every rank
+        chunk = max(1, (1 << 24) // max(1, comp.shape[0] * self.ndim))
+        for a0 in range(0, pts.shape[0], chunk):
+            wp = pts[a0:a0 + chunk] @ chol_inv_t
+            d2 = ((wp[:, None, :] - wc[None, :, :]) ** 2).sum(dim=2)
+            out[a0:a0 + chunk] = torch.logsumexp(-0.5 * d2, dim=1) + log_norm
+        return out
+
+    def _propose_kde(self, xa, ids, comp, half):
+        """emcee KDEMove(bw_method="silverman"): independence proposal from the Gaussian KDE of the complementary
+        set, factor = log kde(s) - log kde(q)."""
+        nc, d = comp.shape
+        h = (nc * (d + 2) / 4.0) ** (-1.0 / (d + 4))  # scipy.stats.gaussian_kde.silverman_factor
+        mean = comp.mean(dim=0)
+        cen = comp - mean
+        cov = (cen.T @ cen) / (nc - 1) * (h * h)
+        chol = torch.linalg.cholesky(cov)
+        chol_inv_t = torch.linalg.inv(chol).T.contiguous()
+        log_norm = -math.log(nc) - 0.5 * d * math.log(2.0 * math.pi) - float(torch.log(torch.diagonal(chol)).sum())
+        j = torch.clamp((uniform01(self.seed, self.step_count, half, ids, 0) * nc).to(torch.int64), max=nc - 1)
+        noise = torch.stack([normal01(self.seed, self.step_count, half, ids, 4 + 2 * k) for k in range(d)], dim=1)
+        q = comp[j] + noise @ chol.T
+        return q, self._kde_logpdf(xa, comp, chol_inv_t, log_norm) - self._kde_logpdf(q, comp, chol_inv_t, log_norm)
+
+    def _pick_move(self) -> str:
+        u = float(uniform01(self.seed, self.step_count, 0, torch.tensor([-1], dtype=torch.int64), 7)[0])
+        acc = 0.0
+        for name, w in self.moves:
+            acc += w
+            if u < acc:
+                return name
+        return self.moves[-1][0]
+
+    # ---- one ensemble step = two red/blue half-steps --------------------------------------------------------
     def step(self):
-        half_size = self.n_total // 2
+        move = self._pick_move()
+        propose = {"stretch": self._propose_stretch, "de": self._propose_de, "kde": self._propose_kde}[move]
         for half in (0, 1):
             allpos = self.gather_positions()
-            # active set: walkers with global index parity == half; partners from the other parity
+            # active set: walkers with global index parity == half; the complementary set is the other parity
             active = (self.ids % 2) == half
             if bool(active.any()):
                 ids = self.ids[active]
-                u_partner = uniform01(self.seed, self.step_count, half, ids, 0)
-                u_z = uniform01(self.seed, self.step_count, half, ids, 1)
+                comp = allpos[(1 - half)::2]
                 u_acc = uniform01(self.seed, self.step_count, half, ids, 2)
-                j = torch.clamp((u_partner * half_size).to(torch.int64), max=half_size - 1)
-                partner = allpos[2 * j + (1 - half)]
-                z = ((self.a - 1.0) * u_z + 1.0) ** 2 / self.a
-                xa = self.x[active]
-                y = partner + z[:, None] * (xa - partner)
+                y, log_factor = propose(self.x[active], ids, comp, half)
                 lp_new = self.log_prob_fn(y.contiguous())
-                log_q = (self.ndim - 1) * torch.log(z) + lp_new - self.logp[active]
+                log_q = log_factor + lp_new - self.logp[active]
                 accept = torch.log(u_acc) < log_q
                 idx = torch.nonzero(active, as_tuple=False)[:, 0][accept]
                 self.x[idx] = y[accept]

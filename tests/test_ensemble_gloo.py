@@ -30,10 +30,10 @@ def _init_positions(W):
     return MU + SIG * torch.randn(W, 3, generator=g, dtype=torch.float64)
 
 
-def _worker(rank, world, port, W, steps, path):
+def _worker(rank, world, port, W, steps, path, moves):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    ens = load_pkg().ensemble.ShardedEnsemble(gauss_logp, _init_positions(W), seed=11)
+    ens = load_pkg().ensemble.ShardedEnsemble(gauss_logp, _init_positions(W), seed=11, moves=moves)
     ens.run(steps)
     pos, lp = ens.full_state()
     acc = ens.acceptance_fraction()
@@ -43,14 +43,14 @@ def _worker(rank, world, port, W, steps, path):
     dist.destroy_process_group()
 
 
-def _run(world, W, steps, tmp_path):
+def _run(world, W, steps, tmp_path, moves=(("stretch", 1.0),)):
     path = str(tmp_path / f"w{world}.pt")
     if world == 1:
-        ens = load_pkg().ensemble.ShardedEnsemble(gauss_logp, _init_positions(W), seed=11)
+        ens = load_pkg().ensemble.ShardedEnsemble(gauss_logp, _init_positions(W), seed=11, moves=moves)
         ens.run(steps)
         pos, lp = ens.full_state()
         return {"pos": pos, "lp": lp, "acc": ens.acceptance_fraction()}
-    mp.spawn(_worker, args=(world, _free_port(), W, steps, path), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), W, steps, path, moves), nprocs=world, join=True)
     return torch.load(path)
 
 
@@ -94,3 +94,39 @@ def test_stretch_move_samples_the_target(tmp_path):
     assert torch.allclose(pos.mean(0), MU, atol=float(4 * SIG.max() / np.sqrt(512)))
     assert torch.allclose(pos.std(0), SIG, rtol=0.2)
     assert torch.allclose(out["lp"], gauss_logp(pos))
+
+
+REF_MOVES = (("kde", 0.30), ("de", 0.70))  # sn/pantheon.py:114-117
+
+
+def test_reference_move_mixture_is_bit_identical_across_ranks(tmp_path):
+    ref = _run(1, 64, 20, tmp_path, REF_MOVES)
+    got = _run(2, 64, 20, tmp_path, REF_MOVES)
+    assert torch.equal(ref["pos"], got["pos"]) and torch.equal(ref["lp"], got["lp"])
+    assert ref["acc"] == got["acc"] and 0.05 < ref["acc"] < 0.95
+
+
+@pytest.mark.parametrize("moves", [(("de", 1.0),), (("kde", 1.0),), REF_MOVES])
+def test_de_and_kde_moves_sample_the_target(tmp_path, moves):
+    out = _run(1, 512, 200, tmp_path, moves)
+    pos = out["pos"]
+    assert torch.allclose(pos.mean(0), MU, atol=float(4 * SIG.max() / np.sqrt(512)))
+    assert torch.allclose(pos.std(0), SIG, rtol=0.2)
+    assert torch.allclose(out["lp"], gauss_logp(pos))
+
+
+def test_kde_density_matches_scipy():
+    from scipy.stats import gaussian_kde
+    ens_mod = load_pkg().ensemble
+    g = torch.Generator().manual_seed(3)
+    comp = MU + SIG * torch.randn(200, 3, generator=g, dtype=torch.float64)
+    pts = MU + SIG * torch.randn(50, 3, generator=g, dtype=torch.float64)
+    ens = ens_mod.ShardedEnsemble(gauss_logp, _init_positions(8), moves=(("kde", 1.0),))
+    nc, d = comp.shape
+    h = (nc * (d + 2) / 4.0) ** (-1.0 / (d + 4))
+    cen = comp - comp.mean(0)
+    chol = torch.linalg.cholesky((cen.T @ cen) / (nc - 1) * h * h)
+    log_norm = -np.log(nc) - 0.5 * d * np.log(2 * np.pi) - float(torch.log(torch.diagonal(chol)).sum())
+    got = ens._kde_logpdf(pts, comp, torch.linalg.inv(chol).T.contiguous(), log_norm)
+    ref = gaussian_kde(comp.numpy().T, bw_method="silverman").logpdf(pts.numpy().T)
+    np.testing.assert_allclose(got.numpy(), ref, rtol=1e-10)
