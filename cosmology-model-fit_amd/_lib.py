@@ -14,9 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcosmofit_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-CF_ABI_VERSION = 1
-CF_P_NSLOTS = 9
-SLOTS = ("offset", "H0", "Om", "obh2", "och2", "w0", "wa", "v", "rd")
+CF_ABI_VERSION = 2
+CF_P_NSLOTS = 10
+SLOTS = ("offset", "H0", "Om", "obh2", "och2", "w0", "wa", "v", "rd", "fcc")
 
 # enums of include/cosmofit.h
 CF_EZ_LATE_FLAT, CF_EZ_PHYSICAL = 0, 1
@@ -65,6 +65,10 @@ class cf_desc(C.Structure):
         ("gauss", C.c_void_p),
         ("n_chi2_gauss", C.c_int32), ("_pad2", C.c_int32),
         ("chi2_gauss", C.c_void_p),
+        ("sn_fixed_mu", C.c_void_p),
+        ("n_cc", C.c_int32), ("_pad3", C.c_int32),
+        ("cc_z", C.c_void_p), ("cc_h", C.c_void_p), ("cc_inv_cov", C.c_void_p),
+        ("cc_logdet", C.c_double),
     ]
 
 

@@ -135,7 +135,7 @@ struct cf_handle {
   cf_dev_desc d{};
   PackedFactor pack;
   DevBuf z_cmb, z_hel, obs, sn_step;
-  DevBuf bao_z, bao_val, bao_inv_cov, bao_qty, gl_x, gl_w;
+  DevBuf bao_z, bao_val, bao_inv_cov, bao_qty, gl_x, gl_w, fixed_mu, cc_z, cc_h, cc_inv_cov;
   DevBuf theta, out, delta, ypk, chi2_extra, nonfinite;
   bool has_small_blocks = false;  // BAO and / or CMB block present
   int64_t max_walkers = 0;
@@ -215,6 +215,9 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
     if (c->n_gl < 1 || c->n_gl > CF_MAX_GL || !c->gl_x || !c->gl_w)
       return fail(CF_ERR_INVALID, "cf_create: the CMB block needs 1..256 Gauss-Legendre nodes");
   }
+  if (c->n_cc < 0 || c->n_cc > CF_MAX_CC) return fail(CF_ERR_INVALID, "cf_create: n_cc must be in 0..64");
+  if (c->n_cc > 0 && (!c->cc_z || !c->cc_h || !c->cc_inv_cov))
+    return fail(CF_ERR_INVALID, "cf_create: cosmic-chronometer arrays must not be null");
   if (c->ez_model == CF_EZ_PHYSICAL && !(c->nu_rho0 > 0.0))
     return fail(CF_ERR_INVALID, "cf_create: CF_EZ_PHYSICAL needs the neutrino constants (nu_rho0 > 0)");
   if (c->n_gauss > CF_MAX_GAUSS || c->n_chi2_gauss > CF_MAX_GAUSS || c->n_gauss < 0 || c->n_chi2_gauss < 0)
@@ -287,7 +290,9 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
   d.n_gl = c->cmb_mode ? c->n_gl : 0;
   for (int i = 0; i < 3; ++i) d.cmb_prior[i] = c->cmb_prior[i];
   for (int i = 0; i < 9; ++i) d.cmb_inv_cov[i] = c->cmb_inv_cov[i];
-  h->has_small_blocks = c->n_bao > 0 || c->cmb_mode != CF_CMB_NONE;
+  d.n_cc = c->n_cc;
+  d.cc_logdet = c->cc_logdet;
+  h->has_small_blocks = c->n_bao > 0 || c->cmb_mode != CF_CMB_NONE || c->n_cc > 0;
   d.cpl_wall = c->cpl_wall;
   d.has_bounds = c->bounds != nullptr;
   d.log_norm = 0.0;
@@ -351,6 +356,20 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
     d.bao_val = h->bao_val.as<const double>();
     d.bao_inv_cov = h->bao_inv_cov.as<const double>();
     d.bao_qty = h->bao_qty.as<const int32_t>();
+  }
+  if (c->n_cc > 0) {
+    int rc;
+    if ((rc = upload_vec(h->cc_z, c->cc_z, c->n_cc))) return bail(rc);
+    if ((rc = upload_vec(h->cc_h, c->cc_h, c->n_cc))) return bail(rc);
+    if ((rc = upload_vec(h->cc_inv_cov, c->cc_inv_cov, (int64_t)c->n_cc * c->n_cc))) return bail(rc);
+    d.cc_z = h->cc_z.as<const double>();
+    d.cc_h = h->cc_h.as<const double>();
+    d.cc_inv_cov = h->cc_inv_cov.as<const double>();
+  }
+  if (c->n_sn > 0 && c->sn_fixed_mu) {
+    int rc;
+    if ((rc = upload_vec(h->fixed_mu, c->sn_fixed_mu, c->n_sn))) return bail(rc);
+    d.sn_fixed_mu = h->fixed_mu.as<const double>();
   }
   if (c->cmb_mode != CF_CMB_NONE) {
     int rc;
@@ -542,8 +561,8 @@ extern "C" int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, doubl
   // the SN accessor path (reference-order mu_corr / mu_theory) is selected by a non-null dm / mu_corr buffer
   if (n > 0 && dm.ensure((size_t)W * n * 8)) return CF_ERR_HIP;
   if (n > 0 && mu_corr && mc.ensure((size_t)W * n * 8)) return CF_ERR_HIP;
-  if (blk.ensure((size_t)W * 5 * 8)) return CF_ERR_HIP;
-  HIP_TRY(hipMemsetAsync(blk.p, 0, (size_t)W * 5 * 8, h->stream));
+  if (blk.ensure((size_t)W * 6 * 8)) return CF_ERR_HIP;
+  HIP_TRY(hipMemsetAsync(blk.p, 0, (size_t)W * 6 * 8, h->stream));
   if (nb > 0 && bt.ensure((size_t)W * nb * 8)) return CF_ERR_HIP;
   HIP_TRY(hipMemcpyAsync(h->theta.p, theta, (size_t)W * h->d.ndim * 8, hipMemcpyHostToDevice, h->stream));
   if ((rc = launch_path(h, h->theta.as<const double>(), W, h->out.as<double>(), CF_OUT_CHI2, h->stream,
@@ -557,22 +576,23 @@ extern "C" int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, doubl
                         hipMemcpyDeviceToHost));
   if (bao_theory) HIP_TRY(hipMemcpy(bao_theory, bt.p, (size_t)W * nb * 8, hipMemcpyDeviceToHost));
   if (chi2_blocks) {
-    std::vector<double> tot((size_t)W), b5((size_t)W * 5);
+    std::vector<double> tot((size_t)W), b6((size_t)W * 6);
     HIP_TRY(hipMemcpy(tot.data(), h->out.p, (size_t)W * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(b5.data(), blk.p, (size_t)W * 5 * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(b6.data(), blk.p, (size_t)W * 6 * 8, hipMemcpyDeviceToHost));
     for (int64_t w = 0; w < W; ++w) {
       double gauss = 0.0;
       for (int g = 0; g < h->d.n_chi2_gauss; ++g) {
         double diff = theta[w * h->d.ndim + h->d.chi2_gauss_idx[g]] - h->d.chi2_gauss_mean[g];
         gauss += diff * diff / (h->d.chi2_gauss_sigma[g] * h->d.chi2_gauss_sigma[g]);
       }
-      // sn = total - bao - cmb - Gaussian terms; then bao, cmb, and the CMB distance vector
-      chi2_blocks[6 * w + 0] = tot[w] - b5[5 * w + 0] - b5[5 * w + 1] - gauss;
-      chi2_blocks[6 * w + 1] = b5[5 * w + 0];
-      chi2_blocks[6 * w + 2] = b5[5 * w + 1];
-      chi2_blocks[6 * w + 3] = b5[5 * w + 2];
-      chi2_blocks[6 * w + 4] = b5[5 * w + 3];
-      chi2_blocks[6 * w + 5] = b5[5 * w + 4];
+      // sn = total - bao - cmb - cc - Gaussian terms; then bao, cmb, the CMB distance vector, cc
+      chi2_blocks[7 * w + 0] = tot[w] - b6[6 * w + 0] - b6[6 * w + 1] - b6[6 * w + 5] - gauss;
+      chi2_blocks[7 * w + 1] = b6[6 * w + 0];
+      chi2_blocks[7 * w + 2] = b6[6 * w + 1];
+      chi2_blocks[7 * w + 3] = b6[6 * w + 2];
+      chi2_blocks[7 * w + 4] = b6[6 * w + 3];
+      chi2_blocks[7 * w + 5] = b6[6 * w + 4];
+      chi2_blocks[7 * w + 6] = b6[6 * w + 5];
     }
   }
   return CF_OK;

@@ -10,7 +10,8 @@
 #define CF_MAX_GAUSS 8
 #define CF_MAX_BAO 64
 #define CF_MAX_GL 256
-#define CF_N_SLOTS 9
+#define CF_MAX_CC 64
+#define CF_N_SLOTS 10
 
 // One block row of the blocked solve = 16 MFMA tiles of 16 rows.
 #define CF_BLOCK_TILES 16
@@ -34,6 +35,7 @@
 #define CF_P_WA_D 6
 #define CF_P_V_D 7
 #define CF_P_RD_D 8
+#define CF_P_FCC_D 9
 
 #define CF_OUT_CHI2_D 0
 #define CF_OUT_LOGL_D 1
@@ -59,6 +61,13 @@ struct cf_dev_desc {
   const double* obs;
   const double* sn_step;
   int32_t has_vstep, pad1;  // 0: the likelihood has no peculiar-velocity step (z_cosmo = z_cmb)
+  const double* sn_fixed_mu;  // [n_sn] or null; non-NaN entries replace mu_theory (SH0ES calibrators)
+  // cosmic chronometers
+  int32_t n_cc, pad3;
+  const double* cc_z;
+  const double* cc_h;
+  const double* cc_inv_cov;
+  double cc_logdet;
   // radiation + massive neutrinos (CF_EZ_PHYSICAL)   cmb/data_planck_act_compression.py:29-66
   double or_h2, omnu_h2, o_gamma_h2, nu_m0, nu_rho0;
   double nu_qs_sq[5], nu_ws[5];

@@ -334,7 +334,7 @@ __device__ double r_drag_fit(const double* f, double wb, double wm) {
 // the quadratic form with the explicit inverse covariance.  CMB (cmb/data_planck_act_compression.py
 // :160-212): thread t < n_gl evaluates node t of the sound-horizon integral, thread n_gl + t node t
 // of the distance integral; thread 0 adds them in node order like the reference's loop.
-// chi2_extra[w] = chi2_bao + chi2_cmb;  blocks_out[w] = (bao, cmb, cmb vector[3]), bao_out[w][k] optional.
+// chi2_extra[w] = chi2_bao + chi2_cmb + chi2_cc;  blocks_out[w] = (bao, cmb, cmb vector[3], cc), bao_out[w][k] optional.
 // ------------------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(CF_TPB_A, 4)
 walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double* __restrict__ delta,
@@ -342,7 +342,7 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
               double* __restrict__ blocks_out, double* __restrict__ bao_out) {
   extern __shared__ __align__(16) d2 lds_tab[];
   __shared__ double wave_tot[16];
-  __shared__ double scratch[2 * CF_MAX_GL + CF_MAX_BAO + 8];
+  __shared__ double scratch[2 * CF_MAX_GL + CF_MAX_BAO + CF_MAX_CC + 8];
 
   const int64_t w = blockIdx.x;
   if (w >= W) return;
@@ -378,7 +378,14 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
           z_cosmo = -1.0 + (1.0 + zc) / (1.0 + z_pec);
         }
         const double DMc = hermite_tab(T, z_cosmo);
-        if (!parts) {
+        const double fixed = d.sn_fixed_mu ? d.sn_fixed_mu[i] : __longlong_as_double(0x7ff8000000000000ll);
+        if (fixed == fixed) {  // calibrator: its distance modulus is data, only mu_corr is theory (sn/pantheon_and_sh0es.py:65-67)
+          const double DM = hermite_tab(T, zc);
+          const double mu_corr = d.has_vstep ? 5.0 * log10_pos(DMc / DM) : 0.0;
+          res = d.obs[i] - off - mu_corr - fixed;
+          if (dm_out) dm_out[w * d.n_sn + i] = DM;
+          if (mucorr_out) mucorr_out[w * d.n_sn + i] = mu_corr;
+        } else if (!parts) {
           res = d.obs[i] - off - (25.0 + 5 * log10_pos((1.0 + d.z_hel[i]) * DMc));
         } else {
           const double DM = hermite_tab(T, zc);
@@ -392,7 +399,7 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
       out[i] = res;  // rows >= n_sn are zero padding for the 16-row MFMA tiles
     }
   }
-  if (d.n_bao == 0 && d.cmb_mode == 0) {
+  if (d.n_bao == 0 && d.cmb_mode == 0 && d.n_cc == 0) {
     if (tid == 0 && chi2_extra) chi2_extra[w] = 0.0;
     return;
   }
@@ -400,11 +407,17 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
   // ---- scalars shared by the two small blocks ----
   double* gl_terms = scratch;                   // [2*n_gl]
   double* bao_delta = scratch + 2 * CF_MAX_GL;  // [n_bao]
-  double* shared = bao_delta + CF_MAX_BAO;      // [0] = z_star, [1] = r_d
+  double* cc_delta = bao_delta + CF_MAX_BAO;    // [n_cc]
+  double* shared = cc_delta + CF_MAX_CC;        // [0] = z_star, [1] = r_d
   const double Ob = slot_get(d, CF_P_OBH2_D, th), Oc = slot_get(d, CF_P_OCH2_D, th);
   if (tid == 0) {
     if (d.cmb_mode) shared[0] = z_star_fit(d.zstar_fit, Ob, Oc + Ob + d.omnu_h2);
     shared[1] = d.rd_from_fit ? r_drag_fit(d.rd_fit, Ob, Ob + Oc + d.omnu_h2) : slot_get(d, CF_P_RD_D, th);
+  }
+  // ---- cosmic chronometers: H_obs - H(z), bao/desi_union3_cc_theta_star.py:129 (last threads of the block) ----
+  if (tid >= CF_TPB_A - d.n_cc) {
+    const int k = CF_TPB_A - 1 - tid;
+    cc_delta[k] = d.cc_h[k] - H_of_z(d, wc, d.cc_z[k]);
   }
   __syncthreads();
 
@@ -473,10 +486,20 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
           c_cmb += t * dl[j];
         }
       }
-      if (blocks_out) { blocks_out[5 * w + 2] = vec[0]; blocks_out[5 * w + 3] = vec[1]; blocks_out[5 * w + 4] = vec[2]; }
+      if (blocks_out) { blocks_out[6 * w + 2] = vec[0]; blocks_out[6 * w + 3] = vec[1]; blocks_out[6 * w + 4] = vec[2]; }
     }
-    if (chi2_extra) chi2_extra[w] = c_cmb + c_bao;
-    if (blocks_out) { blocks_out[5 * w + 0] = c_bao; blocks_out[5 * w + 1] = c_cmb; }
+    double c_cc = 0.0;
+    if (d.n_cc > 0) {  // delta @ inv_cov @ delta * f_cc^2
+      for (int j = 0; j < d.n_cc; ++j) {
+        double t = 0.0;
+        for (int i = 0; i < d.n_cc; ++i) t += cc_delta[i] * d.cc_inv_cov[i * d.n_cc + j];
+        c_cc += t * cc_delta[j];
+      }
+      const double f = slot_get(d, CF_P_FCC_D, th);
+      c_cc *= f * f;
+    }
+    if (chi2_extra) chi2_extra[w] = c_cmb + c_bao + c_cc;
+    if (blocks_out) { blocks_out[6 * w + 0] = c_bao; blocks_out[6 * w + 1] = c_cmb; blocks_out[6 * w + 5] = c_cc; }
   }
 }
 
@@ -509,7 +532,10 @@ __device__ double finalize_value(const cf_dev_desc& d, const double* __restrict_
     atomicAdd(nonfinite, 1ull);
     return -INFINITY;
   }
-  return lp - 0.5 * chi2;
+  double ll = -0.5 * chi2;
+  if (d.n_cc > 0)  // Gaussian normalisation with rescaled errors, bao/desi_union3_cc_theta_star.py:135-139
+    ll -= 0.5 * (d.n_cc * 1.8378770664093453 + d.cc_logdet - 2 * d.n_cc * log(slot_get(d, CF_P_FCC_D, th)));
+  return lp + ll;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -41,12 +41,16 @@ class LikelihoodEngine:
     def __init__(self, *, ndim: int, z_max: float, n_grid: int = 4000, fde: int = L.CF_FDE_LCDM,
                  ez_model: int = L.CF_EZ_LATE_FLAT, params: dict, sn: Optional[dict] = None,
                  bao: Optional[dict] = None, cmb: Optional[dict] = None, physical: Optional[dict] = None,
+                 cc: Optional[dict] = None,
                  bounds=None, gauss: Sequence = (), chi2_gauss: Sequence = (), cpl_wall: bool = False,
                  device: int = 0, c_km_s: float = C_KM_S):
         """
         params: {"H0": Param(1), "Om": Param(2), ...} for the slots of include/cosmofit.h (cf_param_slot).
-        sn: dict(z_cmb, z_hel, obs, chol[, step | z_turn]) — chol is cho_factor(cov, lower=True)[0];
-            the strict upper triangle is never read.
+        sn: dict(z_cmb, z_hel, obs, chol[, step | z_turn, fixed_mu]) — chol is cho_factor(cov, lower=True)[0];
+            the strict upper triangle is never read; fixed_mu[i] (NaN = none) replaces mu_theory for SN i
+            (SH0ES Cepheid hosts, sn/pantheon_and_sh0es.py:63-69).
+        cc: dict(z, h, inv_cov, logdet) — cosmic chronometers with the rescale parameter slot "fcc"
+            (bao/desi_union3_cc_theta_star.py:129-139).
         bao: dict(z, val, qty (0 DV/rd, 1 DM/rd, 2 DH/rd, 3 F_AP), inv_cov[, dh_exact=False, rd_fit=None]);
             rd_fit = (b, m, a1..a9) selects the r_drag fitting formula, otherwise the "rd" slot is used.
         cmb: dict(mode (1 R-lA-wb, 2 lA only, 3 theta*-wb-wm), prior[3], inv_cov[3,3], zstar_fit (s1,s2,b,m)[, n_gl=100]).
@@ -64,7 +68,7 @@ class LikelihoodEngine:
         if unknown:
             raise ValueError(f"unknown parameter slots {sorted(unknown)}; valid: {L.SLOTS}")
         for i, name in enumerate(L.SLOTS):
-            p = params.get(name, Param(fixed=-1.0) if name == "w0" else Param())
+            p = params.get(name, Param(fixed=-1.0) if name == "w0" else (Param(fixed=1.0) if name == "fcc" else Param()))
             d.param[i].idx, d.param[i].scale, d.param[i].fixed = p.idx, p.scale, p.fixed
         keep = []
         if sn is not None:
@@ -78,6 +82,12 @@ class LikelihoodEngine:
             d.sn_z_cmb, d.sn_z_hel, d.sn_obs, d.sn_step = _ptr(z_cmb), _ptr(z_hel), _ptr(obs), _ptr(step)
             d.sn_z_turn = float(sn.get("z_turn", 0.15))
             d.sn_chol, d.sn_chol_ld = _ptr(chol), chol.shape[1]
+            if sn.get("fixed_mu") is not None:
+                fm = _f64(sn["fixed_mu"])
+                if fm.size != z_cmb.size:
+                    raise ValueError("sn['fixed_mu'] must have one entry per SN (NaN where unused)")
+                keep.append(fm)
+                d.sn_fixed_mu = _ptr(fm)
         self.n_bao = 0
         if physical is not None:
             d.or_h2, d.omnu_h2, d.o_gamma_h2 = physical["or_h2"], physical["omnu_h2"], physical["o_gamma_h2"]
@@ -96,6 +106,12 @@ class LikelihoodEngine:
                 d.rd_mode = 1
                 d.rd_fit[:] = [float(x) for x in bao["rd_fit"]]
             self.n_bao = int(bz.size)
+        if cc is not None:
+            cz, ch, cinv = _f64(cc["z"]), _f64(cc["h"]), _f64(cc["inv_cov"])
+            if cz.size != ch.size or cinv.shape != (cz.size, cz.size):
+                raise ValueError("cc: z, h must have n entries and inv_cov must be (n, n)")
+            keep += [cz, ch, cinv]
+            d.n_cc, d.cc_z, d.cc_h, d.cc_inv_cov, d.cc_logdet = cz.size, _ptr(cz), _ptr(ch), _ptr(cinv), float(cc["logdet"])
         if cmb is not None:
             from .cmb_data import ZSTAR_CONSTS
             gx, gw = np.polynomial.legendre.leggauss(int(cmb.get("n_gl", 100)))  # cmb/data_planck_act_compression.py:150
@@ -186,16 +202,17 @@ class LikelihoodEngine:
 
     def parts(self, theta):
         """Intermediates of a (small) batch — for plots and tests: DM(z_cmb), mu_corr, residual (SN block);
-        chi2_blocks[:, 0:3] = (sn, bao, cmb), cmb_vector = the compressed-CMB theory 3-vector, bao_theory."""
+        chi2_blocks[:, 0:3] = (sn, bao, cmb), cmb_vector = the compressed-CMB theory 3-vector, chi2_cc, bao_theory."""
         th = np.atleast_2d(_f64(theta))
         W, n, nb = th.shape[0], self.n_sn, self.n_bao
         dm = np.empty((W, n)) if n else None
         mc = np.empty((W, n)) if n else None
         dl = np.empty((W, n)) if n else None
         bt = np.empty((W, nb)) if nb else None
-        blocks = np.empty((W, 6))
+        blocks = np.empty((W, 7))
         L.check(L.lib().cf_eval_parts(self._h, _ptr(th), W, _ptr(dm), _ptr(mc), _ptr(dl), _ptr(blocks), _ptr(bt)))
-        return dict(dm=dm, mu_corr=mc, delta=dl, chi2_blocks=blocks[:, :3], cmb_vector=blocks[:, 3:], bao_theory=bt)
+        return dict(dm=dm, mu_corr=mc, delta=dl, chi2_blocks=blocks[:, :3], cmb_vector=blocks[:, 3:6], chi2_cc=blocks[:, 6],
+                    bao_theory=bt)
 
     def enable_timing(self, slots=1):
         """Keep HIP-event timings of the last `slots` evaluations (0 = off)."""

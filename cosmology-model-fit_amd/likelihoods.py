@@ -9,6 +9,9 @@ from disk here.
     bao/desi_fs_lya_cmb.py              -> DesiFsLyaCmb         (BAO FS+Lya incl. F_AP + Planck/ACT, CPL, w0+wa wall)
     bao/desi_cmb_des5y.py               -> DesiCmbDes5y         (SN + BAO + CMB, BASELINE config 3 as shipped)
     bao/desi_des5y_bbn_theta_star.py    -> DesiDes5yBbnThetaStar(SN + BAO + l_A + BBN prior, BASELINE config 5)
+    sn/union3_1.py                      -> SnUnion3             (22 binned distances, explicit inverse covariance)
+    bao/desi_union3_cc_theta_star.py    -> DesiUnion3CcThetaStar(Union3 + BAO + l_A + cosmic chronometers with f_cc)
+    sn/pantheon_dipole.py, sn/pantheon_and_sh0es.py -> sn_pantheon.PantheonLikelihood(step=..., fixed_mu=...)
 """
 import numpy as np
 from scipy.linalg import cho_factor
@@ -138,3 +141,36 @@ class DesiDes5yBbnThetaStar(_Base):
             bao=dict(z=bao_z, val=bao_val, qty=bao_qty, inv_cov=bao_inv_cov, dh_exact=True, rd_fit=comp["rd_fit"]),
             cmb=dict(mode=2, prior=comp["cmb_prior"], inv_cov=inv, zstar_fit=comp["zstar_fit"]),
             physical=_physical(comp), bounds=self.bounds, gauss=[(2, bbn[0], bbn[1])], device=device)
+
+
+class SnUnion3(_Base):
+    """sn/union3_1.py: theta = (dM, Om, v); H0 fixed to 70 (:11), velocity step at z = 0.2 (:40).  The reference
+    multiplies by the explicit inverse covariance (:57); the engine solves with its Cholesky factor (same chi^2)."""
+
+    def __init__(self, z_cmb, z_hel, mu_vals, cov_matrix, *, H0=70.0, device=0):
+        self.z_max = float(np.max(z_cmb) + 0.1)
+        self.engine = LikelihoodEngine(
+            ndim=3, z_max=self.z_max, n_grid=N_GRID, fde=L.CF_FDE_LCDM,
+            params=dict(offset=Param(0), H0=Param(fixed=H0), Om=Param(1), v=Param(2)),
+            sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=mu_vals, chol=np.linalg.cholesky(cov_matrix), z_turn=0.2), device=device)
+
+
+class DesiUnion3CcThetaStar(_Base):
+    """bao/desi_union3_cc_theta_star.py: theta = (f_cc, dM, H0, wb, wc, v).  Union3.1 SN (explicit inverse in the
+    reference), DESI BAO with exact D_H, l_A only, cosmic chronometers: chi2_cc * f_cc^2 and the Gaussian
+    normalisation with rescaled errors in log L (:129-139).  nautilus vectorized callback: ``log_likelihood``."""
+
+    def __init__(self, z_cmb, z_hel, mu_values, cov_sn, bao_z, bao_val, bao_qty, bao_inv_cov, z_cc, H_cc, cov_cc, *,
+                 comp=None, device=0):
+        comp = cmb_data.PLANCK_ACT if comp is None else comp
+        inv = np.zeros((3, 3))
+        inv[1, 1] = 1.0 / comp["cmb_cov"][1, 1]
+        self.z_max = float(max(np.max(z_cmb), np.max(bao_z)) + 0.1)  # :24
+        self.engine = LikelihoodEngine(
+            ndim=6, z_max=self.z_max, n_grid=N_GRID, ez_model=L.CF_EZ_PHYSICAL, fde=L.CF_FDE_LCDM,
+            params=dict(fcc=Param(0), offset=Param(1), H0=Param(2), obh2=Param(3), och2=Param(4), v=Param(5)),
+            sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=mu_values, chol=np.linalg.cholesky(cov_sn), z_turn=0.2),
+            bao=dict(z=bao_z, val=bao_val, qty=bao_qty, inv_cov=bao_inv_cov, dh_exact=True, rd_fit=comp["rd_fit"]),
+            cmb=dict(mode=2, prior=comp["cmb_prior"], inv_cov=inv, zstar_fit=comp["zstar_fit"]),
+            cc=dict(z=z_cc, h=H_cc, inv_cov=np.linalg.inv(cov_cc), logdet=np.linalg.slogdet(cov_cc)[1]),
+            physical=_physical(comp), device=device)

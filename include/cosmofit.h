@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 1
+#define CF_ABI_VERSION 2
 
 typedef struct cf_handle cf_handle;
 
@@ -79,7 +79,8 @@ enum cf_param_slot {
   CF_P_WA = 6,
   CF_P_V = 7,      /* peculiar-velocity step amplitude in units of 100 km/s (mu_corr) */
   CF_P_RD = 8,     /* sound horizon in Mpc when fixed or free (BAO block) */
-  CF_P_NSLOTS = 9
+  CF_P_FCC = 9,    /* error-rescale factor of the cosmic-chronometer block (default: fixed 1) */
+  CF_P_NSLOTS = 10
 };
 
 typedef struct cf_param {
@@ -193,6 +194,20 @@ typedef struct cf_desc {
   int32_t n_chi2_gauss;
   int32_t _pad2;
   const cf_gauss_prior* chi2_gauss;
+
+  /* ---- SN block extension: fixed distance moduli (SH0ES Cepheid hosts) ---- */
+  const double* sn_fixed_mu; /* [n_sn] or NULL; entry NaN -> mu_theory, else this value replaces
+                                25 + 5 log10((1+z_hel) DM)          sn/pantheon_and_sh0es.py:63-69 */
+
+  /* ---- cosmic-chronometer block (n_cc = 0 -> absent)  bao/desi_union3_cc_theta_star.py:129-139 ----
+   * chi2_cc = (H_obs - H(z))^T inv_cov (H_obs - H(z)) * f_cc^2 and
+   * log L -= 0.5 * (n_cc ln(2 pi) + logdet - 2 n_cc ln f_cc) */
+  int32_t n_cc;
+  int32_t _pad3;
+  const double* cc_z;       /* [n_cc] */
+  const double* cc_h;       /* [n_cc] km/s/Mpc */
+  const double* cc_inv_cov; /* [n_cc*n_cc] */
+  double cc_logdet;         /* ln det of the CC covariance */
 } cf_desc;
 
 typedef struct cf_info {
@@ -230,7 +245,7 @@ int cf_eval_device(cf_handle* h, const double* d_theta, int64_t W, double* d_out
  *   dm_obs [W*n_sn]  DM(z_cmb)           sn/pantheon.py:58
  *   mu_corr[W*n_sn]                      sn/pantheon.py:43-49
  *   delta  [W*n_sn]  residual vector     sn/pantheon.py:59-60
- *   chi2_blocks[W*6] (chi2_sn, chi2_bao, chi2_cmb, cmb distance vector[3])
+ *   chi2_blocks[W*7] (chi2_sn, chi2_bao, chi2_cmb, cmb distance vector[3], chi2_cc)
  *                                        bao/desi_cmb_des5y.py:126-141, cmb/data_planck_act_compression.py:200-212
  *   bao_theory[W*n_bao]                  bao/desi_cmb_des5y.py:82-100 */
 int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, double* dm_obs, double* mu_corr,

@@ -34,7 +34,7 @@
 #endif
 
 enum { CO_FDE_LCDM = 0, CO_FDE_WCDM = 1, CO_FDE_THAWING = 2, CO_FDE_CPL = 3 };
-enum { CO_P_OFFSET = 0, CO_P_H0, CO_P_OM, CO_P_OBH2, CO_P_OCH2, CO_P_W0, CO_P_WA, CO_P_V, CO_P_RD, CO_P_NSLOTS };
+enum { CO_P_OFFSET = 0, CO_P_H0, CO_P_OM, CO_P_OBH2, CO_P_OCH2, CO_P_W0, CO_P_WA, CO_P_V, CO_P_RD, CO_P_FCC, CO_P_NSLOTS };
 
 typedef struct co_slot {
   int32_t idx;
@@ -69,6 +69,12 @@ typedef struct co_desc {
   double cmb_prior[3], cmb_inv_cov[9], zstar_fit[4];
   int32_t n_chi2_gauss, pad3;
   const double* chi2_gauss; /* [n*3] */
+  /* --- SH0ES calibrators (sn/pantheon_and_sh0es.py:63-69) and cosmic chronometers
+         (bao/desi_union3_cc_theta_star.py:129-139) --- */
+  const double* fixed_mu; /* [n_sn] NaN -> theory, or NULL */
+  int32_t n_cc, pad4;
+  const double *cc_z, *cc_h, *cc_inv_cov;
+  double cc_logdet;
 } co_desc;
 
 static inline double slot_get(const co_slot* s, const double* th) {
@@ -339,6 +345,7 @@ static void sn_delta(const co_desc* d, const double* th, co_work* w, double* dm_
       mu_corr = 5.0 * log10(cubic_eval(z_cosmo, w->zg, w->cum, w->dh, d->n_grid, 1) / DM);
     }
     double mu_th = 25.0 + 5 * log10((1.0 + d->z_hel[i]) * DM);
+    if (d->fixed_mu && !isnan(d->fixed_mu[i])) mu_th = d->fixed_mu[i];
     w->delta[i] = d->obs[i] - off - mu_corr - mu_th;
     if (dm_obs) dm_obs[i] = DM;
     if (mu_corr_out) mu_corr_out[i] = mu_corr;
@@ -357,6 +364,16 @@ static double chi2_one_blocks(const co_desc* d, const double* th, co_work* w, do
   if (d->cmb_mode) cmb = chi2_cmb(d, th);
   if (blocks) { blocks[0] = sn; blocks[1] = bao; blocks[2] = cmb; }
   double total = cmb + bao + sn; /* bao/desi_cmb_des5y.py:141 */
+  if (d->n_cc > 0) { /* bao/desi_union3_cc_theta_star.py:129-130 */
+    double dl[64], acc = 0.0, f = slot_get(&d->slot[CO_P_FCC], th);
+    for (int k = 0; k < d->n_cc; k++) dl[k] = d->cc_h[k] - H_of_z(d, d->cc_z[k], th);
+    for (int j = 0; j < d->n_cc; j++) {
+      double t = 0.0;
+      for (int i = 0; i < d->n_cc; i++) t += dl[i] * d->cc_inv_cov[i * d->n_cc + j];
+      acc += t * dl[j];
+    }
+    total += acc * (f * f);
+  }
   for (int g = 0; g < d->n_chi2_gauss; g++) {
     double diff = th[(int)d->chi2_gauss[3 * g]] - d->chi2_gauss[3 * g + 1], sg = d->chi2_gauss[3 * g + 2];
     total += diff * diff / (sg * sg);
@@ -367,7 +384,10 @@ static double chi2_one(const co_desc* d, const double* th, co_work* w) { return 
 
 static double logl_one(const co_desc* d, const double* th, co_work* w) {
   if (d->cpl_wall && slot_get(&d->slot[CO_P_W0], th) + slot_get(&d->slot[CO_P_WA], th) >= 0.0) return -1e8;
-  return -0.5 * chi2_one(d, th, w);
+  double ll = -0.5 * chi2_one(d, th, w);
+  if (d->n_cc > 0) /* bao/desi_union3_cc_theta_star.py:135-139 */
+    ll -= 0.5 * (d->n_cc * log(2 * M_PI) + d->cc_logdet - 2 * d->n_cc * log(slot_get(&d->slot[CO_P_FCC], th)));
+  return ll;
 }
 
 /* sn/pantheon.py:80-85 */

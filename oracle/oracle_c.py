@@ -14,8 +14,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libcosmofit_oracle.so")
-NSLOTS = 9
-SLOT_NAMES = ("offset", "H0", "Om", "obh2", "och2", "w0", "wa", "v", "rd")
+NSLOTS = 10
+SLOT_NAMES = ("offset", "H0", "Om", "obh2", "och2", "w0", "wa", "v", "rd", "fcc")
 
 
 class _Slot(C.Structure):
@@ -44,6 +44,10 @@ class _Desc(C.Structure):
         ("cmb_prior", C.c_double * 3), ("cmb_inv_cov", C.c_double * 9), ("zstar_fit", C.c_double * 4),
         ("n_chi2_gauss", C.c_int32), ("pad3", C.c_int32),
         ("chi2_gauss", C.c_void_p),
+        ("fixed_mu", C.c_void_p),
+        ("n_cc", C.c_int32), ("pad4", C.c_int32),
+        ("cc_z", C.c_void_p), ("cc_h", C.c_void_p), ("cc_inv_cov", C.c_void_p),
+        ("cc_logdet", C.c_double),
     ]
 
 
@@ -121,6 +125,12 @@ class COracle:
         k["chi2_gauss"] = _f64(np.array(lk.chi2_gauss, dtype=np.float64).reshape(-1, 3)) if len(lk.chi2_gauss) else None
         d.n_chi2_gauss = 0 if k["chi2_gauss"] is None else len(k["chi2_gauss"])
         d.chi2_gauss = _p(k["chi2_gauss"])
+        k["fixed_mu"] = _f64(lk.fixed_mu)
+        d.fixed_mu = _p(k["fixed_mu"])
+        if lk.cc_z is not None:
+            k.update(cc_z=_f64(lk.cc_z), cc_h=_f64(lk.cc_h), cc_inv_cov=_f64(lk.cc_inv_cov))
+            d.n_cc, d.cc_z, d.cc_h, d.cc_inv_cov = len(k["cc_z"]), _p(k["cc_z"]), _p(k["cc_h"]), _p(k["cc_inv_cov"])
+            d.cc_logdet = float(lk.cc_logdet)
         self.d = d
         self.threads_used = 1
 

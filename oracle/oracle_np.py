@@ -154,6 +154,7 @@ class Likelihood:
     wa: Slot = field(default_factory=Slot)
     v: Slot = field(default_factory=Slot)
     rd: Slot = field(default_factory=Slot)
+    fcc: Slot = field(default_factory=lambda: Slot(fixed=1.0))
     # SN block
     z_cmb: Optional[np.ndarray] = None
     z_hel: Optional[np.ndarray] = None
@@ -162,6 +163,12 @@ class Likelihood:
     z_turn: float = 0.15
     chol: Optional[np.ndarray] = None
     has_vstep: bool = True  # False: no peculiar-velocity step at all (z_cosmo = z_cmb, mu_corr = 0)
+    fixed_mu: Optional[np.ndarray] = None  # per SN: NaN -> mu_theory, else this distance modulus (SH0ES calibrators)
+    # cosmic-chronometer block: H(z) data with explicit inverse covariance and error-rescale parameter f_cc
+    cc_z: Optional[np.ndarray] = None
+    cc_h: Optional[np.ndarray] = None
+    cc_inv_cov: Optional[np.ndarray] = None
+    cc_logdet: float = 0.0
     # radiation + massive-neutrino constants of a cmb.data_*_compression module (EZ_PHYSICAL)
     or_h2: float = 0.0
     omnu_h2: float = 0.0
@@ -356,8 +363,16 @@ def sn_parts(lk: Likelihood, theta, tables=None):
     else:  # bao/desi_des5y_bbn_theta_star.py:94-97: no step term at all
         mu_corr = np.zeros_like(DM)
     mu_theory = 25.0 + 5 * np.log10((1.0 + lk.z_hel) * DM)
+    if lk.fixed_mu is not None:  # sn/pantheon_and_sh0es.py:65
+        mu_theory = np.where(np.isnan(lk.fixed_mu), mu_theory, lk.fixed_mu)
     delta = lk.obs - lk.offset.get(theta) - mu_corr - mu_theory
     return DM, mu_corr, mu_theory, delta
+
+
+def chi2_cc(lk: Likelihood, theta) -> float:
+    """bao/desi_union3_cc_theta_star.py:129-130."""
+    delta = lk.cc_h - H_z(lk, lk.cc_z, theta)
+    return float(delta @ lk.cc_inv_cov @ delta * lk.fcc.get(theta) ** 2)
 
 
 def chi2_blocks(lk: Likelihood, theta):
@@ -380,6 +395,8 @@ def chi_squared(lk: Likelihood, theta) -> float:
     theta = np.asarray(theta, dtype=np.float64)
     sn, bao, cmb = chi2_blocks(lk, theta)
     total = cmb + bao + sn
+    if lk.cc_z is not None:
+        total += chi2_cc(lk, theta)
     for idx, mean, sigma in lk.chi2_gauss:
         total += (theta[idx] - mean) ** 2 / sigma**2
     return total
@@ -389,7 +406,11 @@ def log_likelihood(lk: Likelihood, theta) -> float:
     theta = np.asarray(theta, dtype=np.float64)
     if lk.cpl_wall and lk.w0.get(theta) + lk.wa.get(theta) >= 0.0:
         return -1e8  # bao/desi_fs_lya_cmb.py:118-121
-    return -0.5 * chi_squared(lk, theta)
+    ll = -0.5 * chi_squared(lk, theta)
+    if lk.cc_z is not None:  # bao/desi_union3_cc_theta_star.py:135-139
+        n_cc = len(lk.cc_z)
+        ll -= 0.5 * (n_cc * np.log(2 * np.pi) + lk.cc_logdet - 2 * n_cc * np.log(lk.fcc.get(theta)))
+    return ll
 
 
 def log_prior(lk: Likelihood, theta) -> float:

@@ -305,6 +305,97 @@ def case_bao_desi_des5y_bbn_theta_star():
     print("bao_desi_des5y_bbn_theta_star.npz chi2[:3] =", out["chi2"][:3])
 
 
+
+def case_sn_union3_1():
+    """sn/union3_1.py: 22 binned distances with the REAL covariance (explicit inverse), H0 fixed to 70, velocity
+    step at z = 0.2.  Everything it needs is in the snapshot."""
+    _enter_reference()
+    import sn.union3_1 as m
+
+    rng = np.random.default_rng(8)
+    box = [(-1.0, 1.0), (0.1, 0.7), (-9.0, 9.0)]  # nautilus prior of main() (sn/union3_1.py:77-79)
+    thetas = np.vstack([_uniform(box, 20, rng), [[0.027, 0.335, 0.0]]])  # docstring medians, chi2 28.76 (:145)
+    out = dict(z_cmb=m.z_cmb, z_hel=m.z_hel, obs=m.mu_vals, cov=m.cov_matrix, thetas=thetas, H0=np.float64(m.H0),
+               z_max=np.float64(m.z_grid[-1]), chi2=np.array([m.chi_squared(t) for t in thetas]),
+               logl=np.array([m.log_likelihood(t) for t in thetas]))
+    np.savez_compressed(os.path.join(HERE, "sn_union3_1.npz"), **out)
+    print("sn_union3_1.npz chi2 at docstring medians:", out["chi2"][-1])
+
+
+def case_sn_pantheon_dipole():
+    """sn/pantheon_dipole.py: per-SN velocity weights cos(angle) * tanh attenuation * survey mask (:60-68)."""
+    _enter_reference()
+    import pandas as pd
+
+    df = pd.read_csv(os.path.join(REF, "y2022pantheonSHOES/raw-data/distances.txt"), sep=" ")
+    sel = df["zHD"].to_numpy(np.float64) > 0.01
+    col = lambda name, dt=np.float64: df[name].to_numpy(dtype=dt)[sel]
+    z, zh, mb, sig = col("zHD"), col("zHEL"), col("m_b_corr"), col("m_b_corr_err_DIAG")
+    cov = synthetic_cov(sig)
+    pkg = types.ModuleType("y2022pantheonSHOES"); pkg.__path__ = []
+    mod = types.ModuleType("y2022pantheonSHOES.data")
+    mod.get_data_with_position = lambda: ("Pantheon+ (synthetic cov)", z, zh, mb, col("RA"), col("DEC"), col("IDSURVEY", np.int32), cov)
+    sys.modules["y2022pantheonSHOES"] = pkg
+    sys.modules["y2022pantheonSHOES.data"] = mod
+    import sn.pantheon_dipole as m
+
+    rng = np.random.default_rng(9)
+    box = [(-20.0, -19.0), (62.0, 78.0), (0.1, 0.7), (-0.5, 4.5)]
+    thetas = _uniform(box, 16, rng)
+    att = 0.5 * (1.0 - np.tanh((m.z_cmb - 0.10) / 0.02))
+    out = dict(z_cmb=z, z_hel=zh, obs=mb, sigma=sig, weights=m.cos_angle * att * m.survey_mask, thetas=thetas,
+               z_max=np.float64(m.z_grid[-1]), chi2=np.array([m.chi_squared(t) for t in thetas]))
+    np.savez_compressed(os.path.join(HERE, "sn_pantheon_dipole.npz"), **out)
+    print("sn_pantheon_dipole.npz chi2[:3] =", out["chi2"][:3], "nonzero weights:", int(np.count_nonzero(out["weights"])))
+
+
+def case_sn_pantheon_and_sh0es():
+    """sn/pantheon_and_sh0es.py: Cepheid-calibrated hosts take their distance modulus from CEPH_DIST (:63-69)."""
+    _enter_reference()
+    import pandas as pd
+
+    df = pd.read_csv(os.path.join(REF, "y2022pantheonSHOES/raw-data/distances.txt"), sep=" ")
+    zall = df["zHD"].to_numpy(np.float64)
+    rng_sel = np.where(((zall >= 0.0) & (df["IS_CALIBRATOR"] == 1)) | (zall > 0.01))[0]  # data_shoes.py:30-31
+    col = lambda name: df[name].to_numpy(np.float64)[rng_sel]
+    z, zh, mb, ceph, sig = col("zHD"), col("zHEL"), col("m_b_corr"), col("CEPH_DIST"), col("m_b_corr_err_DIAG")
+    cov = synthetic_cov(sig)
+    pkg = types.ModuleType("y2022pantheonSHOES"); pkg.__path__ = []
+    mod = types.ModuleType("y2022pantheonSHOES.data_shoes")
+    mod.get_data = lambda z_cut_ceph=0.0: ("Pantheon+ and SH0ES (synthetic cov)", z, zh, mb, ceph, cov)
+    sys.modules["y2022pantheonSHOES"] = pkg
+    sys.modules["y2022pantheonSHOES.data_shoes"] = mod
+    import sn.pantheon_and_sh0es as m
+
+    rng = np.random.default_rng(10)
+    thetas = theta_batch(m.bounds, 14, rng)
+    out = dict(z_cmb=z, z_hel=zh, obs=mb, ceph=ceph, sigma=sig, bounds=m.bounds, thetas=thetas,
+               corr_sign=np.where(m.correction_mask, 1.0, -1.0), z_max=np.float64(m.z_grid[-1]),
+               chi2=np.array([m.chi_squared(t) for t in thetas]), logp=np.array([m.log_probability(t) for t in thetas]))
+    np.savez_compressed(os.path.join(HERE, "sn_pantheon_and_sh0es.npz"), **out)
+    print("sn_pantheon_and_sh0es.npz chi2[:3] =", out["chi2"][:3], "calibrators:", int(np.sum(ceph != -9)))
+
+
+def case_bao_desi_union3_cc_theta_star():
+    """bao/desi_union3_cc_theta_star.py: Union3.1 (explicit inverse) + DESI BAO (exact D_H) + l_A + cosmic
+    chronometers with the error-rescale parameter f_cc and its log-determinant term (:129-139).  All data real."""
+    _enter_reference()
+    import bao.desi_union3_cc_theta_star as m
+
+    cmb = m.cmb
+    rng = np.random.default_rng(11)
+    box = [(0.2, 3.0), (-1.0, 1.0), (50.0, 85.0), (0.003, 0.050), (0.05, 0.30), (-10.5, 4.5)]  # :160-170
+    thetas = np.vstack([_uniform(box, 20, rng), [[1.0, 0.0, 67.5, 0.0224, 0.119, 0.0]]])
+    out = _bao_inputs(m.bao_data, m.cov_matrix_bao, m.desi_qty, m.inv_cov_bao)
+    out.update(_cmb_consts(cmb))
+    out.update(z_cmb=m.z_cmb, z_hel=m.z_hel, obs=m.mu_values, cov_sn=m.cov_matrix_sn, cc_z=m.z_cc_vals, cc_h=m.H_cc_vals,
+               cc_cov=m.cov_matrix_cc, cc_inv_cov=m.inv_cov_cc, cc_logdet=np.float64(m.logdet_cc), thetas=thetas,
+               z_max=np.float64(m.z_grid[-1]), chi2=np.array([m.chi_squared(t) for t in thetas]),
+               logl=np.array([m.log_likelihood_single(t) for t in thetas]), logl_vec32=m.log_likelihood(thetas))
+    np.savez_compressed(os.path.join(HERE, "bao_desi_union3_cc_theta_star.npz"), **out)
+    print("bao_desi_union3_cc_theta_star.npz chi2[-1] =", out["chi2"][-1], "logl[-1] =", out["logl"][-1])
+
+
 CASES = {
     "interpolator": case_interpolator,
     "sn_pantheon": case_sn_pantheon,
@@ -313,6 +404,10 @@ CASES = {
     "bao_desi_fs_lya_cmb": case_bao_desi_fs_lya_cmb,
     "bao_desi_cmb_des5y": case_bao_desi_cmb_des5y,
     "bao_desi_des5y_bbn_theta_star": case_bao_desi_des5y_bbn_theta_star,
+    "sn_union3_1": case_sn_union3_1,
+    "sn_pantheon_dipole": case_sn_pantheon_dipole,
+    "sn_pantheon_and_sh0es": case_sn_pantheon_and_sh0es,
+    "bao_desi_union3_cc_theta_star": case_bao_desi_union3_cc_theta_star,
 }
 
 if __name__ == "__main__":

@@ -148,3 +148,47 @@ def test_f_de_variants_with_sn_block_vs_oracle(gpu):
                               rng.uniform(-2, 2, 64), rng.uniform(-1.2, -0.5, 64), rng.uniform(-1.0, 0.4, 64)])
         np.testing.assert_allclose(eng.chi_squared(th), co.chi2(th), rtol=RTOL)
         eng.close()
+
+
+# ---- SURVEY 8f-2 widening: Union3, dipole weights, SH0ES calibrators, cosmic chronometers -------------------------
+def test_sn_union3_1_real_covariance(gpu):
+    g = golden("sn_union3_1")
+    lk = gpu.likelihoods.SnUnion3(g["z_cmb"], g["z_hel"], g["obs"], g["cov"], H0=float(g["H0"]))
+    np.testing.assert_allclose(lk.chi_squared(g["thetas"]), g["chi2"], rtol=RTOL)
+    np.testing.assert_allclose(lk.log_likelihood(g["thetas"]), g["logl"], rtol=RTOL)
+    # the reference's own docstring value at its posterior medians (sn/union3_1.py:145): chi^2 = 28.76, real data
+    assert lk.chi_squared(np.array([0.027, 0.335, 0.0])) == pytest.approx(28.76, abs=0.01)
+    lk.engine.close()
+
+
+def test_sn_pantheon_dipole_weights(gpu):
+    g = golden("sn_pantheon_dipole")
+    lk = gpu.sn_pantheon.PantheonLikelihood(g["z_cmb"], g["z_hel"], g["obs"], chol=_chol_of(g), step=g["weights"],
+                                            bounds=np.array([(-20.0, -19.0), (50.0, 90.0), (0.0, 0.8), (-1.0, 5.0)]))
+    np.testing.assert_allclose(lk.chi_squared(g["thetas"]), g["chi2"], rtol=RTOL)
+    lk.engine.close()
+
+
+def test_sn_pantheon_and_sh0es_calibrators(gpu):
+    g = golden("sn_pantheon_and_sh0es")
+    fixed = np.where(g["ceph"] != -9, g["ceph"], np.nan)
+    lk = gpu.sn_pantheon.PantheonLikelihood(g["z_cmb"], g["z_hel"], g["obs"], chol=_chol_of(g), step=g["corr_sign"],
+                                            fixed_mu=fixed, bounds=g["bounds"], h0_prior=None)
+    fin = np.isfinite(g["logp"])
+    with np.errstate(all="ignore"):
+        np.testing.assert_allclose(lk.chi_squared(g["thetas"])[fin], g["chi2"][fin], rtol=RTOL)
+        logp = lk.log_probs_vectorized(g["thetas"])
+    np.testing.assert_allclose(logp[fin], g["logp"][fin], rtol=RTOL)
+    assert np.all(logp[~fin] == -np.inf)
+    lk.engine.close()
+
+
+def test_desi_union3_cc_theta_star_all_real_data(gpu):
+    g = golden("bao_desi_union3_cc_theta_star")
+    lk = gpu.likelihoods.DesiUnion3CcThetaStar(g["z_cmb"], g["z_hel"], g["obs"], g["cov_sn"], *_bao_args(g), g["cc_z"],
+                                               g["cc_h"], g["cc_cov"])
+    np.testing.assert_allclose(lk.chi_squared(g["thetas"]), g["chi2"], rtol=RTOL)
+    logl = lk.log_likelihood(g["thetas"])
+    np.testing.assert_allclose(logl, g["logl"], rtol=RTOL)
+    np.testing.assert_allclose(logl.astype(np.float32), g["logl_vec32"], rtol=1e-6)  # the reference's batch API is float32
+    lk.engine.close()

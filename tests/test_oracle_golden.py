@@ -319,3 +319,60 @@ def test_c_oracle_joint_likelihoods(name):
             fin = np.isfinite(g["logl"])
             got = co.logl(g["thetas"])
             np.testing.assert_allclose(got[fin], g["logl"][fin], rtol=1e-9)
+
+
+# ---- Union3 (explicit inverse -> Cholesky), dipole weights, SH0ES calibrators, cosmic chronometers
+def lk_sn_union3_1(g):
+    return onp.Likelihood(ndim=3, z_max=float(g["z_max"]), offset=onp.Slot(0), H0=onp.Slot(fixed=float(g["H0"])), Om=onp.Slot(1),
+                          v=onp.Slot(2), z_cmb=g["z_cmb"], z_hel=g["z_hel"], obs=g["obs"], z_turn=0.2,
+                          chol=np.linalg.cholesky(g["cov"]))
+
+
+def lk_sn_pantheon_dipole(g):
+    return onp.Likelihood(ndim=4, z_max=float(g["z_max"]), offset=onp.Slot(0), H0=onp.Slot(1), Om=onp.Slot(2), v=onp.Slot(3),
+                          z_cmb=g["z_cmb"], z_hel=g["z_hel"], obs=g["obs"], step=g["weights"], chol=_chol_of(g))
+
+
+def lk_sn_pantheon_and_sh0es(g):
+    fixed = np.where(g["ceph"] != -9, g["ceph"], np.nan)
+    return onp.Likelihood(ndim=4, z_max=float(g["z_max"]), offset=onp.Slot(0), H0=onp.Slot(1), Om=onp.Slot(2), v=onp.Slot(3),
+                          z_cmb=g["z_cmb"], z_hel=g["z_hel"], obs=g["obs"], step=g["corr_sign"], fixed_mu=fixed,
+                          chol=_chol_of(g), bounds=g["bounds"])
+
+
+def lk_bao_desi_union3_cc_theta_star(g):
+    d = _cmbdata("PLANCK_ACT")
+    inv = np.zeros((3, 3))
+    inv[1, 1] = 1.0 / d["cmb_cov"][1, 1]
+    return onp.Likelihood(ndim=6, z_max=float(g["z_max"]), ez_model=onp.EZ_PHYSICAL, fde=onp.FDE_LCDM, fcc=onp.Slot(0),
+                          offset=onp.Slot(1), H0=onp.Slot(2), obh2=onp.Slot(3), och2=onp.Slot(4), v=onp.Slot(5),
+                          z_cmb=g["z_cmb"], z_hel=g["z_hel"], obs=g["obs"], z_turn=0.2, chol=np.linalg.cholesky(g["cov_sn"]),
+                          bao_z=g["bao_z"], bao_val=g["bao_val"], bao_qty=g["bao_qty"], bao_inv_cov=g["bao_inv_cov"],
+                          bao_dh_exact=True, rd_fit=d["rd_fit"], cmb_mode=2, cmb_prior=d["cmb_prior"], cmb_inv_cov=inv,
+                          zstar_fit=d["zstar_fit"], cc_z=g["cc_z"], cc_h=g["cc_h"], cc_inv_cov=g["cc_inv_cov"],
+                          cc_logdet=float(g["cc_logdet"]), **_phys(d))
+
+
+@pytest.mark.parametrize("name", ["sn_union3_1", "sn_pantheon_dipole", "sn_pantheon_and_sh0es", "bao_desi_union3_cc_theta_star"])
+def test_oracles_on_widening_scripts(name):
+    from oracle import oracle_c as oc
+
+    g = golden(name)
+    lk = globals()["lk_" + name](g)
+    co = oc.COracle(lk)
+    with np.errstate(all="ignore"):
+        if "logp" in g:
+            fin = np.isfinite(g["logp"])
+            got = co.logp(g["thetas"])
+            np.testing.assert_allclose(got[fin], g["logp"][fin], rtol=1e-10)
+            assert np.all(got[~fin] == -np.inf)
+        fin = np.isfinite(g["chi2"])
+        np.testing.assert_allclose(co.chi2(g["thetas"])[fin], g["chi2"][fin], rtol=1e-10)
+        if "logl" in g:
+            np.testing.assert_allclose(co.logl(g["thetas"])[fin], g["logl"][fin], rtol=1e-10)
+        k = int(np.flatnonzero(fin)[0])
+        assert onp.chi_squared(lk, g["thetas"][k]) == pytest.approx(g["chi2"][k], rel=1e-10)
+        if "logl" in g:
+            assert onp.log_likelihood(lk, g["thetas"][k]) == pytest.approx(g["logl"][k], rel=1e-10)
+    if name == "sn_union3_1":  # the reference's docstring chi^2 at its posterior medians: 28.76 (sn/union3_1.py:145)
+        assert g["chi2"][-1] == pytest.approx(28.76, abs=0.01)
