@@ -9,7 +9,7 @@ from . import _lib
 from ._lib import CosmofitError, build, lib
 from ._lib import (CF_FDE_CPL, CF_FDE_LCDM, CF_FDE_THAWING, CF_FDE_WCDM, CF_OUT_CHI2, CF_OUT_LOGL, CF_OUT_LOGP)
 from .engine import C_KM_S, LikelihoodEngine, Param
-from . import cmb_data, interpolator, likelihoods, solve_triangular, sn_pantheon, synthetic
+from . import cmb_data, interpolator, laplace, likelihoods, solve_triangular, sn_pantheon, synthetic
 
 
 

@@ -259,3 +259,23 @@ def test_ill_conditioned_factor_is_refused_not_silently_wrong(gpu, config2):
     z = np.sort(rng.uniform(0.01, 1.0, n))
     with pytest.raises(gpu.CosmofitError, match="CF_ERR_ILL_CONDITIONED"):
         gpu.sn_pantheon.PantheonLikelihood(z, z, 40 + 0 * z, chol=bad)
+
+
+def test_batched_laplace_evidence_gpu_vs_oracle(gpu):
+    """the job of log_evidence.py with every stencil as one GPU batch; same ln Z as with the CPU oracle."""
+    from oracle import oracle_c, oracle_np as onp
+
+    syn = gpu.synthetic.pantheon_like(n_sn=300, seed=4)
+    lk = gpu.sn_pantheon.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"])
+    co = oracle_c.COracle(onp.Likelihood(
+        ndim=4, z_max=lk.z_max, offset=onp.Slot(0), H0=onp.Slot(1), Om=onp.Slot(2), v=onp.Slot(3),
+        z_cmb=syn["z_cmb"], z_hel=syn["z_hel"], obs=syn["obs"], chol=syn["chol"],
+        bounds=gpu.sn_pantheon.bounds, gauss=[gpu.sn_pantheon.H0_PRIOR]))
+    samples = gpu.synthetic.THETA_TRUE + np.array([0.02, 1.0, 0.03, 0.3]) * np.random.default_rng(2).standard_normal((64, 4))
+    lp = lk.log_probs_vectorized(samples)
+    z_gpu, d_gpu = gpu.laplace.log_evidence(samples, lp, lk.log_probs_vectorized, lk.bounds, return_details=True)
+    z_cpu, d_cpu = gpu.laplace.log_evidence(samples, lp, co.logp, lk.bounds, return_details=True)
+    assert np.isfinite(z_gpu) and z_gpu == pytest.approx(z_cpu, abs=1e-5)
+    np.testing.assert_allclose(d_gpu["theta_map"], d_cpu["theta_map"], rtol=1e-5, atol=1e-6)
+    assert d_gpu["log_post_map"] >= lp.max() - 1e-9
+    lk.engine.close()
