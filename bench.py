@@ -164,7 +164,7 @@ def main():
                 "measured_mfma_f64_ceiling": FP64_MFMA_MEASURED_TFLOPS,
                 "frac_of_measured_ceiling": achieved / FP64_MFMA_MEASURED_TFLOPS,
             },
-            "kernels_ms": {"sn_residual_kernel": resid_ms, "trsm_chi2_kernel": solve_ms},
+            "kernels_ms": {"walker_kernel": resid_ms, "trsm_chi2_kernel": solve_ms},
         }
         if world == 1:
             # the ctypes boundary as emcee / nautilus call it: host numpy in, host numpy out (PCIe + sync included).

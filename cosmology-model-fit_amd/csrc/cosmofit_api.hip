@@ -22,9 +22,22 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // the solve kernel's prefetch reads up to 4 K-step pairs (4 KiB) past the end of a panel's Y range
 #define CF_YPK_SLACK 8192
 
-extern "C" __global__ void walker_kernel(cf_dev_desc d, const double* theta, int64_t W, double* delta,
-                                         double* chi2_extra, double* dm_out, double* mucorr_out, double* blocks_out,
-                                         double* bao_out);
+template <int MODEL, int FDE>
+__global__ void walker_kernel(cf_dev_desc d, const double* theta, int64_t W, double* delta, double* chi2_extra,
+                              double* dm_out, double* mucorr_out, double* blocks_out, double* bao_out);
+#define CF_DECLARE_WALKER(M, F)                                                                                        \
+  extern template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, \
+                                                      double*, double*, double*);
+CF_DECLARE_WALKER(0, 0) CF_DECLARE_WALKER(0, 1) CF_DECLARE_WALKER(0, 2) CF_DECLARE_WALKER(0, 3)
+CF_DECLARE_WALKER(1, 0) CF_DECLARE_WALKER(1, 1) CF_DECLARE_WALKER(1, 2) CF_DECLARE_WALKER(1, 3)
+
+typedef void (*walker_fn)(cf_dev_desc, const double*, int64_t, double*, double*, double*, double*, double*, double*);
+static walker_fn pick_walker(int model, int fde) {
+  static const walker_fn table[2][4] = {
+      {walker_kernel<0, 0>, walker_kernel<0, 1>, walker_kernel<0, 2>, walker_kernel<0, 3>},
+      {walker_kernel<1, 0>, walker_kernel<1, 1>, walker_kernel<1, 2>, walker_kernel<1, 3>}};
+  return table[model][fde];
+}
 template <int KS, int TC>
 __global__ void trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* theta, int64_t W, const double* delta,
                                  d2* ypk, const double* chi2_extra, double* out, int out_kind,
@@ -258,7 +271,7 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
   d.step = c->z_max / (double)(c->n_grid - 1);  // np.linspace step
   d.inv_step = 1.0 / d.step;
   d.inv_last = 1.0 / (c->z_max - (double)(c->n_grid - 2) * d.step);
-  d.chunk_shift = 0;
+  d.chunk_shift = 3;  // 8 grid nodes per thread of the 512-thread walker kernel, more for grids > 4096
   while ((512 << d.chunk_shift) < c->n_grid) d.chunk_shift++;
   d.c = c->c_km_s;
   for (int s = 0; s < CF_P_NSLOTS; ++s) {
@@ -324,8 +337,11 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
 
   if (c->n_sn > 0) {
     std::vector<double> step((size_t)c->n_sn);
-    for (int64_t i = 0; i < c->n_sn; ++i)
+    d.step_pm1 = 1;
+    for (int64_t i = 0; i < c->n_sn; ++i) {
       step[i] = c->sn_step ? c->sn_step[i] : (c->sn_z_cmb[i] <= c->sn_z_turn ? 1.0 : -1.0);  // sn/pantheon.py:46
+      if (step[i] != 1.0 && step[i] != -1.0) d.step_pm1 = 0;
+    }
     int rc;
     if ((rc = upload_vec(h->z_cmb, c->sn_z_cmb, c->n_sn))) return bail(rc);
     if ((rc = upload_vec(h->z_hel, c->sn_z_hel, c->n_sn))) return bail(rc);
@@ -492,8 +508,8 @@ static int launch_path(cf_handle* h, const double* d_theta, int64_t W, double* d
   if (walker_work) {
     // skewed {cum, dh} table: one spare 16-byte slot per 2^chunk_shift nodes
     const size_t lds = ((size_t)d.n_grid + (d.n_grid >> d.chunk_shift) + 2) * 16;
-    hipLaunchKernelGGL(walker_kernel, dim3((unsigned)W), dim3(512), lds, st, d, d_theta, W, h->delta.as<double>(), extra,
-                       dm_out, mucorr_out, blocks_out, bao_out);
+    hipLaunchKernelGGL(pick_walker(d.ez_model, d.fde), dim3((unsigned)W), dim3(512), lds, st, d, d_theta, W,
+                       h->delta.as<double>(), extra, dm_out, mucorr_out, blocks_out, bao_out);
   }
   if (ev) HIP_TRY(hipEventRecord(ev[1], st));
   if (d.n_sn > 0) {

@@ -60,7 +60,8 @@ struct cf_dev_desc {
   const double* z_hel;
   const double* obs;
   const double* sn_step;
-  int32_t has_vstep, pad1;  // 0: the likelihood has no peculiar-velocity step (z_cosmo = z_cmb)
+  int32_t has_vstep;  // 0: the likelihood has no peculiar-velocity step (z_cosmo = z_cmb)
+  int32_t step_pm1;   // 1: every sn_step entry is +1 or -1
   const double* sn_fixed_mu;  // [n_sn] or null; non-NaN entries replace mu_theory (SH0ES calibrators)
   // cosmic chronometers
   int32_t n_cc, pad3;

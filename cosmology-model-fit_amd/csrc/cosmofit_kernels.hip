@@ -63,16 +63,18 @@ __device__ __forceinline__ WalkerCosmo make_cosmo(const cf_dev_desc& d, const do
   return wc;
 }
 
+// MODEL / FDE are compile-time: one kernel instantiation per expansion-rate family keeps the hot
+// loops free of the other families' code (the all-in-one kernel was 14 k instructions, well past
+// the instruction cache, and ran its table build 3x slower than its VALU work).
+template <int FDE>
 __device__ __forceinline__ double f_de(const WalkerCosmo& wc, double z, double zp1, double cubed) {
-  switch (wc.fde) {
-    case CF_FDE_LCDM_D: return 1.0;
-    case CF_FDE_WCDM_D: return pow(zp1, 3 * (1 + wc.w0));
-    case CF_FDE_THAWING_D: {
-      double r = 2 * cubed / ((1.0 + wc.w0) + (1.0 - wc.w0) * cubed);
-      return r * r;
-    }
-    default: return pow(zp1, 3 * (1 + wc.w0 + wc.wa)) * exp(-3 * wc.wa * z / zp1);
+  if (FDE == CF_FDE_LCDM_D) return 1.0;
+  if (FDE == CF_FDE_WCDM_D) return pow(zp1, 3 * (1 + wc.w0));
+  if (FDE == CF_FDE_THAWING_D) {
+    double r = 2 * cubed / ((1.0 + wc.w0) + (1.0 - wc.w0) * cubed);
+    return r * r;
   }
+  return pow(zp1, 3 * (1 + wc.w0 + wc.wa)) * exp(-3 * wc.wa * z / zp1);
 }
 
 // 5-node massive-neutrino density, cmb/data_planck_act_compression.py:53-66
@@ -86,24 +88,27 @@ __device__ __forceinline__ double omnu_z(const cf_dev_desc& d, double zp1) {
 }
 
 // E^2(z) of both families.
+template <int MODEL, int FDE>
 __device__ __forceinline__ double e2_of_z(const cf_dev_desc& d, const WalkerCosmo& wc, double z) {
   const double zp1 = 1.0 + z;
   const double cubed = zp1 * zp1 * zp1;
-  if (wc.model == CF_EZ_LATE_FLAT_D)
-    return (wc.fde == CF_FDE_LCDM_D) ? wc.Om * cubed + (1.0 - wc.Om)
-                                     : wc.Om * cubed + (1.0 - wc.Om) * f_de(wc, z, zp1, cubed);
-  const double de = (wc.fde == CF_FDE_LCDM_D) ? wc.Ode : wc.Ode * f_de(wc, z, zp1, cubed);
+  if (MODEL == CF_EZ_LATE_FLAT_D)
+    return (FDE == CF_FDE_LCDM_D) ? wc.Om * cubed + (1.0 - wc.Om)
+                                  : wc.Om * cubed + (1.0 - wc.Om) * f_de<FDE>(wc, z, zp1, cubed);
+  const double de = (FDE == CF_FDE_LCDM_D) ? wc.Ode : wc.Ode * f_de<FDE>(wc, z, zp1, cubed);
   return wc.Or * (cubed * zp1) + wc.Obc * cubed + de + wc.Onu * omnu_z(d, zp1);  // bao/desi_cmb_des5y.py:43-48
 }
 
 // H(z) in the reference's form H0 * sqrt(E^2) (used where only a few values are needed).
+template <int MODEL, int FDE>
 __device__ __forceinline__ double H_of_z(const cf_dev_desc& d, const WalkerCosmo& wc, double z) {
-  return wc.H0 * sqrt(e2_of_z(d, wc, z));
+  return wc.H0 * sqrt(e2_of_z<MODEL, FDE>(d, wc, z));
 }
 
 // dh(z) = c/H(z) on the grid without the sqrt + divide pair: (c/H0) * rsqrt(E^2), <= 2 ulp away.
+template <int MODEL, int FDE>
 __device__ __forceinline__ double dh_of_z_fast(const cf_dev_desc& d, const WalkerCosmo& wc, double c_over_H0, double z) {
-  return c_over_H0 * rsqrt(e2_of_z(d, wc, z));
+  return c_over_H0 * rsqrt(e2_of_z<MODEL, FDE>(d, wc, z));
 }
 
 // Grid node i of np.linspace(0, z_max, G): i*step, last node forced to z_max (sn/pantheon.py:16).
@@ -206,23 +211,74 @@ __device__ __forceinline__ double log10_pos(double x) {
   return val_lo + ww;
 }
 
-// Inclusive scan across the 64 lanes of a wave (Hillis-Steele on shuffles).
-__device__ __forceinline__ double wave_inclusive_scan(double v, int lane) {
-#pragma unroll
-  for (int off = 1; off < CF_WAVE; off <<= 1) {
-    double n = __shfl_up(v, off, CF_WAVE);
-    if (lane >= off) v += n;
-  }
+// Inclusive scan across the 64 lanes of a wave on DPP row operations (no LDS round trips, unlike
+// ds_bpermute-based shuffles): Hillis-Steele inside each row of 16 lanes (row_shr 1, 2, 4, 8), then
+// lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast:15) and lane 31 into rows 2-3 (row_bcast:31).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(hi, lo);  // lanes without a source (or outside ROW_MASK) get 0
+}
+
+__device__ __forceinline__ double wave_inclusive_scan(double v) {
+  v += dpp_move<0x111, 0xF>(v);  // row_shr:1
+  v += dpp_move<0x112, 0xF>(v);  // row_shr:2
+  v += dpp_move<0x114, 0xF>(v);  // row_shr:4
+  v += dpp_move<0x118, 0xF>(v);  // row_shr:8
+  v += dpp_move<0x142, 0xA>(v);  // row_bcast:15 -> rows 1 and 3
+  v += dpp_move<0x143, 0xC>(v);  // row_bcast:31 -> rows 2 and 3
   return v;
 }
 
 // Build the table.  All CF_TPB_A threads call it.
 //   dh[g]  = c/H(z_g)
 //   cum[g] = sum_{k<g} (dh[k]+dh[k+1])/2 * (z[k+1]-z[k])          (sn/pantheon.py:35-39)
-// Chunk-sequential inside a thread, wave64 shuffle scan over the chunk totals, wave totals
-// carried through LDS.  Thread t owns CH = 2^chs contiguous nodes, CH*CF_TPB_A >= G.
-__device__ __forceinline__ void build_distance_table(const cf_dev_desc& d, const WalkerCosmo& wc, d2* tab,
-                                                     double* wave_tot) {
+// Thread t owns CH = 2^chs contiguous nodes (CH*CF_TPB_A >= G): chunk-sequential trapezoid sums in
+// registers, wave64 DPP scan over the chunk totals, wave totals carried through LDS, then ONE 16-byte
+// LDS store per node.  The node before a chunk comes from the neighbouring lane (shuffle); the first
+// lane of a wave re-evaluates it instead of waiting for another wave (one barrier less).
+template <int MODEL, int FDE, int CH>
+__device__ __forceinline__ void build_distance_table_regs(const cf_dev_desc& d, const WalkerCosmo& wc, d2* tab,
+                                                          double* wave_tot) {
+  const int G = d.n_grid;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g0 = tid * CH;
+  const int base = g0 + tid;  // skewed position of node g0
+  const double c_over_H0 = wc.c / wc.H0;
+  double dh[CH];
+#pragma unroll
+  for (int k = 0; k < CH; ++k)
+    dh[k] = g0 + k < G ? dh_of_z_fast<MODEL, FDE>(d, wc, c_over_H0, grid_z(g0 + k, G, d.step, d.z_max)) : 0.0;
+  double prev = __shfl_up(dh[CH - 1], 1, CF_WAVE);
+  if (lane == 0 && g0 > 0 && g0 <= G) prev = dh_of_z_fast<MODEL, FDE>(d, wc, c_over_H0, grid_z(g0 - 1, G, d.step, d.z_max));
+  double loc[CH];
+  double run = 0.0;
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const int g = g0 + k;
+    if (g >= 1 && g < G) {
+      const double dz = grid_z(g, G, d.step, d.z_max) - grid_z(g - 1, G, d.step, d.z_max);
+      run += (prev + dh[k]) / 2 * dz;
+    }
+    loc[k] = run;
+    prev = dh[k];
+  }
+  const double incl = wave_inclusive_scan(run);
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  double carry = incl - run;  // exclusive inside the wave
+  for (int w = 0; w < wave; ++w) carry += wave_tot[w];
+#pragma unroll
+  for (int k = 0; k < CH; ++k)
+    if (g0 + k < G) tab[base + k] = (d2){loc[k] + carry, dh[k]};
+  __syncthreads();
+}
+
+// Same result for long grids (CH > 8 would not fit the register budget): the chunk lives in LDS.
+template <int MODEL, int FDE>
+__device__ __forceinline__ void build_distance_table_lds(const cf_dev_desc& d, const WalkerCosmo& wc, d2* tab,
+                                                         double* wave_tot) {
   const int G = d.n_grid, chs = d.chunk_shift, CH = 1 << chs;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g0 = tid << chs;
@@ -230,12 +286,10 @@ __device__ __forceinline__ void build_distance_table(const cf_dev_desc& d, const
   const int n_own = max(0, min(CH, G - g0));
   const double c_over_H0 = wc.c / wc.H0;
   for (int k = 0; k < n_own; ++k)
-    tab[base + k].y = dh_of_z_fast(d, wc, c_over_H0, grid_z(g0 + k, G, d.step, d.z_max));
+    tab[base + k].y = dh_of_z_fast<MODEL, FDE>(d, wc, c_over_H0, grid_z(g0 + k, G, d.step, d.z_max));
   __syncthreads();
-  // chunk-local inclusive prefix of the trapezoid terms (node g needs dh[g-1]: the last node of
-  // the previous thread's chunk sits at skewed position base-2)
   double run = 0.0;
-  double prev = g0 > 0 && n_own > 0 ? tab[base - 2].y : 0.0;
+  double prev = g0 > 0 && n_own > 0 ? tab[base - 2].y : 0.0;  // last node of the previous thread's chunk
   for (int k = 0; k < n_own; ++k) {
     const int g = g0 + k;
     const double cur = tab[base + k].y;
@@ -246,13 +300,21 @@ __device__ __forceinline__ void build_distance_table(const cf_dev_desc& d, const
     tab[base + k].x = run;
     prev = cur;
   }
-  const double incl = wave_inclusive_scan(run, lane);
+  const double incl = wave_inclusive_scan(run);
   if (lane == 63) wave_tot[wave] = incl;
   __syncthreads();
-  double carry = incl - run;  // exclusive inside the wave
+  double carry = incl - run;
   for (int w = 0; w < wave; ++w) carry += wave_tot[w];
   for (int k = 0; k < n_own; ++k) tab[base + k].x += carry;
   __syncthreads();
+}
+
+template <int MODEL, int FDE>
+__device__ __forceinline__ void build_distance_table(const cf_dev_desc& d, const WalkerCosmo& wc, d2* tab,
+                                                     double* wave_tot) {
+  // grids up to 4096 nodes (the reference uses 4000) take the register path, 8 nodes per thread
+  if (d.chunk_shift == 3) build_distance_table_regs<MODEL, FDE, 8>(d, wc, tab, wave_tot);
+  else build_distance_table_lds<MODEL, FDE>(d, wc, tab, wave_tot);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -321,6 +383,47 @@ __device__ double r_drag_fit(const double* f, double wb, double wm) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// SN residuals, production path (no accessor outputs, no fixed distance moduli): one Hermite, one
+// log10 per SN; the per-SN inputs of the NEXT iteration are fetched while the current one computes.
+// PM1: every step weight is +1 or -1 (the Heaviside step of sn/pantheon.py:46), so 1 + z_pec takes
+// two values per walker and z_cosmo = -1 + (1+z) * (1/(1+z_pec)) needs no per-SN division
+// (<= 1 ulp of 1+z_cosmo away from the quotient form).
+// ------------------------------------------------------------------------------------------------
+template <bool PM1>
+__device__ __forceinline__ void sn_fast_loop(const cf_dev_desc& d, const DistTable& T, double* __restrict__ out,
+                                             double off, double v100, int tid) {
+  const int n_sn = d.n_sn;
+  double r_pos = 1.0, r_neg = 1.0;
+  if (PM1 && d.has_vstep) {
+    r_pos = 1.0 / (1.0 + v100 / d.c);
+    r_neg = 1.0 / (1.0 + (-v100) / d.c);
+  }
+  int i = tid;
+  double zc = 0.0, st = 1.0, zh = 0.0, ob = 0.0;
+  if (i < n_sn) { zc = d.z_cmb[i]; st = d.sn_step[i]; zh = d.z_hel[i]; ob = d.obs[i]; }
+  for (; i < d.n_pad; i += CF_TPB_A) {
+    const int nx = i + CF_TPB_A;
+    double zc_n = 0.0, st_n = 1.0, zh_n = 0.0, ob_n = 0.0;
+    if (nx < n_sn) { zc_n = d.z_cmb[nx]; st_n = d.sn_step[nx]; zh_n = d.z_hel[nx]; ob_n = d.obs[nx]; }
+    double res = 0.0;
+    if (i < n_sn) {
+      double z_cosmo = zc;
+      if (d.has_vstep) {
+        if (PM1) {
+          z_cosmo = -1.0 + (1.0 + zc) * (st > 0.0 ? r_pos : r_neg);
+        } else {  // general weights (dipole fits): sn/pantheon.py:43-48 as written
+          const double z_pec = (v100 * st) / d.c;
+          z_cosmo = -1.0 + (1.0 + zc) / (1.0 + z_pec);
+        }
+      }
+      res = ob - off - (25.0 + 5 * log10_pos((1.0 + zh) * hermite_tab(T, z_cosmo)));
+    }
+    out[i] = res;  // rows >= n_sn are zero padding for the 16-row MFMA tiles
+    zc = zc_n; st = st_n; zh = zh_n; ob = ob_n;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Kernel A: one 512-thread workgroup per walker: distance table, SN residual vector, and the small
 // BAO / compressed-CMB blocks of the joint likelihoods.
 //
@@ -336,7 +439,8 @@ __device__ double r_drag_fit(const double* f, double wb, double wm) {
 // of the distance integral; thread 0 adds them in node order like the reference's loop.
 // chi2_extra[w] = chi2_bao + chi2_cmb + chi2_cc;  blocks_out[w] = (bao, cmb, cmb vector[3], cc), bao_out[w][k] optional.
 // ------------------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(CF_TPB_A, 4)
+template <int MODEL, int FDE>
+__global__ void __launch_bounds__(CF_TPB_A, 4)
 walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double* __restrict__ delta,
               double* __restrict__ chi2_extra, double* __restrict__ dm_out, double* __restrict__ mucorr_out,
               double* __restrict__ blocks_out, double* __restrict__ bao_out) {
@@ -359,7 +463,7 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
   T.inv_last = d.inv_last;
   T.z_max = d.z_max;
 
-  if (d.n_sn > 0 || d.n_bao > 0) build_distance_table(d, wc, lds_tab, wave_tot);
+  if (d.n_sn > 0 || d.n_bao > 0) build_distance_table<MODEL, FDE>(d, wc, lds_tab, wave_tot);
 
   // ---- SN residual vector ----
   if (d.n_sn > 0) {
@@ -367,6 +471,10 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
     const double off = slot_get(d, CF_P_OFFSET_D, th);
     const double v100 = 100 * slot_get(d, CF_P_V_D, th);
     const bool parts = dm_out != nullptr || mucorr_out != nullptr;
+    if (!parts && !d.sn_fixed_mu) {
+      if (d.step_pm1) sn_fast_loop<true>(d, T, out, off, v100, tid);
+      else sn_fast_loop<false>(d, T, out, off, v100, tid);
+    } else
     for (int i = tid; i < d.n_pad; i += CF_TPB_A) {
       double res = 0.0;
       if (i < d.n_sn) {
@@ -417,7 +525,7 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
   // ---- cosmic chronometers: H_obs - H(z), bao/desi_union3_cc_theta_star.py:129 (last threads of the block) ----
   if (tid >= CF_TPB_A - d.n_cc) {
     const int k = CF_TPB_A - 1 - tid;
-    cc_delta[k] = d.cc_h[k] - H_of_z(d, wc, d.cc_z[k]);
+    cc_delta[k] = d.cc_h[k] - H_of_z<MODEL, FDE>(d, wc, d.cc_z[k]);
   }
   __syncthreads();
 
@@ -425,7 +533,7 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
   if (tid < d.n_bao) {
     const double z = d.bao_z[tid], rd = shared[1];
     const double DM = hermite_tab(T, z);
-    const double DH = d.bao_dh_exact ? d.c / H_of_z(d, wc, z) : pchip_dh_tab(T, z);
+    const double DH = d.bao_dh_exact ? d.c / H_of_z<MODEL, FDE>(d, wc, z) : pchip_dh_tab(T, z);
     double t;
     switch (d.bao_qty[tid]) {
       case 2: t = DH / rd; break;
@@ -444,11 +552,11 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
       const double a = half * d.gl_x[tid] + half;
       const double z = (1.0 / a) - 1.0;
       const double Rb = (3.0 / 4.0) * (Ob / d.o_gamma_h2) * a;
-      gl_terms[tid] = d.gl_w[tid] * (d.c / (a * a * H_of_z(d, wc, z) * sqrt(3.0 * (1.0 + Rb))));
+      gl_terms[tid] = d.gl_w[tid] * (d.c / (a * a * H_of_z<MODEL, FDE>(d, wc, z) * sqrt(3.0 * (1.0 + Rb))));
     } else {
       const int k = tid - d.n_gl;
       const double half = zstar / 2.0;
-      gl_terms[tid] = d.gl_w[k] * (d.c / H_of_z(d, wc, half * d.gl_x[k] + half));
+      gl_terms[tid] = d.gl_w[k] * (d.c / H_of_z<MODEL, FDE>(d, wc, half * d.gl_x[k] + half));
     }
   }
   __syncthreads();
@@ -502,6 +610,12 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
     if (blocks_out) { blocks_out[6 * w + 0] = c_bao; blocks_out[6 * w + 1] = c_cmb; blocks_out[6 * w + 5] = c_cc; }
   }
 }
+
+#define CF_INSTANTIATE_WALKER(M, F)                                                                              \
+  template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, \
+                                               double*, double*, double*);
+CF_INSTANTIATE_WALKER(0, 0) CF_INSTANTIATE_WALKER(0, 1) CF_INSTANTIATE_WALKER(0, 2) CF_INSTANTIATE_WALKER(0, 3)
+CF_INSTANTIATE_WALKER(1, 0) CF_INSTANTIATE_WALKER(1, 1) CF_INSTANTIATE_WALKER(1, 2) CF_INSTANTIATE_WALKER(1, 3)
 
 // ------------------------------------------------------------------------------------------------
 // Prior / output epilogue shared by every likelihood form.   sn/pantheon.py:80-97
