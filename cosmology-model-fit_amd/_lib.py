@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcosmofit_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-CF_ABI_VERSION = 2
+CF_ABI_VERSION = 3
 CF_P_NSLOTS = 10
 SLOTS = ("offset", "H0", "Om", "obh2", "och2", "w0", "wa", "v", "rd", "fcc")
 
@@ -22,6 +22,7 @@ SLOTS = ("offset", "H0", "Om", "obh2", "och2", "w0", "wa", "v", "rd", "fcc")
 CF_EZ_LATE_FLAT, CF_EZ_PHYSICAL = 0, 1
 CF_FDE_LCDM, CF_FDE_WCDM, CF_FDE_THAWING, CF_FDE_CPL = 0, 1, 2, 3
 CF_OUT_CHI2, CF_OUT_LOGL, CF_OUT_LOGP = 0, 1, 2
+CF_SOLVE_BLOCKED_TRSM, CF_SOLVE_INVERSE_GEMM = 0, 1
 CF_CMB_NONE = 0
 STATUS = {0: "CF_OK", -1: "CF_ERR_INVALID", -2: "CF_ERR_NO_DEVICE", -3: "CF_ERR_HIP", -4: "CF_ERR_NOT_POSDEF",
           -5: "CF_ERR_UNSUPPORTED", -6: "CF_ERR_ILL_CONDITIONED"}
@@ -69,6 +70,7 @@ class cf_desc(C.Structure):
         ("n_cc", C.c_int32), ("_pad3", C.c_int32),
         ("cc_z", C.c_void_p), ("cc_h", C.c_void_p), ("cc_inv_cov", C.c_void_p),
         ("cc_logdet", C.c_double),
+        ("solve_mode", C.c_int32), ("_pad4", C.c_int32),
     ]
 
 
@@ -100,6 +102,7 @@ EXPORTS = {
     "cf_interp_hermite": (C.c_int, [_VP, _I64, _VP, _VP, _VP, _I64, _VP]),
     "cf_interp_pchip": (C.c_int, [_VP, _I64, _VP, _VP, _I64, _VP]),
     "cf_solve_triangular": (C.c_int, [_VP, _I64, _I64, _VP, _I64, _VP]),
+    "cf_selftest_invpack_host": (C.c_int, [_VP, _I64, _I64, _VP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "cf_selftest_log10": (C.c_int, [_VP, _I64, _VP]),
     "cf_selftest_pack_host": (C.c_int, [_VP, _I64, _I64, _VP, C.POINTER(C.c_double), C.POINTER(_I64)]),
 }

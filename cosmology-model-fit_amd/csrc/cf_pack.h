@@ -211,4 +211,124 @@ static double cf_pack_probe(const cf_host_pack& pk, const double* L, int64_t ld)
   return std::fabs(got - ref) / (std::fabs(ref) > 0 ? std::fabs(ref) : 1.0);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Latency mode (cf_desc.solve_mode = CF_SOLVE_INVERSE_GEMM): Y = X Delta with X = L^-1 computed
+// once on the host -- a triangular GEMM with no dependency chain, so rows split over as many
+// workgroups as the batch needs ("Hard parts": the alternative to the blocked solve).
+// Stream of (row block rb of 4 tiles = 64 rows, wave g of 4): the wave's quarter of the K range
+// [0, 64 (rb+1)), as [q < 2 (rb+1)][tile j < 4][lane] -> {X[row][8 s2 + k], X[row][8 s2 + 4 + k]},
+// row = 64 rb + 16 j + (l&15), k = l>>4, s2 = g * 2 (rb+1) + q.
+// ------------------------------------------------------------------------------------------------
+struct cf_host_invpack {
+  int64_t n = 0, n_pad = 0;
+  int32_t n_rowblocks = 0;
+  std::vector<cf_d2> frags;
+  std::vector<int64_t> off;  // [n_rowblocks*4] in fragments
+};
+
+// X = L^-1 (lower triangular, row-major n_pad x n_pad, identity on the padding), column by column.
+static void cf_invert_lower(const double* L, int64_t n, int64_t ld, int64_t n_pad, std::vector<double>& X) {
+  X.assign((size_t)n_pad * n_pad, 0.0);
+  std::vector<double> col((size_t)n_pad);
+  for (int64_t j = 0; j < n_pad; ++j) {
+    if (j >= n) { X[(size_t)j * n_pad + j] = 1.0; continue; }
+    col[j] = 1.0 / L[j * ld + j];
+    for (int64_t i = j + 1; i < n; ++i) {
+      const double* row = L + i * ld;
+      double acc = 0.0;
+      for (int64_t k = j; k < i; ++k) acc += row[k] * col[k];
+      col[i] = -acc / row[i];
+    }
+    for (int64_t i = j; i < n; ++i) X[(size_t)i * n_pad + j] = col[i];
+  }
+}
+
+static void cf_pack_inverse(const double* L, int64_t n, int64_t ld, cf_host_invpack& out) {
+  const int64_t n_pad = (n + 15) / 16 * 16, T = n_pad / 16;
+  const int RB = (int)((T + 3) / 4);
+  out.n = n;
+  out.n_pad = n_pad;
+  out.n_rowblocks = RB;
+  out.off.assign((size_t)RB * 4, 0);
+  std::vector<double> X;
+  cf_invert_lower(L, n, ld, n_pad, X);
+  int64_t total = 0;
+  for (int rb = 0; rb < RB; ++rb)
+    for (int g = 0; g < 4; ++g) {
+      out.off[rb * 4 + g] = total;
+      total += (int64_t)2 * (rb + 1) * 4;
+    }
+  total += 32;  // slack for the kernel's software pipeline
+  out.frags.assign((size_t)total * 64, cf_d2{0.0, 0.0});
+  for (int rb = 0; rb < RB; ++rb)
+    for (int g = 0; g < 4; ++g) {
+      cf_d2* st = out.frags.data() + out.off[rb * 4 + g] * 64;
+      const int64_t nq = 2 * (rb + 1);
+      for (int64_t q = 0; q < nq; ++q)
+        for (int j = 0; j < 4; ++j)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int64_t row = 64 * rb + 16 * j + (lane & 15);
+            const int64_t c0 = 8 * (g * nq + q) + (lane >> 4);
+            if (row >= n_pad) continue;  // missing tile of the last row block stays zero
+            cf_d2& f = st[(q * 4 + j) * 64 + lane];
+            f.x = c0 <= row ? X[(size_t)row * n_pad + c0] : 0.0;
+            f.y = c0 + 4 <= row ? X[(size_t)row * n_pad + c0 + 4] : 0.0;
+          }
+    }
+}
+
+static double cf_invpack_replay_host(const cf_host_invpack& pk, const double* b_in) {
+  const int64_t n_pad = pk.n_pad;
+  std::vector<double> b((size_t)n_pad + 64, 0.0);
+  for (int64_t i = 0; i < pk.n; ++i) b[i] = b_in[i];
+  double chi = 0.0;
+  for (int rb = 0; rb < pk.n_rowblocks; ++rb) {
+    double y[64] = {0.0};
+    const int64_t nq = 2 * (rb + 1);
+    for (int g = 0; g < 4; ++g) {
+      const cf_d2* st = pk.frags.data() + pk.off[rb * 4 + g] * 64;
+      for (int64_t q = 0; q < nq; ++q)
+        for (int j = 0; j < 4; ++j)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int64_t c0 = 8 * (g * nq + q) + (lane >> 4);
+            const cf_d2& f = st[(q * 4 + j) * 64 + lane];
+            y[16 * j + (lane & 15)] += f.x * b[c0] + f.y * b[c0 + 4];
+          }
+    }
+    for (int i = 0; i < 64; ++i) chi += y[i] * y[i];
+  }
+  return chi;
+}
+
+// Probe of the inverse pack: worst relative chi^2 discrepancy against row-by-row substitution over
+// a pseudo-random vector and the all-ones vector (an offset-like residual).
+static double cf_invpack_probe(const cf_host_invpack& pk, const double* L, int64_t ld) {
+  const int64_t n = pk.n;
+  double worst = 0.0;
+  for (int mode = 0; mode < 2; ++mode) {
+    std::vector<double> b((size_t)n), y((size_t)n);
+    uint64_t s = 0x1234567ull;
+    for (int64_t i = 0; i < n; ++i) {
+      s += 0x9E3779B97F4A7C15ull;
+      uint64_t z = s;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      z ^= z >> 31;
+      b[i] = mode == 0 ? (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0 : 1.0;
+    }
+    double ref = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+      const double* row = L + i * ld;
+      double acc = 0.0;
+      for (int64_t j = 0; j < i; ++j) acc += row[j] * y[j];
+      y[i] = (b[i] - acc) / row[i];
+      ref += y[i] * y[i];
+    }
+    const double got = cf_invpack_replay_host(pk, b.data());
+    const double rel = std::fabs(got - ref) / (std::fabs(ref) > 0 ? std::fabs(ref) : 1.0);
+    if (!(rel <= worst)) worst = rel;
+  }
+  return worst;
+}
+
 #endif

@@ -50,6 +50,11 @@ CF_DECLARE_TRSM(1, 4)
 CF_DECLARE_TRSM(2, 4)
 CF_DECLARE_TRSM(4, 4)
 CF_DECLARE_TRSM(2, 8)
+extern "C" __global__ void inv_gemm_chi2_kernel(cf_dev_invpack pk, int n_pad, const double* delta, int64_t w_pad,
+                                                double* partial);
+extern "C" __global__ void finalize_partials_kernel(cf_dev_desc d, const double* theta, int64_t W, int64_t w_pad,
+                                                    const double* partial, int n_rowblocks, const double* chi2_extra,
+                                                    double* out, int out_kind, unsigned long long* nonfinite);
 extern "C" __global__ void finalize_kernel(cf_dev_desc d, const double* theta, int64_t W, const double* chi2_extra,
                                            double* out, int out_kind, unsigned long long* nonfinite);
 extern "C" __global__ void interp_kernel(const double* xq, int64_t nq, const double* x, const double* y,
@@ -138,8 +143,28 @@ struct PackedFactor {
   }
 };
 
+struct InversePack {
+  DevBuf frags, off;
+  cf_dev_invpack dev{};
+  int64_t bytes = 0;
+  int upload(const cf_host_invpack& hp) {
+    bytes = (int64_t)(hp.frags.size() * sizeof(cf_d2));
+    if (frags.ensure(hp.frags.size() * sizeof(cf_d2))) return CF_ERR_HIP;
+    if (off.ensure(hp.off.size() * 8)) return CF_ERR_HIP;
+    HIP_TRY(hipMemcpy(frags.p, hp.frags.data(), hp.frags.size() * sizeof(cf_d2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(off.p, hp.off.data(), hp.off.size() * 8, hipMemcpyHostToDevice));
+    dev.frags = frags.as<const cf_d2>();
+    dev.off = off.as<const int64_t>();
+    dev.n_rowblocks = hp.n_rowblocks;
+    return 0;
+  }
+};
+
 struct cf_handle {
   int device = 0;
+  int solve_mode = 0;
+  InversePack ipack;
+  DevBuf partial;
   hipStream_t stream = nullptr;
   // timing ring: 3 events per evaluation (before A, between A and B, after B)
   std::vector<hipEvent_t> ev;
@@ -182,6 +207,9 @@ static int ensure_workspace(cf_handle* h, int64_t W) {
   if (h->theta.ensure((size_t)w_pad * (h->d.ndim > 0 ? h->d.ndim : 1) * 8)) return CF_ERR_HIP;
   if (h->out.ensure((size_t)w_pad * 8)) return CF_ERR_HIP;
   if (h->chi2_extra.ensure((size_t)w_pad * 8)) return CF_ERR_HIP;
+  if (h->d.n_sn > 0 && h->solve_mode == CF_SOLVE_INVERSE_GEMM) {
+    if (h->partial.ensure((size_t)w_pad * h->ipack.dev.n_rowblocks * 8)) return CF_ERR_HIP;
+  }
   if (h->d.n_sn > 0) {
     if (h->delta.ensure((size_t)w_pad * n_pad * 8)) return CF_ERR_HIP;
     if (h->ypk.ensure((size_t)w_pad * n_pad * 8 + CF_YPK_SLACK)) return CF_ERR_HIP;
@@ -228,6 +256,8 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
     if (c->n_gl < 1 || c->n_gl > CF_MAX_GL || !c->gl_x || !c->gl_w)
       return fail(CF_ERR_INVALID, "cf_create: the CMB block needs 1..256 Gauss-Legendre nodes");
   }
+  if (c->solve_mode != CF_SOLVE_BLOCKED_TRSM && c->solve_mode != CF_SOLVE_INVERSE_GEMM)
+    return fail(CF_ERR_INVALID, "cf_create: bad solve_mode");
   if (c->n_cc < 0 || c->n_cc > CF_MAX_CC) return fail(CF_ERR_INVALID, "cf_create: n_cc must be in 0..64");
   if (c->n_cc > 0 && (!c->cc_z || !c->cc_h || !c->cc_inv_cov))
     return fail(CF_ERR_INVALID, "cf_create: cosmic-chronometer arrays must not be null");
@@ -359,6 +389,18 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
                                                    std::to_string(h->pack_probe_rel) + " relative on a probe vector (limit 1e-11): "
                                                    "the factor's diagonal blocks are too ill-conditioned for 256-row block inverses"));
     if ((rc = h->pack.upload(hp))) return bail(rc);
+    h->solve_mode = c->solve_mode;
+    if (c->solve_mode == CF_SOLVE_INVERSE_GEMM) {
+      cf_host_invpack ip;
+      cf_pack_inverse(c->sn_chol, c->n_sn, c->sn_chol_ld, ip);
+      const double probe = cf_invpack_probe(ip, c->sn_chol, c->sn_chol_ld);
+      if (!(probe <= CF_PROBE_LIMIT))
+        return bail(fail(CF_ERR_ILL_CONDITIONED, "cf_create: the explicit inverse of the factor disagrees with row-by-row forward "
+                                                     "substitution by " + std::to_string(probe) + " relative (limit 1e-11); use "
+                                                     "CF_SOLVE_BLOCKED_TRSM for this covariance"));
+      if (probe > h->pack_probe_rel) h->pack_probe_rel = probe;
+      if ((rc = h->ipack.upload(ip))) return bail(rc);
+    }
   }
   if (c->n_bao > 0) {
     int rc;
@@ -416,7 +458,7 @@ extern "C" int cf_get_info(cf_handle* h, cf_info* info) {
   memset(info, 0, sizeof(*info));
   info->n_sn = h->d.n_sn;
   info->n_sn_pad = h->d.n_pad;
-  info->packed_chol_bytes = h->pack.bytes;
+  info->packed_chol_bytes = h->pack.bytes + h->ipack.bytes;
   info->workspace_bytes = (int64_t)(h->theta.bytes + h->out.bytes + h->delta.bytes + h->ypk.bytes);
   info->max_walkers = h->max_walkers;
   info->device = h->device;
@@ -512,7 +554,14 @@ static int launch_path(cf_handle* h, const double* d_theta, int64_t W, double* d
                        h->delta.as<double>(), extra, dm_out, mucorr_out, blocks_out, bao_out);
   }
   if (ev) HIP_TRY(hipEventRecord(ev[1], st));
-  if (d.n_sn > 0) {
+  if (d.n_sn > 0 && h->solve_mode == CF_SOLVE_INVERSE_GEMM) {
+    const int64_t w_pad = h->max_walkers;
+    const unsigned panels = (unsigned)((W + 15) / 16);
+    hipLaunchKernelGGL(inv_gemm_chi2_kernel, dim3((unsigned)h->ipack.dev.n_rowblocks, panels), dim3(256), 0, st, h->ipack.dev,
+                       (int)d.n_pad, h->delta.as<const double>(), w_pad, h->partial.as<double>());
+    hipLaunchKernelGGL(finalize_partials_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, d, d_theta, W, w_pad,
+                       h->partial.as<const double>(), (int)h->ipack.dev.n_rowblocks, (const double*)extra, d_out, out_kind, nf);
+  } else if (d.n_sn > 0) {
     int rc = launch_trsm(d, h->pack.dev, d_theta, W, h->delta.as<const double>(), h->ypk.as<d2>(), extra, d_out, out_kind, nf, st);
     if (rc) return rc;
   } else {
@@ -682,6 +731,20 @@ extern "C" int cf_solve_triangular(const double* L, int64_t n, int64_t ld, const
     return rc;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, dout.p, (size_t)nrhs * 8, hipMemcpyDeviceToHost));
+  return CF_OK;
+}
+
+// Host-only self-test of the latency-mode packing (explicit inverse): chi^2 of one right-hand side by
+// replaying the fragment streams, and the create-time probe value.  CPU test-suite only.
+extern "C" int cf_selftest_invpack_host(const double* L, int64_t n, int64_t ld, const double* b, double* chi2_out,
+                                        double* probe_out) {
+  if (!L || !b || !chi2_out) return fail(CF_ERR_INVALID, "cf_selftest_invpack_host: null argument");
+  for (int64_t i = 0; i < n; ++i)
+    if (!(L[i * ld + i] > 0.0) || !std::isfinite(L[i * ld + i])) return fail(CF_ERR_NOT_POSDEF, "cf_selftest_invpack_host: bad pivot");
+  cf_host_invpack ip;
+  cf_pack_inverse(L, n, ld, ip);
+  *chi2_out = cf_invpack_replay_host(ip, b);
+  if (probe_out) *probe_out = cf_invpack_probe(ip, L, ld);
   return CF_OK;
 }
 

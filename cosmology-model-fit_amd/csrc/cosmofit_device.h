@@ -114,6 +114,14 @@ struct cf_dev_pack {
   int32_t pad;
 };
 
+// Latency mode: fragment streams of X = L^-1 per (64-row block, wave); see cf_pack.h.
+struct cf_dev_invpack {
+  const cf_d2* frags;
+  const int64_t* off;  // [n_rowblocks*4]
+  int32_t n_rowblocks;
+  int32_t pad;
+};
+
 #ifdef __HIPCC__
 #define CF_HD __host__ __device__
 #else

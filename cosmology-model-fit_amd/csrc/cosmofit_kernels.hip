@@ -873,6 +873,89 @@ CF_INSTANTIATE_TRSM(4, 4)
 CF_INSTANTIATE_TRSM(2, 8)
 
 // ------------------------------------------------------------------------------------------------
+// Latency mode: Y = L^-1 Delta as a triangular GEMM against the host-inverted factor, one 256-thread
+// workgroup per (64-row block, 16-walker panel); the four waves split the K range, meet in LDS, and
+// the workgroup writes its share of chi^2 to partial[rb][walker].  No dependency between workgroups,
+// so a single walker already spreads over ~27 CUs (the blocked solve keeps a panel on one CU).
+// Sums of the partials in a fixed order happen in finalize_kernel -> results do not depend on timing.
+// ------------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(256)
+inv_gemm_chi2_kernel(cf_dev_invpack pk, int n_pad, const double* __restrict__ delta, int64_t w_pad,
+                     double* __restrict__ partial) {
+  __shared__ __align__(16) d4 part[4][4][64];  // [wave][tile][lane]: 32 KB
+  __shared__ double chi_tile[4][16];
+  const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+  const int col = lane & 15, kq = lane >> 4;
+  const int rb = blockIdx.x;
+  const int64_t w0 = (int64_t)blockIdx.y * 16;
+  const int nq = 2 * (rb + 1);
+  const d2* A = pk.frags + pk.off[rb * 4 + g] * 64 + lane;
+  const double* drow = delta + (w0 + col) * (int64_t)n_pad;
+  int kidx = 8 * g * nq + kq;  // column of X / row of Delta this lane feeds for the current K-step pair
+  d4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
+  // 2-deep software pipeline (nq is even).  The factor stream carries slack for the overrun; Delta is
+  // only read inside the walker's own row (the ragged last row block has K columns past n_pad: a
+  // neighbour's NaN times a zero of X would otherwise leak across walkers).
+  d2 a[2][4];
+  double bx[2], by[2];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[p][j] = A[(p * 4 + j) * 64];
+    bx[p] = kidx < n_pad ? drow[kidx] : 0.0;
+    by[p] = kidx + 4 < n_pad ? drow[kidx + 4] : 0.0;
+    kidx += 8;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  A += 2 * 4 * 64;
+  for (int q = 0; q < nq; q += 2) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = mfma_f64(a[p][j].x, bx[p], acc[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = mfma_f64(a[p][j].y, by[p], acc[j]);
+      __builtin_amdgcn_sched_barrier(0);
+      const bool more = q + 2 + p < nq;  // wave-uniform: refills past the wave's K range are not used
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[p][j] = A[(p * 4 + j) * 64];
+      bx[p] = (more && kidx < n_pad) ? drow[kidx] : 0.0;
+      by[p] = (more && kidx + 4 < n_pad) ? drow[kidx + 4] : 0.0;
+      kidx += 8;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    A += 2 * 4 * 64;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) part[g][j][lane] = acc[j];
+  __syncthreads();
+  // wave j owns tile j: y = sum of the four K-quarters, then this tile's column sums of y^2
+  const d4 y = part[0][g][lane] + part[1][g][lane] + part[2][g][lane] + part[3][g][lane];
+  double c = y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
+  c += __shfl_xor(c, 16, CF_WAVE);
+  c += __shfl_xor(c, 32, CF_WAVE);
+  if (lane < 16) chi_tile[g][lane] = c;
+  __syncthreads();
+  if (tid < 16) partial[(int64_t)rb * w_pad + w0 + tid] = ((chi_tile[0][tid] + chi_tile[1][tid]) + chi_tile[2][tid]) + chi_tile[3][tid];
+}
+
+// Epilogue of the latency mode: chi2 = sum over row blocks (fixed order) + the small blocks.
+extern "C" __global__ void finalize_partials_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, int64_t w_pad,
+                                                    const double* __restrict__ partial, int n_rowblocks,
+                                                    const double* __restrict__ chi2_extra, double* __restrict__ out,
+                                                    int out_kind, unsigned long long* nonfinite) {
+  const int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (w >= W) return;
+  double c2 = 0.0;
+  for (int rb = 0; rb < n_rowblocks; ++rb) c2 += partial[(int64_t)rb * w_pad + w];
+  if (chi2_extra) c2 += chi2_extra[w];
+  out[w] = finalize_value(d, theta + w * d.ndim, c2, out_kind, nonfinite);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Likelihoods without an SN block: only the epilogue.
 // ------------------------------------------------------------------------------------------------
 extern "C" __global__ void finalize_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W,

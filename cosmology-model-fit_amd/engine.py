@@ -41,7 +41,7 @@ class LikelihoodEngine:
     def __init__(self, *, ndim: int, z_max: float, n_grid: int = 4000, fde: int = L.CF_FDE_LCDM,
                  ez_model: int = L.CF_EZ_LATE_FLAT, params: dict, sn: Optional[dict] = None,
                  bao: Optional[dict] = None, cmb: Optional[dict] = None, physical: Optional[dict] = None,
-                 cc: Optional[dict] = None,
+                 cc: Optional[dict] = None, solve_mode: int = L.CF_SOLVE_BLOCKED_TRSM,
                  bounds=None, gauss: Sequence = (), chi2_gauss: Sequence = (), cpl_wall: bool = False,
                  device: int = 0, c_km_s: float = C_KM_S):
         """
@@ -57,6 +57,8 @@ class LikelihoodEngine:
         physical: dict(or_h2, omnu_h2, o_gamma_h2, nu_m0, nu_rho0, nu_qs_sq[5], nu_ws[5]) — required by
             ez_model=CF_EZ_PHYSICAL (see cmb_data.PLANCK_ACT / EARLY_LCDM).
         gauss / chi2_gauss: sequences of (idx, mean, sigma).
+        solve_mode: CF_SOLVE_BLOCKED_TRSM (default, throughput) or CF_SOLVE_INVERSE_GEMM (latency mode for
+            small batches: single theta calls of log_evidence.py, emcee ensembles of a few hundred walkers).
         """
         lib = L.lib()
         d = L.cf_desc()
@@ -64,6 +66,7 @@ class LikelihoodEngine:
         d.device, d.ndim = device, ndim
         d.ez_model, d.fde, d.n_grid = ez_model, fde, n_grid
         d.z_max, d.c_km_s = float(z_max), float(c_km_s)
+        d.solve_mode = int(solve_mode)
         unknown = set(params) - set(L.SLOTS)
         if unknown:
             raise ValueError(f"unknown parameter slots {sorted(unknown)}; valid: {L.SLOTS}")

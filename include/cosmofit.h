@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 2
+#define CF_ABI_VERSION 3
 
 typedef struct cf_handle cf_handle;
 
@@ -108,6 +108,16 @@ enum cf_cmb_mode {
   CF_CMB_R_LA_WB = 1,   /* (R, l_A, omega_b) 3-vector x 3x3 inverse cov   bao/desi_cmb_des5y.py:126-129 */
   CF_CMB_LA_ONLY = 2,   /* only the l_A component                        bao/desi_des5y_bbn_theta_star.py:110-111 */
   CF_CMB_THETA_WB_WM = 3 /* (100 theta*, omega_b, omega_m)               cmb/data_early_lcdm_compression.py:198-207 */
+};
+
+/* How chi^2 = || L^-1 Delta ||^2 is evaluated (both on FP64 matrix cores). */
+enum cf_solve_mode {
+  CF_SOLVE_BLOCKED_TRSM = 0, /* default: blocked forward substitution, one workgroup per 16-walker panel; best
+                                throughput for batches >= ~4096 walkers */
+  CF_SOLVE_INVERSE_GEMM = 1  /* latency mode: triangular GEMM against L^-1 (inverted once on the host, probed
+                                against row-by-row substitution at cf_create); rows spread over many CUs, so
+                                batches of 1..2048 walkers finish several times sooner (solve_triangular.py:5-14
+                                evaluated one theta at a time by log_evidence.py:20-46 and by small emcee ensembles) */
 };
 
 /* Output selector for cf_eval*. */
@@ -208,6 +218,9 @@ typedef struct cf_desc {
   const double* cc_h;       /* [n_cc] km/s/Mpc */
   const double* cc_inv_cov; /* [n_cc*n_cc] */
   double cc_logdet;         /* ln det of the CC covariance */
+
+  int32_t solve_mode;       /* cf_solve_mode */
+  int32_t _pad4;
 } cf_desc;
 
 typedef struct cf_info {
@@ -277,6 +290,11 @@ int cf_solve_triangular(const double* L, int64_t n, int64_t ld, const double* b,
  * entry point ever calls it. */
 int cf_selftest_pack_host(const double* L, int64_t n, int64_t ld, const double* b, double* chi2_out,
                           int64_t* packed_bytes);
+
+/* The same for the latency-mode packing (explicit inverse); probe_out (may be NULL) receives the value
+ * cf_create compares with 1e-11. */
+int cf_selftest_invpack_host(const double* L, int64_t n, int64_t ld, const double* b, double* chi2_out,
+                             double* probe_out);
 
 /* Device self-test of the in-kernel log10 used for the distance moduli: out[k] = log10(x[k]). */
 int cf_selftest_log10(const double* x, int64_t n, double* out);

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(pkg):
 def test_desc_layout_matches_c(pkg, tmp_path):
     """sizeof / offsetof of cf_desc and cf_info as gcc sees them == the ctypes mirror."""
     fields = ["ndim", "z_max", "param", "n_sn", "sn_chol_ld", "n_bao", "rd_fit", "cmb_mode", "cmb_inv_cov", "nu_ws",
-              "bounds", "gauss", "chi2_gauss", "sn_fixed_mu", "n_cc", "cc_logdet"]
+              "bounds", "gauss", "chi2_gauss", "sn_fixed_mu", "n_cc", "cc_logdet", "solve_mode"]
     prog = '#include <stdio.h>\n#include <stddef.h>\n#include "cosmofit.h"\nint main(){printf("%zu %zu", sizeof(cf_desc), sizeof(cf_info));' + \
         "".join(f'printf(" %zu", offsetof(cf_desc, {f}));' for f in fields) + "return 0;}"
     src = tmp_path / "sz.c"
@@ -87,6 +87,22 @@ def test_packed_factor_replay_matches_forward_substitution(pkg, n):
     pkg._lib.check(pkg.lib().cf_selftest_pack_host(p(Lm), n, n, p(b), C.byref(chi2), C.byref(nbytes)))
     assert chi2.value == pytest.approx(oc.solve_triangular(Lm, b), rel=1e-12)
     assert nbytes.value > 0
+
+
+@pytest.mark.parametrize("n", [1, 16, 63, 64, 65, 200, 531])
+def test_inverse_pack_replay_matches_forward_substitution(pkg, n):
+    """Latency-mode packing (explicit inverse, 64-row blocks x 4 K-quarters) replayed on the host."""
+    from oracle import oracle_c as oc
+
+    rng = np.random.default_rng(100 + n)
+    M = rng.standard_normal((n, n))
+    Lm = np.linalg.cholesky(M @ M.T + n * np.eye(n)) + np.triu(rng.standard_normal((n, n)), 1) * 3.0
+    b = rng.standard_normal(n)
+    chi2, probe = C.c_double(), C.c_double()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    pkg._lib.check(pkg.lib().cf_selftest_invpack_host(p(Lm), n, n, p(b), C.byref(chi2), C.byref(probe)))
+    assert chi2.value == pytest.approx(oc.solve_triangular(Lm, b), rel=1e-12)
+    assert probe.value < 1e-12
 
 
 def test_pack_probe_flags_ill_conditioned_blocks(pkg):

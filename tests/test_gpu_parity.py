@@ -279,3 +279,41 @@ def test_batched_laplace_evidence_gpu_vs_oracle(gpu):
     np.testing.assert_allclose(d_gpu["theta_map"], d_cpu["theta_map"], rtol=1e-5, atol=1e-6)
     assert d_gpu["log_post_map"] >= lp.max() - 1e-9
     lk.engine.close()
+
+
+# ---- latency mode: triangular GEMM against the explicit inverse (cf_solve_mode CF_SOLVE_INVERSE_GEMM) -------------
+def test_latency_mode_parity_and_speed(gpu, config2):
+    import time
+    lk_blocked, ref, theta = config2
+    syn = gpu.synthetic.pantheon_like(n_sn=1701, seed=0)
+    lk = gpu.sn_pantheon.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"], latency_mode=True)
+    assert lk.engine.info()["pack_probe_rel"] < 1e-12
+    full = lk.chi_squared(theta)
+    want = ref.chi2(theta)
+    rel = np.abs(full - want) / np.abs(want)
+    assert rel.max() < RTOL, f"max rel diff {rel.max():.3e}"
+    np.testing.assert_allclose(lk.log_probs_vectorized(theta[:300]), ref.logp(theta[:300]), rtol=RTOL)
+    for W in (1, 2, 15, 16, 17, 100, 512, 2048):  # batch-size invariance inside the mode: bit-identical
+        np.testing.assert_array_equal(lk.chi_squared(theta[:W]), full[:W])
+    one = lk.log_probability(theta[7])
+    assert isinstance(one, float) and one == pytest.approx(ref.logp(theta[7:8])[0], rel=RTOL)
+    # a NaN walker must not leak into its neighbours (the ragged last row block reads K columns past n_pad)
+    bad = theta[:40].copy()
+    bad[13, 2] = -4.0
+    got = lk.chi_squared(bad)
+    assert not np.isfinite(got[13])
+    np.testing.assert_array_equal(np.delete(got, 13), np.delete(full[:40], 13))
+
+    def wall(fn, arg, reps=20):
+        fn(arg)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn(arg)
+        return (time.perf_counter() - t0) / reps * 1e6
+
+    lines = []
+    for W in (1, 75, 512, 2048, 4096):
+        lines.append(f"W={W}: blocked {wall(lk_blocked.log_probs_vectorized, theta[:W]):.0f} us, latency mode {wall(lk.log_probs_vectorized, theta[:W]):.0f} us")
+    print("\n".join(lines))
+    assert wall(lk.log_probs_vectorized, theta[:1]) < wall(lk_blocked.log_probs_vectorized, theta[:1])
+    lk.engine.close()
