@@ -160,9 +160,25 @@ struct InversePack {
   }
 };
 
+// Pinned host staging: pageable caller buffers make hipMemcpyAsync go through the runtime's own
+// bounce buffers; a handle-owned pinned block keeps the host round trip of a small batch short.
+struct PinnedBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+  int ensure(size_t need) {
+    if (need <= bytes) return 0;
+    if (p) { (void)hipHostFree(p); p = nullptr; bytes = 0; }
+    HIP_TRY(hipHostMalloc(&p, need, hipHostMallocDefault));
+    bytes = need;
+    return 0;
+  }
+};
+
 struct cf_handle {
   int device = 0;
   int solve_mode = 0;
+  PinnedBuf stage_in, stage_out;
   InversePack ipack;
   DevBuf partial;
   hipStream_t stream = nullptr;
@@ -206,6 +222,8 @@ static int ensure_workspace(cf_handle* h, int64_t W) {
   const int64_t n_pad = h->d.n_pad > 0 ? h->d.n_pad : 16;
   if (h->theta.ensure((size_t)w_pad * (h->d.ndim > 0 ? h->d.ndim : 1) * 8)) return CF_ERR_HIP;
   if (h->out.ensure((size_t)w_pad * 8)) return CF_ERR_HIP;
+  if (h->stage_in.ensure((size_t)w_pad * (h->d.ndim > 0 ? h->d.ndim : 1) * 8)) return CF_ERR_HIP;
+  if (h->stage_out.ensure((size_t)w_pad * 8)) return CF_ERR_HIP;
   if (h->chi2_extra.ensure((size_t)w_pad * 8)) return CF_ERR_HIP;
   if (h->d.n_sn > 0 && h->solve_mode == CF_SOLVE_INVERSE_GEMM) {
     if (h->partial.ensure((size_t)w_pad * h->ipack.dev.n_rowblocks * 8)) return CF_ERR_HIP;
@@ -602,12 +620,14 @@ extern "C" int cf_eval(cf_handle* h, const double* theta, int64_t W, double* out
   std::lock_guard<std::mutex> lk(h->mu);
   HIP_TRY(hipSetDevice(h->device));
   if ((rc = ensure_workspace(h, W))) return rc;
-  HIP_TRY(hipMemcpyAsync(h->theta.p, theta, (size_t)W * h->d.ndim * 8, hipMemcpyHostToDevice, h->stream));
+  memcpy(h->stage_in.p, theta, (size_t)W * h->d.ndim * 8);
+  HIP_TRY(hipMemcpyAsync(h->theta.p, h->stage_in.p, (size_t)W * h->d.ndim * 8, hipMemcpyHostToDevice, h->stream));
   if ((rc = launch_path(h, h->theta.as<const double>(), W, h->out.as<double>(), out_kind, h->stream, nullptr, nullptr,
                         nullptr, nullptr)))
     return rc;
-  HIP_TRY(hipMemcpyAsync(out, h->out.p, (size_t)W * 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->stage_out.p, h->out.p, (size_t)W * 8, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  memcpy(out, h->stage_out.p, (size_t)W * 8);
   return CF_OK;
 }
 

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Wall-clock latency of the ctypes boundary (host numpy in / out) vs batch size, both solve modes."""
+import importlib, sys, time, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("cosmology-model-fit_amd")
+syn = pkg.synthetic.pantheon_like(n_sn=1701, seed=0)
+th = pkg.synthetic.walkers(pkg.sn_pantheon.bounds, 4096, seed=0)
+for name, lat in (("blocked TRSM", False), ("latency mode", True)):
+    lk = pkg.sn_pantheon.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"], latency_mode=lat)
+    lk.log_probs_vectorized(th)
+    lk.engine.enable_timing(8)
+    for W in (1, 16, 75, 256, 512, 1024, 2048, 4096):
+        for _ in range(3): lk.log_probs_vectorized(th[:W])
+        t0 = time.perf_counter()
+        for _ in range(20): lk.log_probs_vectorized(th[:W])
+        dt = (time.perf_counter() - t0) / 20 * 1e6
+        k = lk.engine.kernel_ms()[-1]
+        print(f"{name:13s} W={W:5d}: wall {dt:6.0f} us ({W / dt:7.3f} evals/us)  kernels: walker {k[0] * 1e3:5.0f} us, solve {k[1] * 1e3:5.0f} us")
+    lk.engine.close()
