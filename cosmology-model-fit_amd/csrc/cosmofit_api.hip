@@ -218,7 +218,8 @@ static int upload_vec(DevBuf& b, const double* src, int64_t n) {
 static int ensure_workspace(cf_handle* h, int64_t W) {
   const int64_t w_pad = (W + 15) / 16 * 16;
   if (w_pad <= h->max_walkers) return 0;
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  // earlier evaluations may still be running on a caller's stream and use the buffers about to be replaced
+  HIP_TRY(hipDeviceSynchronize());
   const int64_t n_pad = h->d.n_pad > 0 ? h->d.n_pad : 16;
   if (h->theta.ensure((size_t)w_pad * (h->d.ndim > 0 ? h->d.ndim : 1) * 8)) return CF_ERR_HIP;
   if (h->out.ensure((size_t)w_pad * 8)) return CF_ERR_HIP;
@@ -463,7 +464,7 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
 extern "C" void cf_destroy(cf_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
-  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  (void)hipDeviceSynchronize();  // evaluations launched on callers' streams may still use the workspace
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);

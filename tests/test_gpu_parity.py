@@ -317,3 +317,38 @@ def test_latency_mode_parity_and_speed(gpu, config2):
     print("\n".join(lines))
     assert wall(lk.log_probs_vectorized, theta[:1]) < wall(lk_blocked.log_probs_vectorized, theta[:1])
     lk.engine.close()
+
+
+def test_posterior_means_match_the_oracle_driven_chain_to_sampling_noise(gpu):
+    """north_star: 'chi^2 matches to <= 1e-10 (posterior means to sampling noise)'.  A short chain with the reference's
+    move mixture (sn/pantheon.py:114-117) on the GPU engine vs the same chain driven by the CPU oracle."""
+    torch = pytest.importorskip("torch")
+    from oracle import oracle_c, oracle_np as onp
+
+    syn = gpu.synthetic.pantheon_like(n_sn=160, seed=11)
+    lk = gpu.sn_pantheon.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"], latency_mode=True)
+    co = oracle_c.COracle(onp.Likelihood(
+        ndim=4, z_max=lk.z_max, offset=onp.Slot(0), H0=onp.Slot(1), Om=onp.Slot(2), v=onp.Slot(3),
+        z_cmb=syn["z_cmb"], z_hel=syn["z_hel"], obs=syn["obs"], chol=syn["chol"],
+        bounds=gpu.sn_pantheon.bounds, gauss=[gpu.sn_pantheon.H0_PRIOR]))
+    start = gpu.synthetic.THETA_TRUE + np.array([0.02, 1.0, 0.03, 0.3]) * np.random.default_rng(4).standard_normal((128, 4))
+    moves = gpu.ensemble.REFERENCE_MOVES
+    e_gpu = gpu.ensemble.ShardedEnsemble(lk.engine.torch_log_prob(), torch.from_numpy(start).to("cuda:0"), seed=5, moves=moves)
+    e_cpu = gpu.ensemble.ShardedEnsemble(lambda t: torch.from_numpy(co.logp(t.numpy())), torch.from_numpy(start), seed=5, moves=moves)
+    burn, keep = 60, 120
+    chain_g, chain_c = [], []
+    for step in range(burn + keep):
+        e_gpu.step()
+        e_cpu.step()
+        if step >= burn:
+            chain_g.append(e_gpu.x.cpu().numpy().copy())
+            chain_c.append(e_cpu.x.numpy().copy())
+    g, c = np.concatenate(chain_g), np.concatenate(chain_c)
+    sd = c.std(axis=0)
+    # identical seeds + chi^2 agreement at 1e-14: accept/reject decisions essentially never differ
+    assert np.all(np.abs(g.mean(axis=0) - c.mean(axis=0)) < 0.05 * sd), (g.mean(axis=0), c.mean(axis=0), sd)
+    assert np.all(np.abs(g.std(axis=0) / sd - 1) < 0.05)
+    # and the posterior sits on the truth the data were generated from
+    assert np.all(np.abs(g.mean(axis=0) - gpu.synthetic.THETA_TRUE) < 4 * sd)
+    assert 0.1 < e_gpu.acceptance_fraction() < 0.9
+    lk.engine.close()
