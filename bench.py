@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--n-sn", type=int, default=1701)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-seconds of work of the cpu_baseline sample (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="pantheon", choices=["pantheon", "desi_cmb_des5y"],
+                    help="pantheon = BASELINE configs[1] (the headline, default); desi_cmb_des5y = configs[2] shape "
+                         "(N=1820 SN + 14 BAO + Planck/ACT CMB, physical-density E(z)) on the committed fixture data")
     args = ap.parse_args()
 
     import torch
@@ -78,14 +81,28 @@ def main():
     Wl = args.walkers_per_gpu
     W_total = Wl * world
 
-    syn = pkg.synthetic.pantheon_like(n_sn=args.n_sn, seed=0)
-    lk = sn.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"], device=local_rank)
+    if args.workload == "desi_cmb_des5y":
+        # joint likelihood of bao/desi_cmb_des5y.py: real DES-Dovekie redshifts + real DESI FS+Lya BAO data from the
+        # golden fixture (tests/golden/bao_desi_cmb_des5y.npz), seeded synthetic SN covariance
+        g = np.load(os.path.join(ROOT, "tests", "golden", "bao_desi_cmb_des5y.npz"))
+        rng = np.random.default_rng(0)
+        A = 0.01 * rng.standard_normal((g["sigma"].size, 40))
+        chol = np.linalg.cholesky(np.diag(g["sigma"] ** 2) + A @ A.T)
+        lk = pkg.likelihoods.DesiCmbDes5y(g["z_cmb"], g["z_hel"], g["obs"], None, g["bao_z"], g["bao_val"], g["bao_qty"],
+                                          g["bao_inv_cov"], chol=chol, device=local_rank)
+        box = np.array([(-0.5, 0.5), (60.0, 75.0), (0.010, 0.030), (0.01, 0.25), (-4.5, 4.5)])  # bao/desi_cmb_des5y.py:156-161
+        args.n_sn, ndim, kind = int(g["z_cmb"].size), 5, pkg.CF_OUT_LOGL
+        args.no_cpu_baseline = True
+    else:
+        syn = pkg.synthetic.pantheon_like(n_sn=args.n_sn, seed=0)
+        lk = sn.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"], device=local_rank)
+        box, ndim, kind = sn.bounds, 4, pkg.CF_OUT_LOGP
     eng = lk.engine
 
-    theta_all_host = pkg.synthetic.walkers(sn.bounds, W_total, seed=0)
+    theta_all_host = pkg.synthetic.walkers(box, W_total, seed=0)
     mine = slice(rank * Wl, (rank + 1) * Wl)
     theta_local = torch.from_numpy(theta_all_host[mine].copy()).to(dev)
-    theta_all = torch.empty((W_total, 4), dtype=torch.float64, device=dev)
+    theta_all = torch.empty((W_total, ndim), dtype=torch.float64, device=dev)
     logp = torch.empty(Wl, dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -95,10 +112,10 @@ def main():
             if backend == "nccl":
                 dist.all_gather_into_tensor(theta_all, theta_local)
             else:  # rehearsal backend without device collectives: stage through the host
-                host = torch.empty((W_total, 4), dtype=torch.float64)
+                host = torch.empty((W_total, ndim), dtype=torch.float64)
                 dist.all_gather_into_tensor(host, theta_local.cpu())
                 theta_all.copy_(host)
-        eng.eval_device(theta_local.data_ptr(), Wl, logp.data_ptr(), pkg.CF_OUT_LOGP, stream)
+        eng.eval_device(theta_local.data_ptr(), Wl, logp.data_ptr(), kind, stream)
 
     def fence():
         torch.cuda.synchronize()
@@ -133,7 +150,8 @@ def main():
         solve_flops = flops_per_eval_solve(args.n_sn) * Wl
         achieved = solve_flops / (solve_ms * 1e-3) / 1e12
         out = {
-            "metric": "walker-logL evals/s, Pantheon+ 1701-SN full-cov chi2",
+            "metric": "walker-logL evals/s, Pantheon+ 1701-SN full-cov chi2" if args.workload == "pantheon" else
+                      "walker-logL evals/s, DESI BAO + Planck/ACT CMB + DES-SN joint chi2 (config 3 shape)",
             "value": W_total * args.steps / dt,
             "unit": "evals/s",
             "n_gpus": world,
@@ -146,9 +164,12 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"Pantheon+-shaped {args.n_sn}-SN full-cov flat-LCDM chi2 + prior, "
-                            f"{Wl} walkers per GPU per step (BASELINE configs[1] at N=1), G=4000, theta resident in HBM",
-                "walkers_per_gpu": Wl, "walkers_total": W_total, "n_sn": args.n_sn, "n_grid": 4000, "ndim": 4,
+                "workload": (f"Pantheon+-shaped {args.n_sn}-SN full-cov flat-LCDM chi2 + prior, "
+                             f"{Wl} walkers per GPU per step (BASELINE configs[1] at N=1), G=4000, theta resident in HBM")
+                if args.workload == "pantheon" else
+                (f"bao/desi_cmb_des5y.py joint log L: {args.n_sn} SNe (velocity step) + 14 BAO (PCHIP D_H, F_AP) + Planck/ACT "
+                 f"(R, l_A, wb), physical-density E(z), {Wl} walkers per GPU per step"),
+                "walkers_per_gpu": Wl, "walkers_total": W_total, "n_sn": args.n_sn, "n_grid": 4000, "ndim": ndim,
                 "parallelism": f"walkers sharded over {world} GPU(s)" + (", RCCL all-gather of positions per step" if world > 1 else ""),
             },
             "roofline": {
@@ -166,7 +187,7 @@ def main():
             },
             "kernels_ms": {"walker_kernel": resid_ms, "trsm_chi2_kernel": solve_ms},
         }
-        if world == 1:
+        if world == 1 and args.workload == "pantheon":
             # the ctypes boundary as emcee / nautilus call it: host numpy in, host numpy out (PCIe + sync included).
             # Reported for DESIGN.md; never the headline `value`.
             th_host = theta_all_host[mine]

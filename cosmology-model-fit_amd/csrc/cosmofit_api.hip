@@ -189,7 +189,7 @@ struct cf_handle {
   cf_dev_desc d{};
   PackedFactor pack;
   DevBuf z_cmb, z_hel, obs, sn_step;
-  DevBuf bao_z, bao_val, bao_inv_cov, bao_qty, gl_x, gl_w, fixed_mu, cc_z, cc_h, cc_inv_cov;
+  DevBuf bao_z, bao_val, bao_inv_cov, bao_qty, gl_x, gl_w, fixed_mu, cc_z, cc_h, cc_inv_cov, nu_grid;
   DevBuf theta, out, delta, ypk, chi2_extra, nonfinite;
   bool has_small_blocks = false;  // BAO and / or CMB block present
   int64_t max_walkers = 0;
@@ -433,6 +433,22 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
     d.bao_val = h->bao_val.as<const double>();
     d.bao_inv_cov = h->bao_inv_cov.as<const double>();
     d.bao_qty = h->bao_qty.as<const int32_t>();
+  }
+  if (c->ez_model == CF_EZ_PHYSICAL) {
+    // massive-neutrino density at the grid nodes, cmb/data_planck_act_compression.py:53-66 -- independent of theta
+    std::vector<double> nu((size_t)c->n_grid);
+    for (int g = 0; g < c->n_grid; ++g) {
+      const double z = g == c->n_grid - 1 ? c->z_max : (double)g * d.step;
+      const double zp1 = 1.0 + z, r = c->nu_m0 / zp1, mz_sq = r * r;
+      const double ws = std::sqrt(c->nu_qs_sq[0] + mz_sq) * c->nu_ws[0] + std::sqrt(c->nu_qs_sq[1] + mz_sq) * c->nu_ws[1] +
+                        std::sqrt(c->nu_qs_sq[2] + mz_sq) * c->nu_ws[2] + std::sqrt(c->nu_qs_sq[3] + mz_sq) * c->nu_ws[3] +
+                        std::sqrt(c->nu_qs_sq[4] + mz_sq) * c->nu_ws[4];
+      const double zp1_2 = zp1 * zp1;
+      nu[g] = zp1_2 * zp1_2 * ws / c->nu_rho0;
+    }
+    int rc;
+    if ((rc = upload_vec(h->nu_grid, nu.data(), c->n_grid))) return bail(rc);
+    d.nu_grid = h->nu_grid.as<const double>();
   }
   if (c->n_cc > 0) {
     int rc;

@@ -87,16 +87,19 @@ __device__ __forceinline__ double omnu_z(const cf_dev_desc& d, double zp1) {
   return zp1_2 * zp1_2 * ws / d.nu_rho0;
 }
 
-// E^2(z) of both families.
+// E^2(z) of both families.  `nu` < 0: evaluate the massive-neutrino density here; otherwise it is the
+// value tabulated at cf_create for this grid node (it does not depend on theta: 5 sqrt + 2 divides saved
+// per node and per walker, and the tabulated value is the reference's own arithmetic).
 template <int MODEL, int FDE>
-__device__ __forceinline__ double e2_of_z(const cf_dev_desc& d, const WalkerCosmo& wc, double z) {
+__device__ __forceinline__ double e2_of_z(const cf_dev_desc& d, const WalkerCosmo& wc, double z, double nu = -1.0) {
   const double zp1 = 1.0 + z;
   const double cubed = zp1 * zp1 * zp1;
   if (MODEL == CF_EZ_LATE_FLAT_D)
     return (FDE == CF_FDE_LCDM_D) ? wc.Om * cubed + (1.0 - wc.Om)
                                   : wc.Om * cubed + (1.0 - wc.Om) * f_de<FDE>(wc, z, zp1, cubed);
   const double de = (FDE == CF_FDE_LCDM_D) ? wc.Ode : wc.Ode * f_de<FDE>(wc, z, zp1, cubed);
-  return wc.Or * (cubed * zp1) + wc.Obc * cubed + de + wc.Onu * omnu_z(d, zp1);  // bao/desi_cmb_des5y.py:43-48
+  if (nu < 0.0) nu = omnu_z(d, zp1);
+  return wc.Or * (cubed * zp1) + wc.Obc * cubed + de + wc.Onu * nu;  // bao/desi_cmb_des5y.py:43-48
 }
 
 // H(z) in the reference's form H0 * sqrt(E^2) (used where only a few values are needed).
@@ -114,6 +117,13 @@ __device__ __forceinline__ double dh_of_z_fast(const cf_dev_desc& d, const Walke
 // Grid node i of np.linspace(0, z_max, G): i*step, last node forced to z_max (sn/pantheon.py:16).
 __device__ __forceinline__ double grid_z(int i, int G, double step, double z_max) {
   return i == G - 1 ? z_max : (double)i * step;
+}
+
+// the same at grid node g, with the tabulated neutrino density of that node
+template <int MODEL, int FDE>
+__device__ __forceinline__ double dh_of_node(const cf_dev_desc& d, const WalkerCosmo& wc, double c_over_H0, int g) {
+  const double nu = (MODEL == CF_EZ_PHYSICAL_D && d.nu_grid) ? d.nu_grid[g] : -1.0;
+  return c_over_H0 * rsqrt(e2_of_z<MODEL, FDE>(d, wc, grid_z(g, d.n_grid, d.step, d.z_max), nu));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -249,9 +259,9 @@ __device__ __forceinline__ void build_distance_table_regs(const cf_dev_desc& d, 
   double dh[CH];
 #pragma unroll
   for (int k = 0; k < CH; ++k)
-    dh[k] = g0 + k < G ? dh_of_z_fast<MODEL, FDE>(d, wc, c_over_H0, grid_z(g0 + k, G, d.step, d.z_max)) : 0.0;
+    dh[k] = g0 + k < G ? dh_of_node<MODEL, FDE>(d, wc, c_over_H0, g0 + k) : 0.0;
   double prev = __shfl_up(dh[CH - 1], 1, CF_WAVE);
-  if (lane == 0 && g0 > 0 && g0 <= G) prev = dh_of_z_fast<MODEL, FDE>(d, wc, c_over_H0, grid_z(g0 - 1, G, d.step, d.z_max));
+  if (lane == 0 && g0 > 0 && g0 <= G) prev = dh_of_node<MODEL, FDE>(d, wc, c_over_H0, g0 - 1);
   double loc[CH];
   double run = 0.0;
 #pragma unroll
@@ -286,7 +296,7 @@ __device__ __forceinline__ void build_distance_table_lds(const cf_dev_desc& d, c
   const int n_own = max(0, min(CH, G - g0));
   const double c_over_H0 = wc.c / wc.H0;
   for (int k = 0; k < n_own; ++k)
-    tab[base + k].y = dh_of_z_fast<MODEL, FDE>(d, wc, c_over_H0, grid_z(g0 + k, G, d.step, d.z_max));
+    tab[base + k].y = dh_of_node<MODEL, FDE>(d, wc, c_over_H0, g0 + k);
   __syncthreads();
   double run = 0.0;
   double prev = g0 > 0 && n_own > 0 ? tab[base - 2].y : 0.0;  // last node of the previous thread's chunk
@@ -446,7 +456,7 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
               double* __restrict__ blocks_out, double* __restrict__ bao_out) {
   extern __shared__ __align__(16) d2 lds_tab[];
   __shared__ double wave_tot[16];
-  __shared__ double scratch[2 * CF_MAX_GL + CF_MAX_BAO + CF_MAX_CC + 8];
+  __shared__ double scratch[2 * CF_MAX_GL + 2 * CF_MAX_BAO + 2 * CF_MAX_CC + 8];
 
   const int64_t w = blockIdx.x;
   if (w >= W) return;
@@ -518,9 +528,43 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
   double* cc_delta = bao_delta + CF_MAX_BAO;    // [n_cc]
   double* shared = cc_delta + CF_MAX_CC;        // [0] = z_star, [1] = r_d
   const double Ob = slot_get(d, CF_P_OBH2_D, th), Oc = slot_get(d, CF_P_OCH2_D, th);
-  if (tid == 0) {
-    if (d.cmb_mode) shared[0] = z_star_fit(d.zstar_fit, Ob, Oc + Ob + d.omnu_h2);
-    shared[1] = d.rd_from_fit ? r_drag_fit(d.rd_fit, Ob, Ob + Oc + d.omnu_h2) : slot_get(d, CF_P_RD_D, th);
+  // z_star and r_drag are sums of products of powers (14 calls of pow): one power per lane of wave 0, two
+  // dependent rounds (the inner wb^b, wm^m first), then lane 0 combines them in the reference's order.
+  if (tid < 64) {
+    const double wm_z = Oc + Ob + d.omnu_h2, wm_r = Ob + Oc + d.omnu_h2;
+    const double* fz = d.zstar_fit;  // s1 s2 b m e0 c1 e1 e2 c2 e3 e4
+    const double* fr = d.rd_fit;     // b m a1..a9
+    // round 1: lane 0 wb^b(z*), 1 wm^m(z*), 2 wb^b(rd), 3 wm^m(rd)
+    double base1 = (tid & 1) ? ((tid & 2) ? wm_r : wm_z) : Ob;
+    double exp1 = tid == 0 ? fz[2] : tid == 1 ? fz[3] : tid == 2 ? fr[0] : fr[1];
+    const double p1 = tid < 4 ? pow(base1, exp1) : 0.0;
+    const double wbz = __shfl(p1, 0, CF_WAVE), wmz = __shfl(p1, 1, CF_WAVE), wbr = __shfl(p1, 2, CF_WAVE), wmr = __shfl(p1, 3, CF_WAVE);
+    // round 2: lanes 0-4 the z* powers, 5-9 the r_drag powers
+    double base2 = 1.0, exp2 = 1.0;
+    switch (tid) {
+      case 0: base2 = wmz; exp2 = fz[4]; break;
+      case 1: base2 = wbz; exp2 = fz[6]; break;
+      case 2: base2 = wmz; exp2 = fz[7]; break;
+      case 3: base2 = wmz; exp2 = fz[9]; break;
+      case 4: base2 = wbz; exp2 = fz[10]; break;
+      case 5: base2 = wbr; exp2 = fr[3]; break;
+      case 6: base2 = wbr; exp2 = fr[5]; break;
+      case 7: base2 = wmr; exp2 = fr[6]; break;
+      case 8: base2 = wmr; exp2 = fr[8]; break;
+      case 9: base2 = wmr; exp2 = fr[10]; break;
+      default: break;
+    }
+    const double p2 = tid < 10 ? pow(base2, exp2) : 0.0;
+    double q[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) q[k] = __shfl(p2, k, CF_WAVE);
+    if (tid == 0) {
+      // cmb/data_planck_act_compression.py:94-99
+      shared[0] = q[0] + fz[0] * fz[5] * q[1] * q[2] + fz[1] * fz[8] * q[3] * q[4];
+      // cmb/data_planck_act_compression.py:121-124
+      const double den = (fr[2] * q[5]) + (fr[4] * q[6] * q[7]) + (fr[7] * q[8]);
+      shared[1] = d.rd_from_fit ? 1.0 / den - fr[9] / q[9] : slot_get(d, CF_P_RD_D, th);
+    }
   }
   // ---- cosmic chronometers: H_obs - H(z), bao/desi_union3_cc_theta_star.py:129 (last threads of the block) ----
   if (tid >= CF_TPB_A - d.n_cc) {
@@ -560,20 +604,34 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
     }
   }
   __syncthreads();
+  // (delta @ inv_cov)[j] by thread j -- the reference's own order of operations, one column per thread
+  double* bao_t = shared + 2;          // [n_bao]
+  double* cc_t = bao_t + CF_MAX_BAO;   // [n_cc]
+  if (tid < d.n_bao) {
+    double t = 0.0;
+    for (int i = 0; i < d.n_bao; ++i) t += bao_delta[i] * d.bao_inv_cov[i * d.n_bao + tid];
+    bao_t[tid] = t;
+  }
+  if (tid >= 64 && tid < 64 + d.n_cc) {
+    const int j = tid - 64;
+    double t = 0.0;
+    for (int i = 0; i < d.n_cc; ++i) t += cc_delta[i] * d.cc_inv_cov[i * d.n_cc + j];
+    cc_t[j] = t;
+  }
+  // the two Gauss-Legendre sums in node order, on two different waves
+  if (d.cmb_mode && (tid == 128 || tid == 192)) {
+    const int o = tid == 128 ? 0 : d.n_gl;
+    double acc = 0.0;
+    for (int k = 0; k < d.n_gl; ++k) acc += gl_terms[o + k];
+    shared[tid == 128 ? 130 : 131] = acc;
+  }
+  __syncthreads();
   if (tid == 0) {
     double c_bao = 0.0, c_cmb = 0.0;
-    if (d.n_bao > 0) {  // delta @ inv_cov @ delta
-      for (int j = 0; j < d.n_bao; ++j) {
-        double t = 0.0;
-        for (int i = 0; i < d.n_bao; ++i) t += bao_delta[i] * d.bao_inv_cov[i * d.n_bao + j];
-        c_bao += t * bao_delta[j];
-      }
-    }
+    for (int j = 0; j < d.n_bao; ++j) c_bao += bao_t[j] * bao_delta[j];  // ... @ delta
     if (d.cmb_mode) {
       const double zstar = shared[0];
-      double i_rs = 0.0, i_dm = 0.0;
-      for (int k = 0; k < d.n_gl; ++k) i_rs += gl_terms[k];
-      for (int k = 0; k < d.n_gl; ++k) i_dm += gl_terms[d.n_gl + k];
+      const double i_rs = shared[130], i_dm = shared[131];
       const double rs_star = ((1.0 / (1.0 + zstar)) / 2.0) * i_rs;
       const double DM_star = (zstar / 2.0) * i_dm;
       const double Om_h2 = Oc + Ob + d.omnu_h2;
@@ -598,11 +656,7 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
     }
     double c_cc = 0.0;
     if (d.n_cc > 0) {  // delta @ inv_cov @ delta * f_cc^2
-      for (int j = 0; j < d.n_cc; ++j) {
-        double t = 0.0;
-        for (int i = 0; i < d.n_cc; ++i) t += cc_delta[i] * d.cc_inv_cov[i * d.n_cc + j];
-        c_cc += t * cc_delta[j];
-      }
+      for (int j = 0; j < d.n_cc; ++j) c_cc += cc_t[j] * cc_delta[j];
       const double f = slot_get(d, CF_P_FCC_D, th);
       c_cc *= f * f;
     }
