@@ -248,6 +248,44 @@ __device__ __forceinline__ double wave_inclusive_scan(double v) {
 // registers, wave64 DPP scan over the chunk totals, wave totals carried through LDS, then ONE 16-byte
 // LDS store per node.  The node before a chunk comes from the neighbouring lane (shuffle); the first
 // lane of a wave re-evaluates it instead of waiting for another wave (one barrier less).
+// One thread's chunk: dh at its CH nodes and the chunk-local trapezoid prefix.  INTERIOR = the whole WAVE
+// lies strictly inside the grid (no node 0, no last node, nothing past G): no per-node bounds logic.
+template <int MODEL, int FDE, int CH, bool INTERIOR>
+__device__ __forceinline__ double chunk_eval(const cf_dev_desc& d, const WalkerCosmo& wc, double c_over_H0, int g0, int lane,
+                                             double (&dh)[CH], double (&loc)[CH]) {
+  const int G = d.n_grid;
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const int g = g0 + k;
+    if (INTERIOR) {
+      const double nu = (MODEL == CF_EZ_PHYSICAL_D && d.nu_grid) ? d.nu_grid[g] : -1.0;
+      dh[k] = c_over_H0 * rsqrt(e2_of_z<MODEL, FDE>(d, wc, (double)g * d.step, nu));
+    } else {
+      dh[k] = g < G ? dh_of_node<MODEL, FDE>(d, wc, c_over_H0, g) : 0.0;
+    }
+  }
+  // the node before the chunk: the neighbouring lane's last node; lane 0 of a wave re-evaluates it
+  double prev = __shfl_up(dh[CH - 1], 1, CF_WAVE);
+  if (lane == 0 && g0 > 0 && g0 <= G) prev = dh_of_node<MODEL, FDE>(d, wc, c_over_H0, g0 - 1);
+  double run = 0.0;
+  double z_prev = (double)(g0 - 1) * d.step;
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const int g = g0 + k;
+    if (INTERIOR) {
+      const double z_g = (double)g * d.step;
+      run += (prev + dh[k]) / 2 * (z_g - z_prev);
+      z_prev = z_g;
+    } else if (g >= 1 && g < G) {
+      const double dz = grid_z(g, G, d.step, d.z_max) - grid_z(g - 1, G, d.step, d.z_max);
+      run += (prev + dh[k]) / 2 * dz;
+    }
+    loc[k] = run;
+    prev = dh[k];
+  }
+  return run;
+}
+
 template <int MODEL, int FDE, int CH>
 __device__ __forceinline__ void build_distance_table_regs(const cf_dev_desc& d, const WalkerCosmo& wc, d2* tab,
                                                           double* wave_tot) {
@@ -256,24 +294,11 @@ __device__ __forceinline__ void build_distance_table_regs(const cf_dev_desc& d, 
   const int g0 = tid * CH;
   const int base = g0 + tid;  // skewed position of node g0
   const double c_over_H0 = wc.c / wc.H0;
-  double dh[CH];
-#pragma unroll
-  for (int k = 0; k < CH; ++k)
-    dh[k] = g0 + k < G ? dh_of_node<MODEL, FDE>(d, wc, c_over_H0, g0 + k) : 0.0;
-  double prev = __shfl_up(dh[CH - 1], 1, CF_WAVE);
-  if (lane == 0 && g0 > 0 && g0 <= G) prev = dh_of_node<MODEL, FDE>(d, wc, c_over_H0, g0 - 1);
-  double loc[CH];
-  double run = 0.0;
-#pragma unroll
-  for (int k = 0; k < CH; ++k) {
-    const int g = g0 + k;
-    if (g >= 1 && g < G) {
-      const double dz = grid_z(g, G, d.step, d.z_max) - grid_z(g - 1, G, d.step, d.z_max);
-      run += (prev + dh[k]) / 2 * dz;
-    }
-    loc[k] = run;
-    prev = dh[k];
-  }
+  double dh[CH], loc[CH];
+  const int wave_first = (tid - lane) * CH, wave_last = wave_first + 64 * CH - 1;
+  const double run = (wave_first > 0 && wave_last < G - 1)
+                         ? chunk_eval<MODEL, FDE, CH, true>(d, wc, c_over_H0, g0, lane, dh, loc)
+                         : chunk_eval<MODEL, FDE, CH, false>(d, wc, c_over_H0, g0, lane, dh, loc);
   const double incl = wave_inclusive_scan(run);
   if (lane == 63) wave_tot[wave] = incl;
   __syncthreads();

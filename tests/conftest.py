@@ -18,8 +18,12 @@ def pytest_configure(config):
 
 
 def load_pkg():
-    """The package directory has a hyphen in its name, so it is imported through importlib."""
-    return importlib.import_module(PKG_NAME)
+    """The package directory has a hyphen in its name, so it is imported through importlib.
+    A fresh checkout has no built library (it is git-ignored): compile it once, as __graft_entry__.build() does."""
+    pkg = importlib.import_module(PKG_NAME)
+    if not os.path.exists(pkg._lib.LIB_PATH):
+        pkg.build()
+    return pkg
 
 
 def golden(name):
