@@ -77,6 +77,13 @@ def main():
             dist.init_process_group(backend=backend)
 
     pkg = importlib.import_module("cosmology-model-fit_amd")
+    if not os.path.exists(pkg._lib.LIB_PATH):  # normally built by __graft_entry__.build(); never fall back to anything else
+        if local_rank == 0:
+            pkg.build()
+        for _ in range(600):
+            if os.path.exists(pkg._lib.LIB_PATH):
+                break
+            time.sleep(0.5)
     sn = pkg.sn_pantheon
     Wl = args.walkers_per_gpu
     W_total = Wl * world
