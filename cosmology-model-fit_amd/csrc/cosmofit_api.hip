@@ -41,11 +41,11 @@ static walker_fn pick_walker(int model, int fde) {
 template <int KS, int TC>
 __global__ void trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* theta, int64_t W, const double* delta,
                                  d2* ypk, const double* chi2_extra, double* out, int out_kind,
-                                 unsigned long long* nonfinite);
+                                 unsigned long long* nonfinite, double* chi2_sn_out);
 #define CF_DECLARE_TRSM(KS, TC)                                                                                       \
   extern template __global__ void trsm_chi2_kernel<KS, TC>(cf_dev_desc, cf_dev_pack, const double*, int64_t,          \
                                                            const double*, d2*, const double*, double*, int,           \
-                                                           unsigned long long*);
+                                                           unsigned long long*, double*);
 CF_DECLARE_TRSM(1, 4)
 CF_DECLARE_TRSM(2, 4)
 CF_DECLARE_TRSM(4, 4)
@@ -54,7 +54,8 @@ extern "C" __global__ void inv_gemm_chi2_kernel(cf_dev_invpack pk, int n_pad, co
                                                 double* partial);
 extern "C" __global__ void finalize_partials_kernel(cf_dev_desc d, const double* theta, int64_t W, int64_t w_pad,
                                                     const double* partial, int n_rowblocks, const double* chi2_extra,
-                                                    double* out, int out_kind, unsigned long long* nonfinite);
+                                                    double* out, int out_kind, unsigned long long* nonfinite,
+                                                    double* chi2_sn_out);
 extern "C" __global__ void finalize_kernel(cf_dev_desc d, const double* theta, int64_t W, const double* chi2_extra,
                                            double* out, int out_kind, unsigned long long* nonfinite);
 extern "C" __global__ void interp_kernel(const double* xq, int64_t nq, const double* x, const double* y,
@@ -545,7 +546,7 @@ extern "C" int cf_last_kernel_ms(cf_handle* h, float t[2]) {
 template <int KS, int TC>
 static int launch_trsm_t(const cf_dev_desc& d, const cf_dev_pack& pk, const double* d_theta, int64_t W,
                          const double* delta, d2* ypk, const double* chi2_extra, double* d_out, int out_kind,
-                         unsigned long long* nf, hipStream_t st) {
+                         unsigned long long* nf, hipStream_t st, double* chi2_sn_out) {
   const size_t lds = (size_t)KS * (CF_BLOCK_ROWS / 8 * 64) * sizeof(d2);
   static thread_local int attr_device = -1;  // > 64 KB of dynamic LDS must be allowed once per device
   int dev = 0;
@@ -556,18 +557,18 @@ static int launch_trsm_t(const cf_dev_desc& d, const cf_dev_pack& pk, const doub
   }
   const unsigned panels = (unsigned)((W + 15) / 16);
   hipLaunchKernelGGL((trsm_chi2_kernel<KS, TC>), dim3(panels), dim3(64 * KS * TC), lds, st, d, pk, d_theta, W, delta, ypk,
-                     chi2_extra, d_out, out_kind, nf);
+                     chi2_extra, d_out, out_kind, nf, chi2_sn_out);
   return 0;
 }
 
 static int launch_trsm(const cf_dev_desc& d, const cf_dev_pack& pk, const double* d_theta, int64_t W,
                        const double* delta, d2* ypk, const double* chi2_extra, double* d_out, int out_kind,
-                       unsigned long long* nf, hipStream_t st) {
+                       unsigned long long* nf, hipStream_t st, double* chi2_sn_out = nullptr) {
   switch (pk.ksplit * 16 + pk.tclasses) {
-    case 1 * 16 + 4: return launch_trsm_t<1, 4>(d, pk, d_theta, W, delta, ypk, chi2_extra, d_out, out_kind, nf, st);
-    case 2 * 16 + 4: return launch_trsm_t<2, 4>(d, pk, d_theta, W, delta, ypk, chi2_extra, d_out, out_kind, nf, st);
-    case 4 * 16 + 4: return launch_trsm_t<4, 4>(d, pk, d_theta, W, delta, ypk, chi2_extra, d_out, out_kind, nf, st);
-    case 2 * 16 + 8: return launch_trsm_t<2, 8>(d, pk, d_theta, W, delta, ypk, chi2_extra, d_out, out_kind, nf, st);
+    case 1 * 16 + 4: return launch_trsm_t<1, 4>(d, pk, d_theta, W, delta, ypk, chi2_extra, d_out, out_kind, nf, st, chi2_sn_out);
+    case 2 * 16 + 4: return launch_trsm_t<2, 4>(d, pk, d_theta, W, delta, ypk, chi2_extra, d_out, out_kind, nf, st, chi2_sn_out);
+    case 4 * 16 + 4: return launch_trsm_t<4, 4>(d, pk, d_theta, W, delta, ypk, chi2_extra, d_out, out_kind, nf, st, chi2_sn_out);
+    case 2 * 16 + 8: return launch_trsm_t<2, 8>(d, pk, d_theta, W, delta, ypk, chi2_extra, d_out, out_kind, nf, st, chi2_sn_out);
   }
   return fail(CF_ERR_INVALID, "bad solve shape");
 }
@@ -575,7 +576,8 @@ static int launch_trsm(const cf_dev_desc& d, const cf_dev_pack& pk, const double
 // Launch the path on `st`: per-walker kernel (distance table, residuals, BAO / CMB blocks), then the
 // blocked solve + chi^2 + epilogue (or the bare epilogue for likelihoods without an SN block).
 static int launch_path(cf_handle* h, const double* d_theta, int64_t W, double* d_out, int out_kind, hipStream_t st,
-                       double* dm_out, double* mucorr_out, double* blocks_out, double* bao_out) {
+                       double* dm_out, double* mucorr_out, double* blocks_out, double* bao_out,
+                       double* chi2_sn_out = nullptr) {
   const cf_dev_desc& d = h->d;
   unsigned long long* nf = h->nonfinite.as<unsigned long long>();
   hipEvent_t* ev = h->timing_slots ? &h->ev[3 * (h->timed_calls % h->timing_slots)] : nullptr;
@@ -595,9 +597,11 @@ static int launch_path(cf_handle* h, const double* d_theta, int64_t W, double* d
     hipLaunchKernelGGL(inv_gemm_chi2_kernel, dim3((unsigned)h->ipack.dev.n_rowblocks, panels), dim3(256), 0, st, h->ipack.dev,
                        (int)d.n_pad, h->delta.as<const double>(), w_pad, h->partial.as<double>());
     hipLaunchKernelGGL(finalize_partials_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, d, d_theta, W, w_pad,
-                       h->partial.as<const double>(), (int)h->ipack.dev.n_rowblocks, (const double*)extra, d_out, out_kind, nf);
+                       h->partial.as<const double>(), (int)h->ipack.dev.n_rowblocks, (const double*)extra, d_out, out_kind, nf,
+                       chi2_sn_out);
   } else if (d.n_sn > 0) {
-    int rc = launch_trsm(d, h->pack.dev, d_theta, W, h->delta.as<const double>(), h->ypk.as<d2>(), extra, d_out, out_kind, nf, st);
+    int rc = launch_trsm(d, h->pack.dev, d_theta, W, h->delta.as<const double>(), h->ypk.as<d2>(), extra, d_out, out_kind, nf, st,
+                         chi2_sn_out);
     if (rc) return rc;
   } else {
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, d, d_theta, W,
@@ -659,7 +663,9 @@ extern "C" int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, doubl
   int rc;
   if ((rc = ensure_workspace(h, W))) return rc;
   const int64_t n = h->d.n_sn, n_pad = h->d.n_pad, nb = h->d.n_bao;
-  DevBuf dm, mc, blk, bt;
+  DevBuf dm, mc, blk, bt, snb;
+  if (snb.ensure((size_t)W * 8)) return CF_ERR_HIP;
+  HIP_TRY(hipMemsetAsync(snb.p, 0, (size_t)W * 8, h->stream));
   // the SN accessor path (reference-order mu_corr / mu_theory) is selected by a non-null dm / mu_corr buffer
   if (n > 0 && dm.ensure((size_t)W * n * 8)) return CF_ERR_HIP;
   if (n > 0 && mu_corr && mc.ensure((size_t)W * n * 8)) return CF_ERR_HIP;
@@ -668,7 +674,7 @@ extern "C" int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, doubl
   if (nb > 0 && bt.ensure((size_t)W * nb * 8)) return CF_ERR_HIP;
   HIP_TRY(hipMemcpyAsync(h->theta.p, theta, (size_t)W * h->d.ndim * 8, hipMemcpyHostToDevice, h->stream));
   if ((rc = launch_path(h, h->theta.as<const double>(), W, h->out.as<double>(), CF_OUT_CHI2, h->stream,
-                        dm.as<double>(), mc.as<double>(), blk.as<double>(), bt.as<double>())))
+                        dm.as<double>(), mc.as<double>(), blk.as<double>(), bt.as<double>(), snb.as<double>())))
     return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (dm_obs) HIP_TRY(hipMemcpy(dm_obs, dm.p, (size_t)W * n * 8, hipMemcpyDeviceToHost));
@@ -678,17 +684,12 @@ extern "C" int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, doubl
                         hipMemcpyDeviceToHost));
   if (bao_theory) HIP_TRY(hipMemcpy(bao_theory, bt.p, (size_t)W * nb * 8, hipMemcpyDeviceToHost));
   if (chi2_blocks) {
-    std::vector<double> tot((size_t)W), b6((size_t)W * 6);
-    HIP_TRY(hipMemcpy(tot.data(), h->out.p, (size_t)W * 8, hipMemcpyDeviceToHost));
+    std::vector<double> sn((size_t)W), b6((size_t)W * 6);
+    HIP_TRY(hipMemcpy(sn.data(), snb.p, (size_t)W * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(b6.data(), blk.p, (size_t)W * 6 * 8, hipMemcpyDeviceToHost));
     for (int64_t w = 0; w < W; ++w) {
-      double gauss = 0.0;
-      for (int g = 0; g < h->d.n_chi2_gauss; ++g) {
-        double diff = theta[w * h->d.ndim + h->d.chi2_gauss_idx[g]] - h->d.chi2_gauss_mean[g];
-        gauss += diff * diff / (h->d.chi2_gauss_sigma[g] * h->d.chi2_gauss_sigma[g]);
-      }
-      // sn = total - bao - cmb - cc - Gaussian terms; then bao, cmb, the CMB distance vector, cc
-      chi2_blocks[7 * w + 0] = tot[w] - b6[6 * w + 0] - b6[6 * w + 1] - b6[6 * w + 5] - gauss;
+      // sn (written by the solve kernel before the other blocks are added), bao, cmb, the CMB distance vector, cc
+      chi2_blocks[7 * w + 0] = sn[w];
       chi2_blocks[7 * w + 1] = b6[6 * w + 0];
       chi2_blocks[7 * w + 2] = b6[6 * w + 1];
       chi2_blocks[7 * w + 3] = b6[6 * w + 2];
@@ -764,7 +765,7 @@ extern "C" int cf_solve_triangular(const double* L, int64_t n, int64_t ld, const
   d.n_sn = (int32_t)n;
   d.n_pad = (int32_t)n_pad;
   if ((rc = launch_trsm(d, pf.dev, dth.as<const double>(), nrhs, delta.as<const double>(), ypk.as<d2>(), nullptr,
-                        dout.as<double>(), (int)CF_OUT_CHI2, nf.as<unsigned long long>(), (hipStream_t)0)))
+                        dout.as<double>(), (int)CF_OUT_CHI2, nf.as<unsigned long long>(), (hipStream_t)0, nullptr)))
     return rc;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, dout.p, (size_t)nrhs * 8, hipMemcpyDeviceToHost));

@@ -802,7 +802,7 @@ template <int KS, int TC>
 __global__ void __launch_bounds__(64 * KS * TC)
 trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* __restrict__ theta, int64_t W,
                  const double* __restrict__ delta, d2* __restrict__ ypk, const double* __restrict__ chi2_extra,
-                 double* __restrict__ out, int out_kind, unsigned long long* nonfinite) {
+                 double* __restrict__ out, int out_kind, unsigned long long* nonfinite, double* __restrict__ chi2_sn_out) {
   constexpr int NW = TC * KS;                  // waves per workgroup
   constexpr int NTU = CF_BLOCK_TILES / TC;     // tiles per wave in the update phase
   constexpr int NTD = CF_BLOCK_TILES / NW;     // tiles per wave in the diagonal phase
@@ -938,6 +938,7 @@ trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* __restrict__ theta
     double c2 = 0.0;
 #pragma unroll
     for (int k = 0; k < NW; ++k) c2 += chi_part[k][tid];
+    if (chi2_sn_out) chi2_sn_out[w] = c2;  // the SN block alone (cf_eval_parts)
     if (chi2_extra) c2 += chi2_extra[w];
     out[w] = finalize_value(d, theta + w * d.ndim, c2, out_kind, nonfinite);
   }
@@ -945,7 +946,7 @@ trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* __restrict__ theta
 
 #define CF_INSTANTIATE_TRSM(KS, TC)                                                                                  \
   template __global__ void trsm_chi2_kernel<KS, TC>(cf_dev_desc, cf_dev_pack, const double*, int64_t, const double*, \
-                                                    d2*, const double*, double*, int, unsigned long long*);
+                                                    d2*, const double*, double*, int, unsigned long long*, double*);
 CF_INSTANTIATE_TRSM(1, 4)
 CF_INSTANTIATE_TRSM(2, 4)
 CF_INSTANTIATE_TRSM(4, 4)
@@ -1025,11 +1026,12 @@ inv_gemm_chi2_kernel(cf_dev_invpack pk, int n_pad, const double* __restrict__ de
 extern "C" __global__ void finalize_partials_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, int64_t w_pad,
                                                     const double* __restrict__ partial, int n_rowblocks,
                                                     const double* __restrict__ chi2_extra, double* __restrict__ out,
-                                                    int out_kind, unsigned long long* nonfinite) {
+                                                    int out_kind, unsigned long long* nonfinite, double* __restrict__ chi2_sn_out) {
   const int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (w >= W) return;
   double c2 = 0.0;
   for (int rb = 0; rb < n_rowblocks; ++rb) c2 += partial[(int64_t)rb * w_pad + w];
+  if (chi2_sn_out) chi2_sn_out[w] = c2;
   if (chi2_extra) c2 += chi2_extra[w];
   out[w] = finalize_value(d, theta + w * d.ndim, c2, out_kind, nonfinite);
 }

@@ -90,7 +90,7 @@ def test_config3_desi_cmb_des5y_golden(des5y):
     np.testing.assert_allclose(lk.chi_squared(g["thetas"]), g["chi2"], rtol=RTOL)
     np.testing.assert_allclose(lk.log_likelihood(g["thetas"]), g["logl"], rtol=RTOL)
     parts = lk.engine.parts(g["thetas"])
-    np.testing.assert_allclose(parts["chi2_blocks"], g["chi2_parts"], rtol=1e-9)
+    np.testing.assert_allclose(parts["chi2_blocks"], g["chi2_parts"], rtol=RTOL)
     np.testing.assert_allclose(parts["bao_theory"][:4], g["theory"], rtol=1e-12)
     np.testing.assert_allclose(parts["cmb_vector"][:4], g["cmb_dist"], rtol=1e-12)
 
