@@ -106,7 +106,7 @@ class DesiCmbDes5y(_Base):
     PCHIP D_H and F_AP, Planck+ACT (R, l_A, wb); dark energy = Lambda as shipped (:46)."""
 
     def __init__(self, z_cmb, z_hel, mu_values, cov_sn, bao_z, bao_val, bao_qty, bao_inv_cov, *, chol=None, comp=None,
-                 device=0):
+                 device=0, latency_mode=False):
         comp = cmb_data.PLANCK_ACT if comp is None else comp
         if chol is None:
             chol = cho_factor(cov_sn, lower=True)[0]  # bao/desi_cmb_des5y.py:17
@@ -117,7 +117,8 @@ class DesiCmbDes5y(_Base):
             sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=mu_values, chol=chol, z_turn=0.10563),
             bao=dict(z=bao_z, val=bao_val, qty=bao_qty, inv_cov=bao_inv_cov, rd_fit=comp["rd_fit"]),
             cmb=dict(mode=comp["cmb_mode"], prior=comp["cmb_prior"], inv_cov=comp["cmb_inv_cov"], zstar_fit=comp["zstar_fit"]),
-            physical=_physical(comp), device=device)
+            physical=_physical(comp), device=device,
+            solve_mode=L.CF_SOLVE_INVERSE_GEMM if latency_mode else L.CF_SOLVE_BLOCKED_TRSM)
 
 
 class DesiDes5yBbnThetaStar(_Base):

@@ -110,6 +110,15 @@ def test_config3_full_batch_vs_c_oracle(gpu, des5y):
     np.testing.assert_array_equal(lk.log_likelihood(theta[:777]), got[:777])  # batch-size invariance
 
 
+def test_config3_latency_mode_agrees_with_blocked_solve(gpu, des5y):
+    g, lk = des5y
+    lat = gpu.likelihoods.DesiCmbDes5y(g["z_cmb"], g["z_hel"], g["obs"], None, *_bao_args(g), chol=g["chol"], latency_mode=True)
+    np.testing.assert_allclose(lat.log_likelihood(g["thetas"]), g["logl"], rtol=RTOL)
+    np.testing.assert_allclose(lat.log_likelihood(g["thetas"]), lk.log_likelihood(g["thetas"]), rtol=1e-12)
+    np.testing.assert_allclose(lat.engine.parts(g["thetas"][:4])["chi2_blocks"], g["chi2_parts"][:4], rtol=RTOL)
+    lat.engine.close()
+
+
 def test_config5_desi_des5y_bbn_theta_star_golden(gpu):
     g = dict(golden("bao_desi_des5y_bbn_theta_star"))
     chol = _chol_of(g)
