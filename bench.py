@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--n-sn", type=int, default=1701)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-seconds of work of the cpu_baseline sample (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--solve", default="default", choices=["default", "blocked", "inverse"],
+                    help="solve kernel: blocked TRSM or the inverse-GEMM form (default: the library's choice)")
     ap.add_argument("--workload", default="pantheon", choices=["pantheon", "desi_cmb_des5y"],
                     help="pantheon = BASELINE configs[1] (the headline, default); desi_cmb_des5y = configs[2] shape "
                          "(N=1820 SN + 14 BAO + Planck/ACT CMB, physical-density E(z)) on the committed fixture data")
@@ -88,6 +90,7 @@ def main():
     Wl = args.walkers_per_gpu
     W_total = Wl * world
 
+    solve_kw = {} if args.solve == "default" else {"latency_mode": args.solve == "inverse"}
     if args.workload == "desi_cmb_des5y":
         # joint likelihood of bao/desi_cmb_des5y.py: real DES-Dovekie redshifts + real DESI FS+Lya BAO data from the
         # golden fixture (tests/golden/bao_desi_cmb_des5y.npz), seeded synthetic SN covariance
@@ -96,13 +99,13 @@ def main():
         A = 0.01 * rng.standard_normal((g["sigma"].size, 40))
         chol = np.linalg.cholesky(np.diag(g["sigma"] ** 2) + A @ A.T)
         lk = pkg.likelihoods.DesiCmbDes5y(g["z_cmb"], g["z_hel"], g["obs"], None, g["bao_z"], g["bao_val"], g["bao_qty"],
-                                          g["bao_inv_cov"], chol=chol, device=local_rank)
+                                          g["bao_inv_cov"], chol=chol, device=local_rank, **solve_kw)
         box = np.array([(-0.5, 0.5), (60.0, 75.0), (0.010, 0.030), (0.01, 0.25), (-4.5, 4.5)])  # bao/desi_cmb_des5y.py:156-161
         args.n_sn, ndim, kind = int(g["z_cmb"].size), 5, pkg.CF_OUT_LOGL
         args.no_cpu_baseline = True
     else:
         syn = pkg.synthetic.pantheon_like(n_sn=args.n_sn, seed=0)
-        lk = sn.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"], device=local_rank)
+        lk = sn.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"], device=local_rank, **solve_kw)
         box, ndim, kind = sn.bounds, 4, pkg.CF_OUT_LOGP
     eng = lk.engine
 

@@ -243,6 +243,11 @@ static void cf_invert_lower(const double* L, int64_t n, int64_t ld, int64_t n_pa
   }
 }
 
+// Column of X (= row of Delta) that lane group kq feeds in K-step h (0 / 1) of K-step pair s2: the two K-steps
+// of a pair take ADJACENT columns per lane group, so that the matching B fragment {Delta[w][c], Delta[w][c+1]}
+// is one aligned 16-byte load from the row-major residual vector.
+static inline int64_t cf_inv_col(int64_t s2, int kq, int h) { return 8 * s2 + 2 * kq + h; }
+
 static void cf_pack_inverse(const double* L, int64_t n, int64_t ld, cf_host_invpack& out) {
   const int64_t n_pad = (n + 15) / 16 * 16, T = n_pad / 16;
   const int RB = (int)((T + 3) / 4);
@@ -268,18 +273,18 @@ static void cf_pack_inverse(const double* L, int64_t n, int64_t ld, cf_host_invp
         for (int j = 0; j < 4; ++j)
           for (int lane = 0; lane < 64; ++lane) {
             const int64_t row = 64 * rb + 16 * j + (lane & 15);
-            const int64_t c0 = 8 * (g * nq + q) + (lane >> 4);
             if (row >= n_pad) continue;  // missing tile of the last row block stays zero
+            const int64_t c0 = cf_inv_col(g * nq + q, lane >> 4, 0), c1 = cf_inv_col(g * nq + q, lane >> 4, 1);
             cf_d2& f = st[(q * 4 + j) * 64 + lane];
             f.x = c0 <= row ? X[(size_t)row * n_pad + c0] : 0.0;
-            f.y = c0 + 4 <= row ? X[(size_t)row * n_pad + c0 + 4] : 0.0;
+            f.y = c1 <= row ? X[(size_t)row * n_pad + c1] : 0.0;
           }
     }
 }
 
 static double cf_invpack_replay_host(const cf_host_invpack& pk, const double* b_in) {
-  const int64_t n_pad = pk.n_pad;
-  std::vector<double> b((size_t)n_pad + 64, 0.0);
+  const int64_t n_ld = (int64_t)pk.n_rowblocks * 64;
+  std::vector<double> b((size_t)n_ld + 64, 0.0);
   for (int64_t i = 0; i < pk.n; ++i) b[i] = b_in[i];
   double chi = 0.0;
   for (int rb = 0; rb < pk.n_rowblocks; ++rb) {
@@ -290,9 +295,8 @@ static double cf_invpack_replay_host(const cf_host_invpack& pk, const double* b_
       for (int64_t q = 0; q < nq; ++q)
         for (int j = 0; j < 4; ++j)
           for (int lane = 0; lane < 64; ++lane) {
-            const int64_t c0 = 8 * (g * nq + q) + (lane >> 4);
             const cf_d2& f = st[(q * 4 + j) * 64 + lane];
-            y[16 * j + (lane & 15)] += f.x * b[c0] + f.y * b[c0 + 4];
+            y[16 * j + (lane & 15)] += f.x * b[cf_inv_col(g * nq + q, lane >> 4, 0)] + f.y * b[cf_inv_col(g * nq + q, lane >> 4, 1)];
           }
     }
     for (int i = 0; i < 64; ++i) chi += y[i] * y[i];

@@ -21,6 +21,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 // the solve kernel's prefetch reads up to 4 K-step pairs (4 KiB) past the end of a panel's Y range
 #define CF_YPK_SLACK 8192
+#define CF_DELTA_SLACK 4096  // the inverse-GEMM pipeline prefetches a few K-step pairs past the last residual row
 
 template <int MODEL, int FDE>
 __global__ void walker_kernel(cf_dev_desc d, const double* theta, int64_t W, double* delta, double* chi2_extra,
@@ -50,8 +51,15 @@ CF_DECLARE_TRSM(1, 4)
 CF_DECLARE_TRSM(2, 4)
 CF_DECLARE_TRSM(4, 4)
 CF_DECLARE_TRSM(2, 8)
-extern "C" __global__ void inv_gemm_chi2_kernel(cf_dev_invpack pk, int n_pad, const double* delta, int64_t w_pad,
-                                                double* partial);
+template <int NP, int PF>
+__global__ void tri_gemm_chi2_kernel(cf_dev_invpack pk, int n_ld, const double* delta, int64_t w_pad, double* partial);
+#define CF_DECLARE_TRIGEMM(NP, PF) \
+  extern template __global__ void tri_gemm_chi2_kernel<NP, PF>(cf_dev_invpack, int, const double*, int64_t, double*);
+CF_DECLARE_TRIGEMM(1, 2)
+CF_DECLARE_TRIGEMM(1, 4)
+CF_DECLARE_TRIGEMM(2, 2)
+CF_DECLARE_TRIGEMM(2, 3)
+CF_DECLARE_TRIGEMM(2, 4)
 extern "C" __global__ void finalize_partials_kernel(cf_dev_desc d, const double* theta, int64_t W, int64_t w_pad,
                                                     const double* partial, int n_rowblocks, const double* chi2_extra,
                                                     double* out, int out_kind, unsigned long long* nonfinite,
@@ -61,7 +69,7 @@ extern "C" __global__ void finalize_kernel(cf_dev_desc d, const double* theta, i
 extern "C" __global__ void interp_kernel(const double* xq, int64_t nq, const double* x, const double* y,
                                          const double* yp, int64_t n, double* out, int mode);
 extern "C" __global__ void log10_selftest_kernel(const double* x, int64_t n, double* out);
-extern "C" __global__ void pad_rhs_kernel(const double* b, int64_t nrhs, int64_t n, int64_t n_pad, double* delta);
+extern "C" __global__ void pad_rhs_kernel(const double* b, int64_t nrhs, int64_t n, int64_t n_ld, double* delta);
 
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -217,11 +225,11 @@ static int upload_vec(DevBuf& b, const double* src, int64_t n) {
 }
 
 static int ensure_workspace(cf_handle* h, int64_t W) {
-  const int64_t w_pad = (W + 15) / 16 * 16;
+  const int64_t w_pad = (W + 31) / 32 * 32;  // whole panels of the widest solve kernel (2 x 16 walkers)
   if (w_pad <= h->max_walkers) return 0;
   // earlier evaluations may still be running on a caller's stream and use the buffers about to be replaced
   HIP_TRY(hipDeviceSynchronize());
-  const int64_t n_pad = h->d.n_pad > 0 ? h->d.n_pad : 16;
+  const int64_t n_pad = h->d.n_pad > 0 ? h->d.n_pad : 16, n_ld = h->d.n_ld > 0 ? h->d.n_ld : 64;
   if (h->theta.ensure((size_t)w_pad * (h->d.ndim > 0 ? h->d.ndim : 1) * 8)) return CF_ERR_HIP;
   if (h->out.ensure((size_t)w_pad * 8)) return CF_ERR_HIP;
   if (h->stage_in.ensure((size_t)w_pad * (h->d.ndim > 0 ? h->d.ndim : 1) * 8)) return CF_ERR_HIP;
@@ -231,10 +239,10 @@ static int ensure_workspace(cf_handle* h, int64_t W) {
     if (h->partial.ensure((size_t)w_pad * h->ipack.dev.n_rowblocks * 8)) return CF_ERR_HIP;
   }
   if (h->d.n_sn > 0) {
-    if (h->delta.ensure((size_t)w_pad * n_pad * 8)) return CF_ERR_HIP;
+    if (h->delta.ensure((size_t)w_pad * n_ld * 8 + CF_DELTA_SLACK)) return CF_ERR_HIP;
     if (h->ypk.ensure((size_t)w_pad * n_pad * 8 + CF_YPK_SLACK)) return CF_ERR_HIP;
     // columns of a partly filled last panel must hold finite numbers
-    HIP_TRY(hipMemsetAsync(h->delta.p, 0, (size_t)w_pad * n_pad * 8, h->stream));
+    HIP_TRY(hipMemsetAsync(h->delta.p, 0, (size_t)w_pad * n_ld * 8 + CF_DELTA_SLACK, h->stream));
     HIP_TRY(hipMemsetAsync(h->ypk.p, 0, (size_t)w_pad * n_pad * 8 + CF_YPK_SLACK, h->stream));
     // the evaluation may be launched on a caller's stream: the fills must have landed before it starts
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -331,6 +339,7 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
   }
   d.n_sn = (int32_t)c->n_sn;
   d.n_pad = (int32_t)((c->n_sn + 15) / 16 * 16);
+  d.n_ld = (int32_t)((c->n_sn + 63) / 64 * 64);
   // a velocity step exists if its slot is a parameter or a non-zero constant
   d.has_vstep = c->param[CF_P_V].idx >= 0 || c->param[CF_P_V].fixed != 0.0;
   d.or_h2 = c->or_h2;
@@ -573,6 +582,35 @@ static int launch_trsm(const cf_dev_desc& d, const cf_dev_pack& pk, const double
   return fail(CF_ERR_INVALID, "bad solve shape");
 }
 
+// Inverse-GEMM solve: panels of 16*NP walkers per workgroup.  NP = 2 halves the factor traffic per flop and is
+// the throughput shape; NP = 1 keeps the latency of small batches short.  CF_GEMM_SHAPE=<NP>x<PF> overrides (tuning).
+template <int NP, int PF>
+static int launch_tri_gemm_t(const cf_dev_invpack& pk, int n_ld, const double* delta, int64_t W, int64_t w_pad, double* partial,
+                             hipStream_t st) {
+  const unsigned panels = (unsigned)((W + 16 * NP - 1) / (16 * NP));
+  hipLaunchKernelGGL((tri_gemm_chi2_kernel<NP, PF>), dim3(panels, (unsigned)pk.n_rowblocks), dim3(256), 0, st, pk,
+                     n_ld, delta, w_pad, partial);
+  return 0;
+}
+
+static int launch_tri_gemm(const cf_dev_invpack& pk, int n_ld, const double* delta, int64_t W, int64_t w_pad, double* partial,
+                           hipStream_t st) {
+  static const int shape = [] {
+    const char* e = getenv("CF_GEMM_SHAPE");
+    return (e && strlen(e) == 3 && e[1] == 'x') ? (e[0] - '0') * 16 + (e[2] - '0') : 0;
+  }();
+  int np = W > 256 ? 2 : 1, pf = 4;
+  if (shape) { np = shape / 16; pf = shape % 16; }
+  switch (np * 16 + pf) {
+    case 1 * 16 + 2: return launch_tri_gemm_t<1, 2>(pk, n_ld, delta, W, w_pad, partial, st);
+    case 1 * 16 + 4: return launch_tri_gemm_t<1, 4>(pk, n_ld, delta, W, w_pad, partial, st);
+    case 2 * 16 + 2: return launch_tri_gemm_t<2, 2>(pk, n_ld, delta, W, w_pad, partial, st);
+    case 2 * 16 + 3: return launch_tri_gemm_t<2, 3>(pk, n_ld, delta, W, w_pad, partial, st);
+    case 2 * 16 + 4: return launch_tri_gemm_t<2, 4>(pk, n_ld, delta, W, w_pad, partial, st);
+  }
+  return fail(CF_ERR_INVALID, "bad CF_GEMM_SHAPE");
+}
+
 // Launch the path on `st`: per-walker kernel (distance table, residuals, BAO / CMB blocks), then the
 // blocked solve + chi^2 + epilogue (or the bare epilogue for likelihoods without an SN block).
 static int launch_path(cf_handle* h, const double* d_theta, int64_t W, double* d_out, int out_kind, hipStream_t st,
@@ -593,9 +631,8 @@ static int launch_path(cf_handle* h, const double* d_theta, int64_t W, double* d
   if (ev) HIP_TRY(hipEventRecord(ev[1], st));
   if (d.n_sn > 0 && h->solve_mode == CF_SOLVE_INVERSE_GEMM) {
     const int64_t w_pad = h->max_walkers;
-    const unsigned panels = (unsigned)((W + 15) / 16);
-    hipLaunchKernelGGL(inv_gemm_chi2_kernel, dim3((unsigned)h->ipack.dev.n_rowblocks, panels), dim3(256), 0, st, h->ipack.dev,
-                       (int)d.n_pad, h->delta.as<const double>(), w_pad, h->partial.as<double>());
+    int rc = launch_tri_gemm(h->ipack.dev, (int)d.n_ld, h->delta.as<const double>(), W, w_pad, h->partial.as<double>(), st);
+    if (rc) return rc;
     hipLaunchKernelGGL(finalize_partials_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, d, d_theta, W, w_pad,
                        h->partial.as<const double>(), (int)h->ipack.dev.n_rowblocks, (const double*)extra, d_out, out_kind, nf,
                        chi2_sn_out);
@@ -662,7 +699,7 @@ extern "C" int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, doubl
   HIP_TRY(hipSetDevice(h->device));
   int rc;
   if ((rc = ensure_workspace(h, W))) return rc;
-  const int64_t n = h->d.n_sn, n_pad = h->d.n_pad, nb = h->d.n_bao;
+  const int64_t n = h->d.n_sn, n_ld = h->d.n_ld, nb = h->d.n_bao;
   DevBuf dm, mc, blk, bt, snb;
   if (snb.ensure((size_t)W * 8)) return CF_ERR_HIP;
   HIP_TRY(hipMemsetAsync(snb.p, 0, (size_t)W * 8, h->stream));
@@ -680,7 +717,7 @@ extern "C" int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, doubl
   if (dm_obs) HIP_TRY(hipMemcpy(dm_obs, dm.p, (size_t)W * n * 8, hipMemcpyDeviceToHost));
   if (mu_corr) HIP_TRY(hipMemcpy(mu_corr, mc.p, (size_t)W * n * 8, hipMemcpyDeviceToHost));
   if (delta && n > 0)
-    HIP_TRY(hipMemcpy2D(delta, (size_t)n * 8, h->delta.p, (size_t)n_pad * 8, (size_t)n * 8, (size_t)W,
+    HIP_TRY(hipMemcpy2D(delta, (size_t)n * 8, h->delta.p, (size_t)n_ld * 8, (size_t)n * 8, (size_t)W,
                         hipMemcpyDeviceToHost));
   if (bao_theory) HIP_TRY(hipMemcpy(bao_theory, bt.p, (size_t)W * nb * 8, hipMemcpyDeviceToHost));
   if (chi2_blocks) {
@@ -752,18 +789,19 @@ extern "C" int cf_solve_triangular(const double* L, int64_t n, int64_t ld, const
   PackedFactor pf;
   int rc;
   if ((rc = pf.upload(hp))) return rc;
-  const int64_t w_pad = (nrhs + 15) / 16 * 16, n_pad = hp.n_pad;
+  const int64_t w_pad = (nrhs + 15) / 16 * 16, n_pad = hp.n_pad, n_ld = (n + 63) / 64 * 64;
   DevBuf db, delta, ypk, dout, nf, dth;
-  if (db.ensure((size_t)nrhs * n * 8) || delta.ensure((size_t)w_pad * n_pad * 8) || ypk.ensure((size_t)w_pad * n_pad * 8 + CF_YPK_SLACK) ||
+  if (db.ensure((size_t)nrhs * n * 8) || delta.ensure((size_t)w_pad * n_ld * 8) || ypk.ensure((size_t)w_pad * n_pad * 8 + CF_YPK_SLACK) ||
       dout.ensure((size_t)w_pad * 8) || nf.ensure(8) || dth.ensure(8))
     return CF_ERR_HIP;
   HIP_TRY(hipMemcpy(db.p, b, (size_t)nrhs * n * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(nf.p, 0, 8));
-  hipLaunchKernelGGL(pad_rhs_kernel, dim3((unsigned)w_pad), dim3(256), 0, 0, db.as<const double>(), nrhs, n, n_pad,
+  hipLaunchKernelGGL(pad_rhs_kernel, dim3((unsigned)w_pad), dim3(256), 0, 0, db.as<const double>(), nrhs, n, n_ld,
                      delta.as<double>());
   cf_dev_desc d{};
   d.n_sn = (int32_t)n;
   d.n_pad = (int32_t)n_pad;
+  d.n_ld = (int32_t)n_ld;
   if ((rc = launch_trsm(d, pf.dev, dth.as<const double>(), nrhs, delta.as<const double>(), ypk.as<d2>(), nullptr,
                         dout.as<double>(), (int)CF_OUT_CHI2, nf.as<unsigned long long>(), (hipStream_t)0, nullptr)))
     return rc;

@@ -55,7 +55,8 @@ struct cf_dev_desc {
   int32_t chunk_shift, pad0;  // residual kernel: each of its 512 threads owns 2^chunk_shift grid nodes
   cf_dev_slot slot[CF_N_SLOTS];
   // SN block (device pointers)
-  int32_t n_sn, n_pad;
+  int32_t n_sn, n_pad;  // n_pad: n_sn rounded up to the 16-row MFMA tile
+  int32_t n_ld, pad_ld;  // n_ld: leading dimension of the residual rows Delta[w][n_ld] (multiple of 64, zero filled past n_sn)
   const double* z_cmb;
   const double* z_hel;
   const double* obs;
@@ -115,7 +116,7 @@ struct cf_dev_pack {
   int32_t pad;
 };
 
-// Latency mode: fragment streams of X = L^-1 per (64-row block, wave); see cf_pack.h.
+// Inverse-GEMM solve: fragment streams of X = L^-1 per (64-row block, K quarter); see cf_pack.h.
 struct cf_dev_invpack {
   const cf_d2* frags;
   const int64_t* off;  // [n_rowblocks*4]

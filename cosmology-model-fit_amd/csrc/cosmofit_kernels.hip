@@ -436,7 +436,7 @@ __device__ __forceinline__ void sn_fast_loop(const cf_dev_desc& d, const DistTab
   int i = tid;
   double zc = 0.0, st = 1.0, zh = 0.0, ob = 0.0;
   if (i < n_sn) { zc = d.z_cmb[i]; st = d.sn_step[i]; zh = d.z_hel[i]; ob = d.obs[i]; }
-  for (; i < d.n_pad; i += CF_TPB_A) {
+  for (; i < d.n_ld; i += CF_TPB_A) {
     const int nx = i + CF_TPB_A;
     double zc_n = 0.0, st_n = 1.0, zh_n = 0.0, ob_n = 0.0;
     if (nx < n_sn) { zc_n = d.z_cmb[nx]; st_n = d.sn_step[nx]; zh_n = d.z_hel[nx]; ob_n = d.obs[nx]; }
@@ -453,7 +453,7 @@ __device__ __forceinline__ void sn_fast_loop(const cf_dev_desc& d, const DistTab
       }
       res = ob - off - (25.0 + 5 * log10_pos((1.0 + zh) * hermite_tab(T, z_cosmo)));
     }
-    out[i] = res;  // rows >= n_sn are zero padding for the 16-row MFMA tiles
+    out[i] = res;  // rows >= n_sn are zero padding for the MFMA tiles / the 64-row blocks of the inverse-GEMM solve
     zc = zc_n; st = st_n; zh = zh_n; ob = ob_n;
   }
 }
@@ -502,7 +502,7 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
 
   // ---- SN residual vector ----
   if (d.n_sn > 0) {
-    double* out = delta + w * d.n_pad;
+    double* out = delta + w * d.n_ld;
     const double off = slot_get(d, CF_P_OFFSET_D, th);
     const double v100 = 100 * slot_get(d, CF_P_V_D, th);
     const bool parts = dm_out != nullptr || mucorr_out != nullptr;
@@ -510,7 +510,7 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
       if (d.step_pm1) sn_fast_loop<true>(d, T, out, off, v100, tid);
       else sn_fast_loop<false>(d, T, out, off, v100, tid);
     } else
-    for (int i = tid; i < d.n_pad; i += CF_TPB_A) {
+    for (int i = tid; i < d.n_ld; i += CF_TPB_A) {
       double res = 0.0;
       if (i < d.n_sn) {
         const double zc = d.z_cmb[i];
@@ -798,6 +798,18 @@ __device__ __forceinline__ void update_loop(d4 (&acc)[NTU], const d2* __restrict
   }
 }
 
+#ifdef CF_TRSM_STAMPS
+// Debug build only (tools/trsm_stamps.py): s_memtime at the phase boundaries of workgroup 0, [wave][block row][5].
+__device__ unsigned long long cf_trsm_stamps[16 * 16 * 5];
+extern "C" int cf_debug_trsm_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cf_trsm_stamps), sizeof(cf_trsm_stamps));
+}
+#define CF_STAMP(k)                                                                   \
+  if (blockIdx.x == 0 && lane == 0 && b < 16) cf_trsm_stamps[(wave * 16 + b) * 5 + (k)] = __builtin_amdgcn_s_memtime()
+#else
+#define CF_STAMP(k)
+#endif
+
 template <int KS, int TC>
 __global__ void __launch_bounds__(64 * KS * TC)
 trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* __restrict__ theta, int64_t W,
@@ -819,13 +831,14 @@ trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* __restrict__ theta
   const int n_pad = d.n_pad;
   const int T = n_pad / 16;
   d2* Yp = ypk + panel * (int64_t)(n_pad / 8) * 64;
-  const double* dcol = delta + (w0 + col) * (int64_t)n_pad;
+  const double* dcol = delta + (w0 + col) * (int64_t)d.n_ld;
   double chi = 0.0;
 
   for (int b = 0; b < pk.n_blocks; ++b) {
     const int tiles_b = min(CF_BLOCK_TILES, T - b * CF_BLOCK_TILES);
     const int nt = tiles_b > wq ? (tiles_b - wq + TC - 1) / TC : 0;
     const int r0 = b * CF_BLOCK_ROWS;
+    CF_STAMP(0);
     // diagonal-phase stream of this wave: start its first loads now, they land during the update
     int ml[NTD], ml_max = -1;
 #pragma unroll
@@ -870,6 +883,7 @@ trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* __restrict__ theta
         else update_loop<1, PF, NTU>(acc, A, Yg, n_s2, lane);
       }
     }
+    CF_STAMP(1);
     // ---- publish this wave's partial right-hand side as B fragments in LDS ----
 #pragma unroll
     for (int j = 0; j < NTU; ++j)
@@ -879,6 +893,7 @@ trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* __restrict__ theta
         ldsP[g * PANEL_FRAGS + (2 * t + 1) * 64 + lane] = (d2){acc[j][2], acc[j][3]};
       }
     __syncthreads();
+    CF_STAMP(2);
     // ---- diagonal block through its inverse: y = inv(L_bb) * rhs (lower triangular) ----
     if (ml_max >= 0) {
       // two accumulation chains per tile (even / odd K-steps): the dependent-MFMA latency, not the
@@ -925,7 +940,9 @@ trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* __restrict__ theta
           Yp[(int64_t)(2 * mt + 1) * 64 + lane] = (d2){y[j][2], y[j][3]};
         }
     }
+    CF_STAMP(3);
     __syncthreads();  // Y of this block visible to the whole workgroup; ldsP reusable
+    CF_STAMP(4);
   }
 
   // ---- chi^2 per walker column: over the 4 row groups of a wave, then over the NW waves ----
@@ -953,74 +970,133 @@ CF_INSTANTIATE_TRSM(4, 4)
 CF_INSTANTIATE_TRSM(2, 8)
 
 // ------------------------------------------------------------------------------------------------
-// Latency mode: Y = L^-1 Delta as a triangular GEMM against the host-inverted factor, one 256-thread
-// workgroup per (64-row block, 16-walker panel); the four waves split the K range, meet in LDS, and
-// the workgroup writes its share of chi^2 to partial[rb][walker].  No dependency between workgroups,
-// so a single walker already spreads over ~27 CUs (the blocked solve keeps a panel on one CU).
-// Sums of the partials in a fixed order happen in finalize_kernel -> results do not depend on timing.
+// Inverse-GEMM solve: Y = X Delta with X = L^-1 inverted once on the host (cf_pack.h), a triangular
+// GEMM with no dependency between row blocks.  One 256-thread workgroup per (64-row block rb,
+// panel of 16*NP walkers): the four waves split the K range [0, 64 (rb+1)), each keeps the 4 x NP
+// accumulator tiles of the block in registers (an A fragment feeds NP MFMAs), the quarters meet in
+// LDS, and the workgroup writes its share of chi^2 to partial[rb][walker].  Row blocks are issued
+// largest first (blockIdx.y = 0 is the last block), every panel of one block at the same time, so
+// that each XCD's L2 reads a factor stream once.  NP = 1 is the latency variant for small batches:
+// a single walker already spreads over ~27 CUs (the blocked solve keeps a panel on one CU).
+// Sums of the partials in a fixed order happen in finalize_partials_kernel -> results do not depend
+// on timing.  B fragments are 16-byte loads straight from the row-major residual rows (cf_inv_col).
 // ------------------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(256)
-inv_gemm_chi2_kernel(cf_dev_invpack pk, int n_pad, const double* __restrict__ delta, int64_t w_pad,
+#ifdef CF_TRSM_STAMPS
+__device__ unsigned long long cf_gemm_stamps[64 * 4 * 4];  // [rb][wave][start, loop start, loop end, end] of panel 5
+extern "C" int cf_debug_gemm_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cf_gemm_stamps), sizeof(cf_gemm_stamps));
+}
+#define CF_GSTAMP(k) \
+  if (blockIdx.x == 5 && lane == 0 && rb < 64) cf_gemm_stamps[(rb * 4 + g) * 4 + (k)] = __builtin_amdgcn_s_memtime()
+#else
+#define CF_GSTAMP(k)
+#endif
+
+// Workgroup barrier for LDS traffic only: __syncthreads() also drains vmcnt, i.e. waits for global loads that
+// have nothing to do with the exchange.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NP, int PF>
+__global__ void __launch_bounds__(256)
+tri_gemm_chi2_kernel(cf_dev_invpack pk, int n_ld, const double* __restrict__ delta, int64_t w_pad,
                      double* __restrict__ partial) {
-  __shared__ __align__(16) d4 part[4][4][64];  // [wave][tile][lane]: 32 KB
-  __shared__ double chi_tile[4][16];
+  __shared__ __align__(16) d4 part[4][4][64];  // [wave][tile][lane] of one 16-walker panel: 32 KB
+  __shared__ double chi_tile[4][16 * NP];
   const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
   const int col = lane & 15, kq = lane >> 4;
-  const int rb = blockIdx.x;
-  const int64_t w0 = (int64_t)blockIdx.y * 16;
-  const int nq = 2 * (rb + 1);
+  const int rb = pk.n_rowblocks - 1 - (int)blockIdx.y;
+  const int64_t w0 = (int64_t)blockIdx.x * (16 * NP);
+  const int nq = 2 * (rb + 1);  // K-step pairs per wave
+  CF_GSTAMP(0);
   const d2* A = pk.frags + pk.off[rb * 4 + g] * 64 + lane;
-  const double* drow = delta + (w0 + col) * (int64_t)n_pad;
-  int kidx = 8 * g * nq + kq;  // column of X / row of Delta this lane feeds for the current K-step pair
-  d4 acc[4];
+  // B fragments: 16 bytes per lane from the walker's residual row; panel c is 16 rows (8 n_ld d2) further on
+  const d2* Bq = reinterpret_cast<const d2*>(delta) + ((w0 + col) * (int64_t)n_ld + 8 * (int64_t)g * nq + 2 * kq) / 2;
+  const int64_t bstride = 8 * (int64_t)n_ld;
+  d4 acc[NP][4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
-  // 2-deep software pipeline (nq is even).  The factor stream carries slack for the overrun; Delta is
-  // only read inside the walker's own row (the ragged last row block has K columns past n_pad: a
-  // neighbour's NaN times a zero of X would otherwise leak across walkers).
-  d2 a[2][4];
-  double bx[2], by[2];
-  __builtin_amdgcn_sched_barrier(0);
+  for (int c = 0; c < NP; ++c)
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
+    for (int j = 0; j < 4; ++j) acc[c][j] = (d4){0.0, 0.0, 0.0, 0.0};
+  // PF-deep software pipeline over the nq K-step pairs.  Nothing is loaded past the wave's K range (but for row
+  // block 0, covered by the buffers' slack): a load that nobody consumes still has to land before the wave may
+  // retire, and it misses every cache.
+  d2 a[PF][4], bf[PF][NP];
+  auto load_stage = [&](int p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) a[p][j] = A[(p * 4 + j) * 64];
-    bx[p] = kidx < n_pad ? drow[kidx] : 0.0;
-    by[p] = kidx + 4 < n_pad ? drow[kidx + 4] : 0.0;
-    kidx += 8;
-    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < NP; ++c) bf[p][c] = Bq[c * bstride + p * 4];
+  };
+  auto mfma_stage = [&](int p) {
+#pragma unroll
+    for (int c = 0; c < NP; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[c][j] = mfma_f64(a[p][j].x, bf[p][c].x, acc[c][j]);
+#pragma unroll
+    for (int c = 0; c < NP; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[c][j] = mfma_f64(a[p][j].y, bf[p][c].y, acc[c][j]);
+  };
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int p = 0; p < PF; ++p) {
+    load_stage(p);  // unconditional (a guard costs hipcc its exact vmcnt bookkeeping); only row block 0 has nq < PF
+    __builtin_amdgcn_sched_barrier(0);  // stage 0 must be the oldest load
   }
-  A += 2 * 4 * 64;
-  for (int q = 0; q < nq; q += 2) {
+  A += PF * 4 * 64;
+  Bq += PF * 4;
+  const int n_groups = nq / PF, rem = nq - n_groups * PF;
+  CF_GSTAMP(1);
+  for (int grp = 0; grp + 1 < n_groups; ++grp) {  // branch-free body: a guard around the MFMAs makes hipcc drain vmcnt(0) per stage
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = mfma_f64(a[p][j].x, bx[p], acc[j]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = mfma_f64(a[p][j].y, by[p], acc[j]);
+    for (int p = 0; p < PF; ++p) {
+      mfma_stage(p);
       __builtin_amdgcn_sched_barrier(0);
-      const bool more = q + 2 + p < nq;  // wave-uniform: refills past the wave's K range are not used
-#pragma unroll
-      for (int j = 0; j < 4; ++j) a[p][j] = A[(p * 4 + j) * 64];
-      bx[p] = (more && kidx < n_pad) ? drow[kidx] : 0.0;
-      by[p] = (more && kidx + 4 < n_pad) ? drow[kidx + 4] : 0.0;
-      kidx += 8;
+      load_stage(p);
       __builtin_amdgcn_sched_barrier(0);
     }
-    A += 2 * 4 * 64;
+    A += PF * 4 * 64;
+    Bq += PF * 4;
+  }
+  if (n_groups > 0) {  // last full group: only the nq % PF pairs of the tail are still to be fetched
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      mfma_stage(p);
+      __builtin_amdgcn_sched_barrier(0);
+      if (p < rem) load_stage(p);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) part[g][j][lane] = acc[j];
-  __syncthreads();
-  // wave j owns tile j: y = sum of the four K-quarters, then this tile's column sums of y^2
-  const d4 y = part[0][g][lane] + part[1][g][lane] + part[2][g][lane] + part[3][g][lane];
-  double c = y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
-  c += __shfl_xor(c, 16, CF_WAVE);
-  c += __shfl_xor(c, 32, CF_WAVE);
-  if (lane < 16) chi_tile[g][lane] = c;
-  __syncthreads();
-  if (tid < 16) partial[(int64_t)rb * w_pad + w0 + tid] = ((chi_tile[0][tid] + chi_tile[1][tid]) + chi_tile[2][tid]) + chi_tile[3][tid];
+  for (int p = 0; p < PF - 1; ++p)
+    if (p < rem) mfma_stage(p);
+  CF_GSTAMP(2);
+  // the four K quarters meet in LDS, one 16-walker panel at a time; wave g owns tile g: y, then the column sums of y^2
+#pragma unroll
+  for (int c = 0; c < NP; ++c) {
+    if (c > 0) lds_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[g][j][lane] = acc[c][j];
+    lds_barrier();
+    const d4 y = ((part[0][g][lane] + part[1][g][lane]) + part[2][g][lane]) + part[3][g][lane];
+    double v = y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
+    v += __shfl_xor(v, 16, CF_WAVE);
+    v += __shfl_xor(v, 32, CF_WAVE);
+    if (lane < 16) chi_tile[g][c * 16 + lane] = v;
+  }
+  lds_barrier();
+  if (tid < 16 * NP)
+    partial[(int64_t)rb * w_pad + w0 + tid] = ((chi_tile[0][tid] + chi_tile[1][tid]) + chi_tile[2][tid]) + chi_tile[3][tid];
+  CF_GSTAMP(3);
 }
+
+#define CF_INSTANTIATE_TRIGEMM(NP, PF) \
+  template __global__ void tri_gemm_chi2_kernel<NP, PF>(cf_dev_invpack, int, const double*, int64_t, double*);
+CF_INSTANTIATE_TRIGEMM(1, 2)
+CF_INSTANTIATE_TRIGEMM(1, 4)
+CF_INSTANTIATE_TRIGEMM(2, 2)
+CF_INSTANTIATE_TRIGEMM(2, 3)
+CF_INSTANTIATE_TRIGEMM(2, 4)
 
 // Epilogue of the latency mode: chi2 = sum over row blocks (fixed order) + the small blocks.
 extern "C" __global__ void finalize_partials_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, int64_t w_pad,
@@ -1120,8 +1196,8 @@ extern "C" __global__ void log10_selftest_kernel(const double* __restrict__ x, i
 }
 
 // Copy right-hand sides b[nrhs][n] into the padded residual layout Delta[nrhs_pad][n_pad].
-extern "C" __global__ void pad_rhs_kernel(const double* __restrict__ b, int64_t nrhs, int64_t n, int64_t n_pad,
+extern "C" __global__ void pad_rhs_kernel(const double* __restrict__ b, int64_t nrhs, int64_t n, int64_t n_ld,
                                           double* __restrict__ delta) {
   const int64_t w = blockIdx.x;
-  for (int64_t i = threadIdx.x; i < n_pad; i += blockDim.x) delta[w * n_pad + i] = (w < nrhs && i < n) ? b[w * n + i] : 0.0;
+  for (int64_t i = threadIdx.x; i < n_ld; i += blockDim.x) delta[w * n_ld + i] = (w < nrhs && i < n) ? b[w * n + i] : 0.0;
 }
