@@ -90,7 +90,7 @@ def main():
     Wl = args.walkers_per_gpu
     W_total = Wl * world
 
-    solve_kw = {} if args.solve == "default" else {"latency_mode": args.solve == "inverse"}
+    solve_kw = {} if args.solve == "default" else {"solve": args.solve}
     if args.workload == "desi_cmb_des5y":
         # joint likelihood of bao/desi_cmb_des5y.py: real DES-Dovekie redshifts + real DESI FS+Lya BAO data from the
         # golden fixture (tests/golden/bao_desi_cmb_des5y.npz), seeded synthetic SN covariance

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcosmofit_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-CF_ABI_VERSION = 3
+CF_ABI_VERSION = 4
 CF_P_NSLOTS = 10
 SLOTS = ("offset", "H0", "Om", "obh2", "och2", "w0", "wa", "v", "rd", "fcc")
 
@@ -22,7 +22,8 @@ SLOTS = ("offset", "H0", "Om", "obh2", "och2", "w0", "wa", "v", "rd", "fcc")
 CF_EZ_LATE_FLAT, CF_EZ_PHYSICAL = 0, 1
 CF_FDE_LCDM, CF_FDE_WCDM, CF_FDE_THAWING, CF_FDE_CPL = 0, 1, 2, 3
 CF_OUT_CHI2, CF_OUT_LOGL, CF_OUT_LOGP = 0, 1, 2
-CF_SOLVE_BLOCKED_TRSM, CF_SOLVE_INVERSE_GEMM = 0, 1
+CF_SOLVE_BLOCKED_TRSM, CF_SOLVE_INVERSE_GEMM, CF_SOLVE_AUTO = 0, 1, 2
+SOLVE_MODES = {"blocked": CF_SOLVE_BLOCKED_TRSM, "inverse": CF_SOLVE_INVERSE_GEMM, "auto": CF_SOLVE_AUTO}
 CF_CMB_NONE = 0
 STATUS = {0: "CF_OK", -1: "CF_ERR_INVALID", -2: "CF_ERR_NO_DEVICE", -3: "CF_ERR_HIP", -4: "CF_ERR_NOT_POSDEF",
           -5: "CF_ERR_UNSUPPORTED", -6: "CF_ERR_ILL_CONDITIONED"}
@@ -79,7 +80,7 @@ class cf_info(C.Structure):
         ("n_sn", C.c_int64), ("n_sn_pad", C.c_int64), ("packed_chol_bytes", C.c_int64),
         ("workspace_bytes", C.c_int64), ("max_walkers", C.c_int64), ("nonfinite_count", C.c_int64),
         ("device", C.c_int32), ("cu_count", C.c_int32), ("gcn_arch", C.c_char * 64),
-        ("pack_probe_rel", C.c_double),
+        ("pack_probe_rel", C.c_double), ("solve_mode", C.c_int32), ("_pad0", C.c_int32),
     ]
 
 

@@ -52,18 +52,18 @@ CF_DECLARE_TRSM(2, 4)
 CF_DECLARE_TRSM(4, 4)
 CF_DECLARE_TRSM(2, 8)
 template <int NP, int PF>
-__global__ void tri_gemm_chi2_kernel(cf_dev_invpack pk, int n_ld, const double* delta, int64_t w_pad, double* partial);
-#define CF_DECLARE_TRIGEMM(NP, PF) \
-  extern template __global__ void tri_gemm_chi2_kernel<NP, PF>(cf_dev_invpack, int, const double*, int64_t, double*);
+__global__ void tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* theta, int64_t W, const double* delta,
+                                     int64_t w_pad, double* partial, unsigned int* arrivals, const double* chi2_extra,
+                                     double* out, int out_kind, unsigned long long* nonfinite, double* chi2_sn_out);
+#define CF_DECLARE_TRIGEMM(NP, PF)                                                                                       \
+  extern template __global__ void tri_gemm_chi2_kernel<NP, PF>(cf_dev_desc, cf_dev_invpack, const double*, int64_t,     \
+                                                               const double*, int64_t, double*, unsigned int*,          \
+                                                               const double*, double*, int, unsigned long long*, double*);
 CF_DECLARE_TRIGEMM(1, 2)
 CF_DECLARE_TRIGEMM(1, 4)
 CF_DECLARE_TRIGEMM(2, 2)
 CF_DECLARE_TRIGEMM(2, 3)
 CF_DECLARE_TRIGEMM(2, 4)
-extern "C" __global__ void finalize_partials_kernel(cf_dev_desc d, const double* theta, int64_t W, int64_t w_pad,
-                                                    const double* partial, int n_rowblocks, const double* chi2_extra,
-                                                    double* out, int out_kind, unsigned long long* nonfinite,
-                                                    double* chi2_sn_out);
 extern "C" __global__ void finalize_kernel(cf_dev_desc d, const double* theta, int64_t W, const double* chi2_extra,
                                            double* out, int out_kind, unsigned long long* nonfinite);
 extern "C" __global__ void interp_kernel(const double* xq, int64_t nq, const double* x, const double* y,
@@ -189,7 +189,7 @@ struct cf_handle {
   int solve_mode = 0;
   PinnedBuf stage_in, stage_out;
   InversePack ipack;
-  DevBuf partial;
+  DevBuf partial, arrivals;  // inverse-GEMM solve: chi^2 shares per (row block, walker); arrival counters per panel
   hipStream_t stream = nullptr;
   // timing ring: 3 events per evaluation (before A, between A and B, after B)
   std::vector<hipEvent_t> ev;
@@ -237,6 +237,8 @@ static int ensure_workspace(cf_handle* h, int64_t W) {
   if (h->chi2_extra.ensure((size_t)w_pad * 8)) return CF_ERR_HIP;
   if (h->d.n_sn > 0 && h->solve_mode == CF_SOLVE_INVERSE_GEMM) {
     if (h->partial.ensure((size_t)w_pad * h->ipack.dev.n_rowblocks * 8)) return CF_ERR_HIP;
+    if (h->arrivals.ensure((size_t)(w_pad / 16) * 4)) return CF_ERR_HIP;
+    HIP_TRY(hipMemsetAsync(h->arrivals.p, 0, (size_t)(w_pad / 16) * 4, h->stream));  // the kernel re-arms them itself
   }
   if (h->d.n_sn > 0) {
     if (h->delta.ensure((size_t)w_pad * n_ld * 8 + CF_DELTA_SLACK)) return CF_ERR_HIP;
@@ -284,7 +286,7 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
     if (c->n_gl < 1 || c->n_gl > CF_MAX_GL || !c->gl_x || !c->gl_w)
       return fail(CF_ERR_INVALID, "cf_create: the CMB block needs 1..256 Gauss-Legendre nodes");
   }
-  if (c->solve_mode != CF_SOLVE_BLOCKED_TRSM && c->solve_mode != CF_SOLVE_INVERSE_GEMM)
+  if (c->solve_mode != CF_SOLVE_BLOCKED_TRSM && c->solve_mode != CF_SOLVE_INVERSE_GEMM && c->solve_mode != CF_SOLVE_AUTO)
     return fail(CF_ERR_INVALID, "cf_create: bad solve_mode");
   if (c->n_cc < 0 || c->n_cc > CF_MAX_CC) return fail(CF_ERR_INVALID, "cf_create: n_cc must be in 0..64");
   if (c->n_cc > 0 && (!c->cc_z || !c->cc_h || !c->cc_inv_cov))
@@ -410,25 +412,40 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
     d.z_hel = h->z_hel.as<const double>();
     d.obs = h->obs.as<const double>();
     d.sn_step = h->sn_step.as<const double>();
-    cf_host_pack hp;
-    if (pack_default(c->sn_chol, c->n_sn, c->sn_chol_ld, hp, &h->pack_probe_rel) != 0)
-      return bail(fail(CF_ERR_NOT_POSDEF, "cf_create: the Cholesky factor has a non-positive or non-finite pivot"));
-    if (!(h->pack_probe_rel <= CF_PROBE_LIMIT))
-      return bail(fail(CF_ERR_ILL_CONDITIONED, "cf_create: the blocked solve disagrees with row-by-row forward substitution by " +
-                                                   std::to_string(h->pack_probe_rel) + " relative on a probe vector (limit 1e-11): "
-                                                   "the factor's diagonal blocks are too ill-conditioned for 256-row block inverses"));
-    if ((rc = h->pack.upload(hp))) return bail(rc);
+    for (int64_t i = 0; i < c->n_sn; ++i) {
+      const double piv = c->sn_chol[i * c->sn_chol_ld + i];
+      if (!(piv > 0.0) || !std::isfinite(piv))
+        return bail(fail(CF_ERR_NOT_POSDEF, "cf_create: the Cholesky factor has a non-positive or non-finite pivot"));
+    }
     h->solve_mode = c->solve_mode;
-    if (c->solve_mode == CF_SOLVE_INVERSE_GEMM) {
+    double inv_probe = 0.0;
+    if (c->solve_mode != CF_SOLVE_BLOCKED_TRSM) {
       cf_host_invpack ip;
       cf_pack_inverse(c->sn_chol, c->n_sn, c->sn_chol_ld, ip);
-      const double probe = cf_invpack_probe(ip, c->sn_chol, c->sn_chol_ld);
-      if (!(probe <= CF_PROBE_LIMIT))
+      inv_probe = cf_invpack_probe(ip, c->sn_chol, c->sn_chol_ld);
+      double inv_limit = CF_PROBE_LIMIT;
+      if (const char* e = getenv("CF_DEBUG_INVERSE_PROBE_LIMIT")) inv_limit = atof(e);  // tests: force the fallback
+      if (inv_probe <= inv_limit) {
+        h->solve_mode = CF_SOLVE_INVERSE_GEMM;
+        h->pack_probe_rel = inv_probe;
+        if ((rc = h->ipack.upload(ip))) return bail(rc);
+      } else if (c->solve_mode == CF_SOLVE_INVERSE_GEMM) {
         return bail(fail(CF_ERR_ILL_CONDITIONED, "cf_create: the explicit inverse of the factor disagrees with row-by-row forward "
-                                                     "substitution by " + std::to_string(probe) + " relative (limit 1e-11); use "
-                                                     "CF_SOLVE_BLOCKED_TRSM for this covariance"));
-      if (probe > h->pack_probe_rel) h->pack_probe_rel = probe;
-      if ((rc = h->ipack.upload(ip))) return bail(rc);
+                                                     "substitution by " + std::to_string(inv_probe) + " relative (limit 1e-11); use "
+                                                     "CF_SOLVE_BLOCKED_TRSM or CF_SOLVE_AUTO for this covariance"));
+      } else {
+        h->solve_mode = CF_SOLVE_BLOCKED_TRSM;  // CF_SOLVE_AUTO falls back to forward substitution by blocks
+      }
+    }
+    if (h->solve_mode == CF_SOLVE_BLOCKED_TRSM) {
+      cf_host_pack hp;
+      if (pack_default(c->sn_chol, c->n_sn, c->sn_chol_ld, hp, &h->pack_probe_rel) != 0)
+        return bail(fail(CF_ERR_NOT_POSDEF, "cf_create: the Cholesky factor has a non-positive or non-finite pivot"));
+      if (!(h->pack_probe_rel <= CF_PROBE_LIMIT))
+        return bail(fail(CF_ERR_ILL_CONDITIONED, "cf_create: the blocked solve disagrees with row-by-row forward substitution by " +
+                                                     std::to_string(h->pack_probe_rel) + " relative on a probe vector (limit 1e-11): "
+                                                     "the factor's diagonal blocks are too ill-conditioned for 256-row block inverses"));
+      if ((rc = h->pack.upload(hp))) return bail(rc);
     }
   }
   if (c->n_bao > 0) {
@@ -504,6 +521,7 @@ extern "C" int cf_get_info(cf_handle* h, cf_info* info) {
   info->n_sn = h->d.n_sn;
   info->n_sn_pad = h->d.n_pad;
   info->packed_chol_bytes = h->pack.bytes + h->ipack.bytes;
+  info->solve_mode = h->solve_mode;
   info->workspace_bytes = (int64_t)(h->theta.bytes + h->out.bytes + h->delta.bytes + h->ypk.bytes);
   info->max_walkers = h->max_walkers;
   info->device = h->device;
@@ -584,29 +602,44 @@ static int launch_trsm(const cf_dev_desc& d, const cf_dev_pack& pk, const double
 
 // Inverse-GEMM solve: panels of 16*NP walkers per workgroup.  NP = 2 halves the factor traffic per flop and is
 // the throughput shape; NP = 1 keeps the latency of small batches short.  CF_GEMM_SHAPE=<NP>x<PF> overrides (tuning).
+struct TriGemmArgs {
+  const cf_dev_desc* d;
+  const cf_dev_invpack* pk;
+  const double* theta;
+  int64_t W;
+  const double* delta;
+  int64_t w_pad;
+  double* partial;
+  unsigned int* arrivals;
+  const double* chi2_extra;
+  double* out;
+  int out_kind;
+  unsigned long long* nonfinite;
+  double* chi2_sn_out;
+};
+
 template <int NP, int PF>
-static int launch_tri_gemm_t(const cf_dev_invpack& pk, int n_ld, const double* delta, int64_t W, int64_t w_pad, double* partial,
-                             hipStream_t st) {
-  const unsigned panels = (unsigned)((W + 16 * NP - 1) / (16 * NP));
-  hipLaunchKernelGGL((tri_gemm_chi2_kernel<NP, PF>), dim3(panels, (unsigned)pk.n_rowblocks), dim3(256), 0, st, pk,
-                     n_ld, delta, w_pad, partial);
+static int launch_tri_gemm_t(const TriGemmArgs& a, hipStream_t st) {
+  const unsigned panels = (unsigned)((a.W + 16 * NP - 1) / (16 * NP));
+  hipLaunchKernelGGL((tri_gemm_chi2_kernel<NP, PF>), dim3(panels, (unsigned)a.pk->n_rowblocks), dim3(256), 0, st, *a.d, *a.pk,
+                     a.theta, a.W, a.delta, a.w_pad, a.partial, a.arrivals, a.chi2_extra, a.out, a.out_kind, a.nonfinite,
+                     a.chi2_sn_out);
   return 0;
 }
 
-static int launch_tri_gemm(const cf_dev_invpack& pk, int n_ld, const double* delta, int64_t W, int64_t w_pad, double* partial,
-                           hipStream_t st) {
+static int launch_tri_gemm(const TriGemmArgs& a, hipStream_t st) {
   static const int shape = [] {
     const char* e = getenv("CF_GEMM_SHAPE");
     return (e && strlen(e) == 3 && e[1] == 'x') ? (e[0] - '0') * 16 + (e[2] - '0') : 0;
   }();
-  int np = W > 256 ? 2 : 1, pf = 4;
+  int np = a.W > 256 ? 2 : 1, pf = 2;
   if (shape) { np = shape / 16; pf = shape % 16; }
   switch (np * 16 + pf) {
-    case 1 * 16 + 2: return launch_tri_gemm_t<1, 2>(pk, n_ld, delta, W, w_pad, partial, st);
-    case 1 * 16 + 4: return launch_tri_gemm_t<1, 4>(pk, n_ld, delta, W, w_pad, partial, st);
-    case 2 * 16 + 2: return launch_tri_gemm_t<2, 2>(pk, n_ld, delta, W, w_pad, partial, st);
-    case 2 * 16 + 3: return launch_tri_gemm_t<2, 3>(pk, n_ld, delta, W, w_pad, partial, st);
-    case 2 * 16 + 4: return launch_tri_gemm_t<2, 4>(pk, n_ld, delta, W, w_pad, partial, st);
+    case 1 * 16 + 2: return launch_tri_gemm_t<1, 2>(a, st);
+    case 1 * 16 + 4: return launch_tri_gemm_t<1, 4>(a, st);
+    case 2 * 16 + 2: return launch_tri_gemm_t<2, 2>(a, st);
+    case 2 * 16 + 3: return launch_tri_gemm_t<2, 3>(a, st);
+    case 2 * 16 + 4: return launch_tri_gemm_t<2, 4>(a, st);
   }
   return fail(CF_ERR_INVALID, "bad CF_GEMM_SHAPE");
 }
@@ -630,12 +663,10 @@ static int launch_path(cf_handle* h, const double* d_theta, int64_t W, double* d
   }
   if (ev) HIP_TRY(hipEventRecord(ev[1], st));
   if (d.n_sn > 0 && h->solve_mode == CF_SOLVE_INVERSE_GEMM) {
-    const int64_t w_pad = h->max_walkers;
-    int rc = launch_tri_gemm(h->ipack.dev, (int)d.n_ld, h->delta.as<const double>(), W, w_pad, h->partial.as<double>(), st);
+    const TriGemmArgs a{&d, &h->ipack.dev, d_theta, W, h->delta.as<const double>(), h->max_walkers, h->partial.as<double>(),
+                        h->arrivals.as<unsigned int>(), extra, d_out, out_kind, nf, chi2_sn_out};
+    int rc = launch_tri_gemm(a, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(finalize_partials_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, d, d_theta, W, w_pad,
-                       h->partial.as<const double>(), (int)h->ipack.dev.n_rowblocks, (const double*)extra, d_out, out_kind, nf,
-                       chi2_sn_out);
   } else if (d.n_sn > 0) {
     int rc = launch_trsm(d, h->pack.dev, d_theta, W, h->delta.as<const double>(), h->ypk.as<d2>(), extra, d_out, out_kind, nf, st,
                          chi2_sn_out);

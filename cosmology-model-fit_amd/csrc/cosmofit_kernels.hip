@@ -978,8 +978,8 @@ CF_INSTANTIATE_TRSM(2, 8)
 // largest first (blockIdx.y = 0 is the last block), every panel of one block at the same time, so
 // that each XCD's L2 reads a factor stream once.  NP = 1 is the latency variant for small batches:
 // a single walker already spreads over ~27 CUs (the blocked solve keeps a panel on one CU).
-// Sums of the partials in a fixed order happen in finalize_partials_kernel -> results do not depend
-// on timing.  B fragments are 16-byte loads straight from the row-major residual rows (cf_inv_col).
+// The workgroup that arrives last for a panel adds the partials in a fixed order and applies the prior /
+// output epilogue -> one launch, and results do not depend on timing.  B fragments are 16-byte loads straight from the row-major residual rows (cf_inv_col).
 // ------------------------------------------------------------------------------------------------
 #ifdef CF_TRSM_STAMPS
 __device__ unsigned long long cf_gemm_stamps[64 * 4 * 4];  // [rb][wave][start, loop start, loop end, end] of panel 5
@@ -998,10 +998,14 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 template <int NP, int PF>
 __global__ void __launch_bounds__(256)
-tri_gemm_chi2_kernel(cf_dev_invpack pk, int n_ld, const double* __restrict__ delta, int64_t w_pad,
-                     double* __restrict__ partial) {
+tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict__ theta, int64_t W,
+                     const double* __restrict__ delta, int64_t w_pad, double* partial, unsigned int* arrivals,
+                     const double* __restrict__ chi2_extra, double* __restrict__ out, int out_kind,
+                     unsigned long long* nonfinite, double* __restrict__ chi2_sn_out) {
   __shared__ __align__(16) d4 part[4][4][64];  // [wave][tile][lane] of one 16-walker panel: 32 KB
   __shared__ double chi_tile[4][16 * NP];
+  __shared__ unsigned int arrived_before;
+  const int n_ld = d.n_ld;
   const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
   const int col = lane & 15, kq = lane >> 4;
   const int rb = pk.n_rowblocks - 1 - (int)blockIdx.y;
@@ -1085,32 +1089,43 @@ tri_gemm_chi2_kernel(cf_dev_invpack pk, int n_ld, const double* __restrict__ del
     if (lane < 16) chi_tile[g][c * 16 + lane] = v;
   }
   lds_barrier();
-  if (tid < 16 * NP)
-    partial[(int64_t)rb * w_pad + w0 + tid] = ((chi_tile[0][tid] + chi_tile[1][tid]) + chi_tile[2][tid]) + chi_tile[3][tid];
+  // Hand-off between workgroups on different XCDs (their L2s are not coherent): the partial sums travel as
+  // agent-scope (L2-bypassing) stores, drained before the arrival counter is bumped, and are read back with
+  // agent-scope loads by the workgroup that arrives last for this panel.  That one adds the row blocks in a
+  // fixed order -- the result does not depend on which workgroup it was -- and re-arms the counter.
+  if (g == 0) {
+    if (lane < 16 * NP)
+      __hip_atomic_store(&partial[(int64_t)rb * w_pad + w0 + lane],
+                         ((chi_tile[0][lane] + chi_tile[1][lane]) + chi_tile[2][lane]) + chi_tile[3][lane], __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): the stores have left this CU
+    if (lane == 0)
+      arrived_before = __hip_atomic_fetch_add(&arrivals[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   CF_GSTAMP(3);
+  lds_barrier();
+  if (arrived_before != (unsigned)pk.n_rowblocks - 1u) return;
+  if (tid == 0) __hip_atomic_store(&arrivals[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid < 16 * NP && w0 + tid < W) {
+    const int64_t w = w0 + tid;
+    double c2 = 0.0;
+    for (int r = 0; r < pk.n_rowblocks; ++r)
+      c2 += __hip_atomic_load(&partial[(int64_t)r * w_pad + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (chi2_sn_out) chi2_sn_out[w] = c2;  // the SN block alone (cf_eval_parts)
+    if (chi2_extra) c2 += chi2_extra[w];
+    out[w] = finalize_value(d, theta + w * d.ndim, c2, out_kind, nonfinite);
+  }
 }
 
-#define CF_INSTANTIATE_TRIGEMM(NP, PF) \
-  template __global__ void tri_gemm_chi2_kernel<NP, PF>(cf_dev_invpack, int, const double*, int64_t, double*);
+#define CF_INSTANTIATE_TRIGEMM(NP, PF)                                                                                   \
+  template __global__ void tri_gemm_chi2_kernel<NP, PF>(cf_dev_desc, cf_dev_invpack, const double*, int64_t, const double*, \
+                                                        int64_t, double*, unsigned int*, const double*, double*, int,   \
+                                                        unsigned long long*, double*);
 CF_INSTANTIATE_TRIGEMM(1, 2)
 CF_INSTANTIATE_TRIGEMM(1, 4)
 CF_INSTANTIATE_TRIGEMM(2, 2)
 CF_INSTANTIATE_TRIGEMM(2, 3)
 CF_INSTANTIATE_TRIGEMM(2, 4)
-
-// Epilogue of the latency mode: chi2 = sum over row blocks (fixed order) + the small blocks.
-extern "C" __global__ void finalize_partials_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, int64_t w_pad,
-                                                    const double* __restrict__ partial, int n_rowblocks,
-                                                    const double* __restrict__ chi2_extra, double* __restrict__ out,
-                                                    int out_kind, unsigned long long* nonfinite, double* __restrict__ chi2_sn_out) {
-  const int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (w >= W) return;
-  double c2 = 0.0;
-  for (int rb = 0; rb < n_rowblocks; ++rb) c2 += partial[(int64_t)rb * w_pad + w];
-  if (chi2_sn_out) chi2_sn_out[w] = c2;
-  if (chi2_extra) c2 += chi2_extra[w];
-  out[w] = finalize_value(d, theta + w * d.ndim, c2, out_kind, nonfinite);
-}
 
 // ------------------------------------------------------------------------------------------------
 // Likelihoods without an SN block: only the epilogue.

@@ -37,11 +37,20 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def solve_mode_of(solve="auto", latency_mode=None) -> int:
+    """solve: "auto" | "inverse" | "blocked"; latency_mode (older keyword): True = "inverse", False = "blocked"."""
+    if latency_mode is not None:
+        solve = "inverse" if latency_mode else "blocked"
+    if solve not in L.SOLVE_MODES:
+        raise ValueError(f"solve must be one of {sorted(L.SOLVE_MODES)}")
+    return L.SOLVE_MODES[solve]
+
+
 class LikelihoodEngine:
     def __init__(self, *, ndim: int, z_max: float, n_grid: int = 4000, fde: int = L.CF_FDE_LCDM,
                  ez_model: int = L.CF_EZ_LATE_FLAT, params: dict, sn: Optional[dict] = None,
                  bao: Optional[dict] = None, cmb: Optional[dict] = None, physical: Optional[dict] = None,
-                 cc: Optional[dict] = None, solve_mode: int = L.CF_SOLVE_BLOCKED_TRSM,
+                 cc: Optional[dict] = None, solve_mode: int = L.CF_SOLVE_AUTO,
                  bounds=None, gauss: Sequence = (), chi2_gauss: Sequence = (), cpl_wall: bool = False,
                  device: int = 0, c_km_s: float = C_KM_S):
         """
@@ -57,8 +66,9 @@ class LikelihoodEngine:
         physical: dict(or_h2, omnu_h2, o_gamma_h2, nu_m0, nu_rho0, nu_qs_sq[5], nu_ws[5]) — required by
             ez_model=CF_EZ_PHYSICAL (see cmb_data.PLANCK_ACT / EARLY_LCDM).
         gauss / chi2_gauss: sequences of (idx, mean, sigma).
-        solve_mode: CF_SOLVE_BLOCKED_TRSM (default, throughput) or CF_SOLVE_INVERSE_GEMM (latency mode for
-            small batches: single theta calls of log_evidence.py, emcee ensembles of a few hundred walkers).
+        solve_mode: CF_SOLVE_AUTO (default: the inverse-GEMM solve when its create-time probe passes, otherwise the
+            blocked forward substitution), CF_SOLVE_INVERSE_GEMM or CF_SOLVE_BLOCKED_TRSM; info()["solve_mode"]
+            tells which one runs.  See solve_mode_of() for the keyword form the mirrors take.
         """
         lib = L.lib()
         d = L.cf_desc()

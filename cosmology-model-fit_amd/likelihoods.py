@@ -18,7 +18,7 @@ from scipy.linalg import cho_factor
 
 from . import _lib as L
 from . import cmb_data
-from .engine import LikelihoodEngine, Param
+from .engine import LikelihoodEngine, Param, solve_mode_of
 
 N_GRID = 4000
 QTY_MAP = {"DV_over_rs": 0, "DM_over_rs": 1, "DH_over_rs": 2, "F_AP": 3}  # bao/desi_cmb_des5y.py:69-78
@@ -106,7 +106,7 @@ class DesiCmbDes5y(_Base):
     PCHIP D_H and F_AP, Planck+ACT (R, l_A, wb); dark energy = Lambda as shipped (:46)."""
 
     def __init__(self, z_cmb, z_hel, mu_values, cov_sn, bao_z, bao_val, bao_qty, bao_inv_cov, *, chol=None, comp=None,
-                 device=0, latency_mode=False):
+                 device=0, solve="auto", latency_mode=None):
         comp = cmb_data.PLANCK_ACT if comp is None else comp
         if chol is None:
             chol = cho_factor(cov_sn, lower=True)[0]  # bao/desi_cmb_des5y.py:17
@@ -118,7 +118,7 @@ class DesiCmbDes5y(_Base):
             bao=dict(z=bao_z, val=bao_val, qty=bao_qty, inv_cov=bao_inv_cov, rd_fit=comp["rd_fit"]),
             cmb=dict(mode=comp["cmb_mode"], prior=comp["cmb_prior"], inv_cov=comp["cmb_inv_cov"], zstar_fit=comp["zstar_fit"]),
             physical=_physical(comp), device=device,
-            solve_mode=L.CF_SOLVE_INVERSE_GEMM if latency_mode else L.CF_SOLVE_BLOCKED_TRSM)
+            solve_mode=solve_mode_of(solve, latency_mode))
 
 
 class DesiDes5yBbnThetaStar(_Base):

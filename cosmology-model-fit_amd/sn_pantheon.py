@@ -13,7 +13,7 @@ import numpy as np
 from scipy.linalg import cho_factor
 
 from . import _lib as L
-from .engine import LikelihoodEngine, Param
+from .engine import LikelihoodEngine, Param, solve_mode_of
 
 # sn/pantheon.py:68-75
 bounds = np.array(
@@ -31,7 +31,7 @@ N_GRID = 4000  # sn/pantheon.py:16
 
 class PantheonLikelihood:
     def __init__(self, z_cmb, z_hel, mb_vals, cov_matrix=None, *, chol=None, device=0, bounds=bounds,
-                 h0_prior=H0_PRIOR, fde=L.CF_FDE_LCDM, step=None, fixed_mu=None, z_turn=Z_TURN, latency_mode=False):
+                 h0_prior=H0_PRIOR, fde=L.CF_FDE_LCDM, step=None, fixed_mu=None, z_turn=Z_TURN, solve="auto", latency_mode=None):
         """step: per-SN velocity weights instead of the +-1 Heaviside step (dipole fits, sn/pantheon_dipole.py:60-68:
         cos(angle) * attenuation * survey mask); fixed_mu: Cepheid distance moduli of calibrator hosts, NaN elsewhere
         (sn/pantheon_and_sh0es.py:63-69)."""
@@ -47,7 +47,7 @@ class PantheonLikelihood:
             params=dict(offset=Param(0), H0=Param(1), Om=Param(2), v=Param(3)),
             sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=mb_vals, chol=chol, z_turn=z_turn, step=step, fixed_mu=fixed_mu),
             bounds=self.bounds, gauss=[h0_prior] if h0_prior else [], device=device,
-            solve_mode=L.CF_SOLVE_INVERSE_GEMM if latency_mode else L.CF_SOLVE_BLOCKED_TRSM,
+            solve_mode=solve_mode_of(solve, latency_mode),
         )
 
     # -- reference names ----------------------------------------------------------------------

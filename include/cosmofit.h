@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 3
+#define CF_ABI_VERSION 4
 
 typedef struct cf_handle cf_handle;
 
@@ -110,14 +110,16 @@ enum cf_cmb_mode {
   CF_CMB_THETA_WB_WM = 3 /* (100 theta*, omega_b, omega_m)               cmb/data_early_lcdm_compression.py:198-207 */
 };
 
-/* How chi^2 = || L^-1 Delta ||^2 is evaluated (both on FP64 matrix cores). */
+/* How chi^2 = || L^-1 Delta ||^2 is evaluated (both on FP64 matrix cores; solve_triangular.py:5-14). */
 enum cf_solve_mode {
-  CF_SOLVE_BLOCKED_TRSM = 0, /* default: blocked forward substitution, one workgroup per 16-walker panel; best
-                                throughput for batches >= ~4096 walkers */
-  CF_SOLVE_INVERSE_GEMM = 1  /* latency mode: triangular GEMM against L^-1 (inverted once on the host, probed
-                                against row-by-row substitution at cf_create); rows spread over many CUs, so
-                                batches of 1..2048 walkers finish several times sooner (solve_triangular.py:5-14
-                                evaluated one theta at a time by log_evidence.py:20-46 and by small emcee ensembles) */
+  CF_SOLVE_BLOCKED_TRSM = 0, /* blocked forward substitution, one workgroup per 16-walker panel: 256-row block rows,
+                                diagonal blocks through their host-computed inverses */
+  CF_SOLVE_INVERSE_GEMM = 1, /* triangular GEMM against X = L^-1 (inverted once on the host in extended precision,
+                                probed against row-by-row substitution at cf_create): no dependency between row
+                                blocks, so the matrix cores stay busy for large batches and a batch of 1..2048
+                                walkers (log_evidence.py:20-46, small emcee ensembles) spreads over the whole chip */
+  CF_SOLVE_AUTO = 2          /* CF_SOLVE_INVERSE_GEMM when its probe passes (<= 1e-11 relative), otherwise
+                                CF_SOLVE_BLOCKED_TRSM; cf_info.solve_mode tells which one is in effect */
 };
 
 /* Output selector for cf_eval*. */
@@ -233,8 +235,10 @@ typedef struct cf_info {
   int32_t device;
   int32_t cu_count;
   char gcn_arch[64];
-  double pack_probe_rel;   /* |chi2(blocked streams) - chi2(row-by-row substitution)| / chi2 on a probe vector,
+  double pack_probe_rel;   /* |chi2(packed streams) - chi2(row-by-row substitution)| / chi2 on a probe vector,
                               measured on the host at cf_create (refused above 1e-11) */
+  int32_t solve_mode;      /* cf_solve_mode in effect (never CF_SOLVE_AUTO) */
+  int32_t _pad0;
 } cf_info;
 
 int cf_device_count(void);

@@ -92,10 +92,11 @@ def test_interp_hermite_reproduces_nodes_and_slopes(gpu):
 
 
 # ---- a1-a10 + a11 + a17: the SN likelihood against the reference's golden vectors -----------
-@pytest.fixture(scope="module")
-def pantheon_lk(gpu, pantheon_golden):
+@pytest.fixture(scope="module", params=["inverse", "blocked"])
+def pantheon_lk(gpu, pantheon_golden, request):
     g = pantheon_golden
-    lk = gpu.sn_pantheon.PantheonLikelihood(g["z_cmb"], g["z_hel"], g["obs"], chol=g["chol"], bounds=g["bounds"])
+    lk = gpu.sn_pantheon.PantheonLikelihood(g["z_cmb"], g["z_hel"], g["obs"], chol=g["chol"], bounds=g["bounds"], solve=request.param)
+    assert lk.engine.info()["solve_mode"] == gpu._lib.SOLVE_MODES[request.param]
     assert abs(lk.z_max - float(g["z_max"])) == 0.0
     yield lk
     lk.engine.close()
@@ -129,12 +130,15 @@ def test_sn_pantheon_golden_intermediates(pantheon_lk, pantheon_golden):
 
 
 # ---- BASELINE config 2 (N=1701, W=4096) at full size ------------------------------------------
-@pytest.fixture(scope="module")
-def config2(gpu):
+@pytest.fixture(scope="module", params=["auto", "blocked"])
+def config2(gpu, request):
+    """Both solve kernels at full size; "auto" is what every mirror uses by default and picks the inverse-GEMM solve here."""
     from oracle import oracle_c, oracle_np as onp
 
     syn = gpu.synthetic.pantheon_like(n_sn=1701, seed=0)
-    lk = gpu.sn_pantheon.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"])
+    lk = gpu.sn_pantheon.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"], solve=request.param)
+    want_mode = gpu.CF_SOLVE_BLOCKED_TRSM if request.param == "blocked" else gpu.CF_SOLVE_INVERSE_GEMM
+    assert lk.engine.info()["solve_mode"] == want_mode
     ref = oracle_c.COracle(onp.Likelihood(
         ndim=4, z_max=lk.z_max, offset=onp.Slot(0), H0=onp.Slot(1), Om=onp.Slot(2), v=onp.Slot(3),
         z_cmb=syn["z_cmb"], z_hel=syn["z_hel"], obs=syn["obs"], chol=syn["chol"],
@@ -281,13 +285,30 @@ def test_batched_laplace_evidence_gpu_vs_oracle(gpu):
     lk.engine.close()
 
 
-# ---- latency mode: triangular GEMM against the explicit inverse (cf_solve_mode CF_SOLVE_INVERSE_GEMM) -------------
+def test_auto_mode_falls_back_to_the_blocked_solve(gpu, config2, monkeypatch):
+    """CF_SOLVE_AUTO with a failing inverse probe (forced through the debug knob) must run the blocked solve."""
+    _, ref, theta = config2
+    syn = gpu.synthetic.pantheon_like(n_sn=1701, seed=0)
+    monkeypatch.setenv("CF_DEBUG_INVERSE_PROBE_LIMIT", "0")
+    lk = gpu.sn_pantheon.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"])
+    assert lk.engine.info()["solve_mode"] == gpu.CF_SOLVE_BLOCKED_TRSM
+    np.testing.assert_allclose(lk.log_probs_vectorized(theta[:200]), ref.logp(theta[:200]), rtol=RTOL)
+    with pytest.raises(gpu.CosmofitError, match="CF_ERR_ILL_CONDITIONED"):
+        gpu.sn_pantheon.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"], solve="inverse")
+    lk.engine.close()
+
+
+# ---- inverse-GEMM solve: triangular GEMM against the explicit inverse (cf_solve_mode CF_SOLVE_INVERSE_GEMM) ---------
 def test_latency_mode_parity_and_speed(gpu, config2):
     import time
     lk_blocked, ref, theta = config2
+    if lk_blocked.engine.info()["solve_mode"] != gpu.CF_SOLVE_BLOCKED_TRSM:
+        pytest.skip("runs once, beside the blocked-solve instance of the fixture")
     syn = gpu.synthetic.pantheon_like(n_sn=1701, seed=0)
     lk = gpu.sn_pantheon.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"], latency_mode=True)
-    assert lk.engine.info()["pack_probe_rel"] < 1e-12
+    assert lk.engine.info()["pack_probe_rel"] < 1e-12 and lk.engine.info()["solve_mode"] == gpu.CF_SOLVE_INVERSE_GEMM
+    # the two kernels agree far inside the parity bar
+    np.testing.assert_allclose(lk.chi_squared(theta), lk_blocked.chi_squared(theta), rtol=1e-12)
     full = lk.chi_squared(theta)
     want = ref.chi2(theta)
     rel = np.abs(full - want) / np.abs(want)
