@@ -54,11 +54,12 @@ CF_DECLARE_TRSM(2, 8)
 template <int NP, int PF>
 __global__ void tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* theta, int64_t W, const double* delta,
                                      int64_t w_pad, double* partial, unsigned int* arrivals, const double* chi2_extra,
-                                     double* out, int out_kind, unsigned long long* nonfinite, double* chi2_sn_out);
+                                     double* out, int out_kind, unsigned long long* nonfinite, double* chi2_sn_out,
+                                     int panels_per_group);
 #define CF_DECLARE_TRIGEMM(NP, PF)                                                                                       \
   extern template __global__ void tri_gemm_chi2_kernel<NP, PF>(cf_dev_desc, cf_dev_invpack, const double*, int64_t,     \
                                                                const double*, int64_t, double*, unsigned int*,          \
-                                                               const double*, double*, int, unsigned long long*, double*);
+                                                               const double*, double*, int, unsigned long long*, double*, int);
 CF_DECLARE_TRIGEMM(1, 2)
 CF_DECLARE_TRIGEMM(1, 4)
 CF_DECLARE_TRIGEMM(2, 2)
@@ -197,7 +198,7 @@ struct cf_handle {
   int64_t timed_calls = 0;
   cf_dev_desc d{};
   PackedFactor pack;
-  DevBuf z_cmb, z_hel, obs, sn_step;
+  DevBuf z_cmb, z_hel, obs, sn_step, sn_rec;
   DevBuf bao_z, bao_val, bao_inv_cov, bao_qty, gl_x, gl_w, fixed_mu, cc_z, cc_h, cc_inv_cov, nu_grid;
   DevBuf theta, out, delta, ypk, chi2_extra, nonfinite;
   bool has_small_blocks = false;  // BAO and / or CMB block present
@@ -412,6 +413,15 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
     d.z_hel = h->z_hel.as<const double>();
     d.obs = h->obs.as<const double>();
     d.sn_step = h->sn_step.as<const double>();
+    {
+      // one record per SN for the production loop; 512 spare records so that its look-ahead needs no bounds check
+      std::vector<cf_d4> rec((size_t)d.n_ld + 512, cf_d4{0.0, 1.0, 0.0, 0.0});
+      for (int64_t i = 0; i < c->n_sn; ++i) rec[i] = cf_d4{c->sn_z_cmb[i], step[i], c->sn_z_hel[i], c->sn_obs[i]};
+      if (h->sn_rec.ensure(rec.size() * sizeof(cf_d4))) return bail(CF_ERR_HIP);
+      if (hipMemcpy(h->sn_rec.p, rec.data(), rec.size() * sizeof(cf_d4), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(fail(CF_ERR_HIP, "hipMemcpy(sn_rec) failed"));
+      d.sn_rec = h->sn_rec.as<const cf_d4>();
+    }
     for (int64_t i = 0; i < c->n_sn; ++i) {
       const double piv = c->sn_chol[i * c->sn_chol_ld + i];
       if (!(piv > 0.0) || !std::isfinite(piv))
@@ -620,10 +630,20 @@ struct TriGemmArgs {
 
 template <int NP, int PF>
 static int launch_tri_gemm_t(const TriGemmArgs& a, hipStream_t st) {
-  const unsigned panels = (unsigned)((a.W + 16 * NP - 1) / (16 * NP));
-  hipLaunchKernelGGL((tri_gemm_chi2_kernel<NP, PF>), dim3(panels, (unsigned)a.pk->n_rowblocks), dim3(256), 0, st, *a.d, *a.pk,
-                     a.theta, a.W, a.delta, a.w_pad, a.partial, a.arrivals, a.chi2_extra, a.out, a.out_kind, a.nonfinite,
-                     a.chi2_sn_out);
+  const int panels = (int)((a.W + 16 * NP - 1) / (16 * NP));
+  // optional panel groups (CF_GEMM_GROUP = panels per group, multiples of 8 so that a panel stays on one XCD): keeps a
+  // group's residual rows in L2 while its row blocks pass.  Measured at N = 1701, W = 4096: no gain (one group 226 us,
+  // two groups 229 us, four 249 us -- the factor streams are re-read per group), so the default is a single group.
+  static const int max_group = [] { const char* e = getenv("CF_GEMM_GROUP"); return e ? atoi(e) : 0; }();
+  int ppg = panels;
+  if (max_group > 0 && panels > max_group) {
+    const int n_groups = (panels + max_group - 1) / max_group;
+    ppg = ((panels + n_groups - 1) / n_groups + 7) / 8 * 8;
+  }
+  const int n_groups = (panels + ppg - 1) / ppg;
+  hipLaunchKernelGGL((tri_gemm_chi2_kernel<NP, PF>), dim3((unsigned)(n_groups * ppg * a.pk->n_rowblocks)), dim3(256), 0, st, *a.d,
+                     *a.pk, a.theta, a.W, a.delta, a.w_pad, a.partial, a.arrivals, a.chi2_extra, a.out, a.out_kind, a.nonfinite,
+                     a.chi2_sn_out, ppg);
   return 0;
 }
 

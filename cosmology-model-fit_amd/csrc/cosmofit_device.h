@@ -48,6 +48,11 @@ struct cf_dev_slot {
   double fixed;
 };
 
+// one supernova of the production loop: {z_cmb, step weight, z_hel, observed magnitude}
+struct cf_d4 {
+  double x, y, z, w;
+};
+
 struct cf_dev_desc {
   int32_t ndim, n_grid, ez_model, fde;
   double z_max, step, c;
@@ -61,6 +66,7 @@ struct cf_dev_desc {
   const double* z_hel;
   const double* obs;
   const double* sn_step;
+  const cf_d4* sn_rec;  // [n_ld + 512] {z_cmb, step, z_hel, obs} per SN, one 32-byte record (the production SN loop); padding {0, 1, 0, 0}
   int32_t has_vstep;  // 0: the likelihood has no peculiar-velocity step (z_cosmo = z_cmb)
   int32_t step_pm1;   // 1: every sn_step entry is +1 or -1
   const double* sn_fixed_mu;  // [n_sn] or null; non-NaN entries replace mu_theory (SH0ES calibrators)

@@ -66,6 +66,18 @@ __device__ __forceinline__ WalkerCosmo make_cosmo(const cf_dev_desc& d, const do
 // MODEL / FDE are compile-time: one kernel instantiation per expansion-rate family keeps the hot
 // loops free of the other families' code (the all-in-one kernel was 14 k instructions, well past
 // the instruction cache, and ran its table build 3x slower than its VALU work).
+#ifdef CF_TRSM_STAMPS
+__device__ unsigned long long cf_walker_stamps[8 * 8 * 8];  // [sampled workgroup][wave][phase]
+extern "C" int cf_debug_walker_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cf_walker_stamps), sizeof(cf_walker_stamps));
+}
+#define CF_WSTAMP(k)                                                                     \
+  if ((blockIdx.x & 511) == 300 && (threadIdx.x & 63) == 0)                               \
+  cf_walker_stamps[((blockIdx.x >> 9) * 8 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime()
+#else
+#define CF_WSTAMP(k)
+#endif
+
 template <int FDE>
 __device__ __forceinline__ double f_de(const WalkerCosmo& wc, double z, double zp1, double cubed) {
   if (FDE == CF_FDE_LCDM_D) return 1.0;
@@ -112,6 +124,14 @@ __device__ __forceinline__ double H_of_z(const cf_dev_desc& d, const WalkerCosmo
 template <int MODEL, int FDE>
 __device__ __forceinline__ double dh_of_z_fast(const cf_dev_desc& d, const WalkerCosmo& wc, double c_over_H0, double z) {
   return c_over_H0 * rsqrt(e2_of_z<MODEL, FDE>(d, wc, z));
+}
+
+// rsqrt for positive finite normal arguments (E^2 on the grid): the library's seed + refinement without its
+// zero / infinity / NaN selects (3 instructions per grid node).
+__device__ __forceinline__ double rsqrt_pos(double x) {
+  const double y0 = __builtin_amdgcn_rsq(x);
+  const double e = fma(-x * y0, y0, 1.0);
+  return fma(y0 * e, fma(e, 0.375, 0.5), y0);
 }
 
 // Grid node i of np.linspace(0, z_max, G): i*step, last node forced to z_max (sn/pantheon.py:16).
@@ -180,6 +200,34 @@ __device__ __forceinline__ double hermite_tab(const DistTable& T, double xi) {
   return h00 * e0.x + h10 * h_i * e0.y + h01 * e1.x + h11 * h_i * e1.y;
 }
 
+// The same interpolant for the production SN loop.  The interval comes from one truncation, without restoring
+// x[i] < xi <= x[i+1] at the ulp level: at a node both neighbouring cubics give the node value (C1 interpolant), so
+// an xi within rounding of a node may use either; t = xi/step - i instead of (xi - x_i)/h_i and h = step also in
+// the last interval (z_max vs (G-1)*step: a rounding apart) move the result by ~1e-14 relative, far inside the
+// 1e-10 bar (tests/test_gpu_parity.py).  ~45 instructions fewer per supernova than hermite_tab.
+__device__ __forceinline__ double hermite_fast(const DistTable& T, double xi) {
+  const int G = T.G;
+  if (xi <= 0.0) {
+    const d2 e = T.at(0);
+    return e.x + e.y * xi;
+  }
+  if (xi >= T.z_max) {
+    const d2 e = T.at(G - 1);
+    return e.x + e.y * (xi - T.z_max);
+  }
+  const double u = xi * T.inv_step;
+  int i = (int)u;
+  i = i > G - 2 ? G - 2 : i;
+  const double t = u - (double)i;
+  const double t2 = t * t, t3 = t2 * t;
+  const double h00 = 2 * t3 - 3 * t2 + 1;
+  const double h10 = t3 - 2 * t2 + t;
+  const double h01 = -2 * t3 + 3 * t2;
+  const double h11 = t3 - t2;
+  const d2 e0 = T.at(i), e1 = T.at(i + 1);
+  return h00 * e0.x + h10 * T.step * e0.y + h01 * e1.x + h11 * T.step * e1.y;
+}
+
 // log10 for positive, finite, normal arguments (distances in Mpc): the fdlibm / msun algorithm
 // (log1p kernel: 14-term odd polynomial in s = f/(2+f); hi/lo split of 1/ln10 and log10(2)), < 1 ulp.
 // About a third of the instructions of the generic library call, which also handles zero, negative,
@@ -245,50 +293,53 @@ __device__ __forceinline__ double wave_inclusive_scan(double v) {
 //   dh[g]  = c/H(z_g)
 //   cum[g] = sum_{k<g} (dh[k]+dh[k+1])/2 * (z[k+1]-z[k])          (sn/pantheon.py:35-39)
 // Thread t owns CH = 2^chs contiguous nodes (CH*CF_TPB_A >= G): chunk-sequential trapezoid sums in
-// registers, wave64 DPP scan over the chunk totals, wave totals carried through LDS, then ONE 16-byte
-// LDS store per node.  The node before a chunk comes from the neighbouring lane (shuffle); the first
-// lane of a wave re-evaluates it instead of waiting for another wave (one barrier less).
-// One thread's chunk: dh at its CH nodes and the chunk-local trapezoid prefix.  INTERIOR = the whole WAVE
-// lies strictly inside the grid (no node 0, no last node, nothing past G): no per-node bounds logic.
+// registers, wave64 DPP scan over the chunk totals, wave totals and the wave-boundary intervals carried
+// through LDS, then ONE 16-byte LDS store per node.
+// One thread's chunk: dh at its CH nodes and the chunk-local trapezoid prefix, branch-free (the CH evaluation
+// chains are independent and interleave; a per-node branch would serialise them: the two edge waves took 4x
+// the interior ones, and the whole workgroup waits for them at the barrier).  INTERIOR = the whole WAVE lies
+// strictly inside the grid (no node 0, no last node, nothing past G): the bounds selects drop out.
+// The interval in front of a chunk belongs to it, with dh of the node before taken from the neighbouring lane
+// (DPP wave_shr:1); lane 0 leaves its first interval out -- build_distance_table_regs adds the eight
+// wave-boundary intervals with the carries.
 template <int MODEL, int FDE, int CH, bool INTERIOR>
 __device__ __forceinline__ double chunk_eval(const cf_dev_desc& d, const WalkerCosmo& wc, double c_over_H0, int g0, int lane,
                                              double (&dh)[CH], double (&loc)[CH]) {
   const int G = d.n_grid;
+  double z[CH];
 #pragma unroll
   for (int k = 0; k < CH; ++k) {
     const int g = g0 + k;
     if (INTERIOR) {
+      z[k] = (double)g * d.step;
       const double nu = (MODEL == CF_EZ_PHYSICAL_D && d.nu_grid) ? d.nu_grid[g] : -1.0;
-      dh[k] = c_over_H0 * rsqrt(e2_of_z<MODEL, FDE>(d, wc, (double)g * d.step, nu));
+      dh[k] = c_over_H0 * rsqrt_pos(e2_of_z<MODEL, FDE>(d, wc, z[k], nu));
     } else {
-      dh[k] = g < G ? dh_of_node<MODEL, FDE>(d, wc, c_over_H0, g) : 0.0;
+      const int gc = g < G ? g : G - 1;  // evaluations past the grid repeat the last node and are discarded
+      z[k] = gc == G - 1 ? d.z_max : (double)gc * d.step;
+      const double nu = (MODEL == CF_EZ_PHYSICAL_D && d.nu_grid) ? d.nu_grid[gc] : -1.0;
+      const double v = c_over_H0 * rsqrt_pos(e2_of_z<MODEL, FDE>(d, wc, z[k], nu));
+      dh[k] = g < G ? v : 0.0;
     }
   }
-  // the node before the chunk: the neighbouring lane's last node; lane 0 of a wave re-evaluates it
-  double prev = __shfl_up(dh[CH - 1], 1, CF_WAVE);
-  if (lane == 0 && g0 > 0 && g0 <= G) prev = dh_of_node<MODEL, FDE>(d, wc, c_over_H0, g0 - 1);
+  double prev = dpp_move<0x138, 0xF>(dh[CH - 1]);  // wave_shr:1; lane 0 gets 0 and skips its first interval
+  double z_prev = (double)(g0 - 1) * d.step;       // g0 - 1 is never the last node
   double run = 0.0;
-  double z_prev = (double)(g0 - 1) * d.step;
 #pragma unroll
   for (int k = 0; k < CH; ++k) {
-    const int g = g0 + k;
-    if (INTERIOR) {
-      const double z_g = (double)g * d.step;
-      run += (prev + dh[k]) / 2 * (z_g - z_prev);
-      z_prev = z_g;
-    } else if (g >= 1 && g < G) {
-      const double dz = grid_z(g, G, d.step, d.z_max) - grid_z(g - 1, G, d.step, d.z_max);
-      run += (prev + dh[k]) / 2 * dz;
-    }
+    const double inc = (prev + dh[k]) / 2 * (z[k] - z_prev);
+    const bool take = INTERIOR ? (k > 0 || lane > 0) : ((k > 0 || lane > 0) && g0 + k < G);
+    run += take ? inc : 0.0;
     loc[k] = run;
     prev = dh[k];
+    z_prev = z[k];
   }
   return run;
 }
 
 template <int MODEL, int FDE, int CH>
 __device__ __forceinline__ void build_distance_table_regs(const cf_dev_desc& d, const WalkerCosmo& wc, d2* tab,
-                                                          double* wave_tot) {
+                                                          d4* wave_pub) {
   const int G = d.n_grid;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g0 = tid * CH;
@@ -299,11 +350,29 @@ __device__ __forceinline__ void build_distance_table_regs(const cf_dev_desc& d, 
   const double run = (wave_first > 0 && wave_last < G - 1)
                          ? chunk_eval<MODEL, FDE, CH, true>(d, wc, c_over_H0, g0, lane, dh, loc)
                          : chunk_eval<MODEL, FDE, CH, false>(d, wc, c_over_H0, g0, lane, dh, loc);
+  CF_WSTAMP(2);
   const double incl = wave_inclusive_scan(run);
-  if (lane == 63) wave_tot[wave] = incl;
+  // per wave: {sum of its intervals, dh of its first node, dh of its last node}
+  const double first_dh = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(dh[0])),
+                                           __builtin_amdgcn_readfirstlane(__double2loint(dh[0])));
+  if (lane == 63) wave_pub[wave] = (d4){incl, first_dh, dh[CH - 1], 0.0};
   __syncthreads();
-  double carry = incl - run;  // exclusive inside the wave
-  for (int w = 0; w < wave; ++w) carry += wave_tot[w];
+  CF_WSTAMP(3);
+  // exclusive prefix inside the wave + the earlier waves' sums + the wave-boundary intervals up to this wave
+  double carry = incl - run;
+  d4 pub[CF_TPB_A / 64];
+#pragma unroll
+  for (int v = 0; v < CF_TPB_A / 64; ++v) pub[v] = wave_pub[v];
+#pragma unroll
+  for (int v = 0; v < CF_TPB_A / 64; ++v) {
+    if (v >= 1) {
+      const int gb = v * 64 * CH;  // first node of wave v; the interval (gb - 1, gb) exists if gb < G
+      const double zb = gb == G - 1 ? d.z_max : (double)gb * d.step;
+      const double bnd = (pub[v - 1][2] + pub[v][1]) / 2 * (zb - (double)(gb - 1) * d.step);
+      carry += (v <= wave && gb < G) ? bnd : 0.0;
+    }
+    carry += v < wave ? pub[v][0] : 0.0;
+  }
 #pragma unroll
   for (int k = 0; k < CH; ++k)
     if (g0 + k < G) tab[base + k] = (d2){loc[k] + carry, dh[k]};
@@ -313,7 +382,8 @@ __device__ __forceinline__ void build_distance_table_regs(const cf_dev_desc& d, 
 // Same result for long grids (CH > 8 would not fit the register budget): the chunk lives in LDS.
 template <int MODEL, int FDE>
 __device__ __forceinline__ void build_distance_table_lds(const cf_dev_desc& d, const WalkerCosmo& wc, d2* tab,
-                                                         double* wave_tot) {
+                                                         d4* wave_pub) {
+  double* wave_tot = reinterpret_cast<double*>(wave_pub);
   const int G = d.n_grid, chs = d.chunk_shift, CH = 1 << chs;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g0 = tid << chs;
@@ -346,10 +416,10 @@ __device__ __forceinline__ void build_distance_table_lds(const cf_dev_desc& d, c
 
 template <int MODEL, int FDE>
 __device__ __forceinline__ void build_distance_table(const cf_dev_desc& d, const WalkerCosmo& wc, d2* tab,
-                                                     double* wave_tot) {
+                                                     d4* wave_pub) {
   // grids up to 4096 nodes (the reference uses 4000) take the register path, 8 nodes per thread
-  if (d.chunk_shift == 3) build_distance_table_regs<MODEL, FDE, 8>(d, wc, tab, wave_tot);
-  else build_distance_table_lds<MODEL, FDE>(d, wc, tab, wave_tot);
+  if (d.chunk_shift == 3) build_distance_table_regs<MODEL, FDE, 8>(d, wc, tab, wave_pub);
+  else build_distance_table_lds<MODEL, FDE>(d, wc, tab, wave_pub);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -433,28 +503,24 @@ __device__ __forceinline__ void sn_fast_loop(const cf_dev_desc& d, const DistTab
     r_pos = 1.0 / (1.0 + v100 / d.c);
     r_neg = 1.0 / (1.0 + (-v100) / d.c);
   }
-  int i = tid;
-  double zc = 0.0, st = 1.0, zh = 0.0, ob = 0.0;
-  if (i < n_sn) { zc = d.z_cmb[i]; st = d.sn_step[i]; zh = d.z_hel[i]; ob = d.obs[i]; }
-  for (; i < d.n_ld; i += CF_TPB_A) {
-    const int nx = i + CF_TPB_A;
-    double zc_n = 0.0, st_n = 1.0, zh_n = 0.0, ob_n = 0.0;
-    if (nx < n_sn) { zc_n = d.z_cmb[nx]; st_n = d.sn_step[nx]; zh_n = d.z_hel[nx]; ob_n = d.obs[nx]; }
-    double res = 0.0;
-    if (i < n_sn) {
-      double z_cosmo = zc;
-      if (d.has_vstep) {
-        if (PM1) {
-          z_cosmo = -1.0 + (1.0 + zc) * (st > 0.0 ? r_pos : r_neg);
-        } else {  // general weights (dipole fits): sn/pantheon.py:43-48 as written
-          const double z_pec = (v100 * st) / d.c;
-          z_cosmo = -1.0 + (1.0 + zc) / (1.0 + z_pec);
-        }
+  const d4* __restrict__ rec = reinterpret_cast<const d4*>(d.sn_rec) + tid;  // {z_cmb, step, z_hel, obs}
+  d4 cur = rec[0];
+  for (int i = tid; i < d.n_ld; i += CF_TPB_A) {
+    rec += CF_TPB_A;
+    const d4 nxt = rec[0];  // the record array carries 512 spare entries
+    const double zc = cur[0], st = cur[1], zh = cur[2], ob = cur[3];
+    double z_cosmo = zc;
+    if (d.has_vstep) {
+      if (PM1) {
+        z_cosmo = -1.0 + (1.0 + zc) * (st > 0.0 ? r_pos : r_neg);
+      } else {  // general weights (dipole fits): sn/pantheon.py:43-48 as written
+        const double z_pec = (v100 * st) / d.c;
+        z_cosmo = -1.0 + (1.0 + zc) / (1.0 + z_pec);
       }
-      res = ob - off - (25.0 + 5 * log10_pos((1.0 + zh) * hermite_tab(T, z_cosmo)));
     }
-    out[i] = res;  // rows >= n_sn are zero padding for the MFMA tiles / the 64-row blocks of the inverse-GEMM solve
-    zc = zc_n; st = st_n; zh = zh_n; ob = ob_n;
+    const double res = ob - off - (25.0 + 5 * log10_pos((1.0 + zh) * hermite_fast(T, z_cosmo)));
+    out[i] = i < n_sn ? res : 0.0;  // rows >= n_sn are zero padding for the MFMA tiles / the 64-row blocks of the inverse-GEMM solve
+    cur = nxt;
   }
 }
 
@@ -480,7 +546,7 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
               double* __restrict__ chi2_extra, double* __restrict__ dm_out, double* __restrict__ mucorr_out,
               double* __restrict__ blocks_out, double* __restrict__ bao_out) {
   extern __shared__ __align__(16) d2 lds_tab[];
-  __shared__ double wave_tot[16];
+  __shared__ __align__(16) d4 wave_pub[CF_TPB_A / 64];  // per-wave {interval sum, first dh, last dh} of the table build
   __shared__ double scratch[2 * CF_MAX_GL + 2 * CF_MAX_BAO + 2 * CF_MAX_CC + 8];
 
   const int64_t w = blockIdx.x;
@@ -488,6 +554,7 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
   const double* th = theta + w * d.ndim;
   const int tid = threadIdx.x;
 
+  CF_WSTAMP(0);
   const WalkerCosmo wc = make_cosmo(d, th);
   DistTable T;
   T.tab = lds_tab;
@@ -498,7 +565,9 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
   T.inv_last = d.inv_last;
   T.z_max = d.z_max;
 
-  if (d.n_sn > 0 || d.n_bao > 0) build_distance_table<MODEL, FDE>(d, wc, lds_tab, wave_tot);
+  CF_WSTAMP(1);
+  if (d.n_sn > 0 || d.n_bao > 0) build_distance_table<MODEL, FDE>(d, wc, lds_tab, wave_pub);
+  CF_WSTAMP(4);
 
   // ---- SN residual vector ----
   if (d.n_sn > 0) {
@@ -542,6 +611,7 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
       out[i] = res;  // rows >= n_sn are zero padding for the 16-row MFMA tiles
     }
   }
+  CF_WSTAMP(5);
   if (d.n_bao == 0 && d.cmb_mode == 0 && d.n_cc == 0) {
     if (tid == 0 && chi2_extra) chi2_extra[w] = 0.0;
     return;
@@ -987,7 +1057,7 @@ extern "C" int cf_debug_gemm_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cf_gemm_stamps), sizeof(cf_gemm_stamps));
 }
 #define CF_GSTAMP(k) \
-  if (blockIdx.x == 5 && lane == 0 && rb < 64) cf_gemm_stamps[(rb * 4 + g) * 4 + (k)] = __builtin_amdgcn_s_memtime()
+  if (px == 5 && lane == 0 && rb < 64) cf_gemm_stamps[(rb * 4 + g) * 4 + (k)] = __builtin_amdgcn_s_memtime()
 #else
 #define CF_GSTAMP(k)
 #endif
@@ -1001,15 +1071,22 @@ __global__ void __launch_bounds__(256)
 tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict__ theta, int64_t W,
                      const double* __restrict__ delta, int64_t w_pad, double* partial, unsigned int* arrivals,
                      const double* __restrict__ chi2_extra, double* __restrict__ out, int out_kind,
-                     unsigned long long* nonfinite, double* __restrict__ chi2_sn_out) {
+                     unsigned long long* nonfinite, double* __restrict__ chi2_sn_out, int panels_per_group) {
   __shared__ __align__(16) d4 part[4][4][64];  // [wave][tile][lane] of one 16-walker panel: 32 KB
   __shared__ double chi_tile[4][16 * NP];
   __shared__ unsigned int arrived_before;
   const int n_ld = d.n_ld;
   const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
   const int col = lane & 15, kq = lane >> 4;
-  const int rb = pk.n_rowblocks - 1 - (int)blockIdx.y;
-  const int64_t w0 = (int64_t)blockIdx.x * (16 * NP);
+  // 1-D grid, issued in this order: panel group (its residual rows stay in the XCDs' L2s while the group's row
+  // blocks pass) > row block, largest first > panel inside the group (consecutive ids = different XCDs, all on the
+  // same factor stream)
+  const int per_group = panels_per_group * pk.n_rowblocks;
+  const int grp = (int)blockIdx.x / per_group, rem_id = (int)blockIdx.x % per_group;
+  const int rb = pk.n_rowblocks - 1 - rem_id / panels_per_group;
+  const int px = grp * panels_per_group + rem_id % panels_per_group;
+  const int64_t w0 = (int64_t)px * (16 * NP);
+  if (w0 >= W) return;  // the last group may be partly empty
   const int nq = 2 * (rb + 1);  // K-step pairs per wave
   CF_GSTAMP(0);
   const d2* A = pk.frags + pk.off[rb * 4 + g] * 64 + lane;
@@ -1100,12 +1177,12 @@ tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict_
                          __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): the stores have left this CU
     if (lane == 0)
-      arrived_before = __hip_atomic_fetch_add(&arrivals[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      arrived_before = __hip_atomic_fetch_add(&arrivals[px], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   CF_GSTAMP(3);
   lds_barrier();
   if (arrived_before != (unsigned)pk.n_rowblocks - 1u) return;
-  if (tid == 0) __hip_atomic_store(&arrivals[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) __hip_atomic_store(&arrivals[px], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (tid < 16 * NP && w0 + tid < W) {
     const int64_t w = w0 + tid;
     double c2 = 0.0;
@@ -1120,7 +1197,7 @@ tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict_
 #define CF_INSTANTIATE_TRIGEMM(NP, PF)                                                                                   \
   template __global__ void tri_gemm_chi2_kernel<NP, PF>(cf_dev_desc, cf_dev_invpack, const double*, int64_t, const double*, \
                                                         int64_t, double*, unsigned int*, const double*, double*, int,   \
-                                                        unsigned long long*, double*);
+                                                        unsigned long long*, double*, int);
 CF_INSTANTIATE_TRIGEMM(1, 2)
 CF_INSTANTIATE_TRIGEMM(1, 4)
 CF_INSTANTIATE_TRIGEMM(2, 2)
