@@ -28,9 +28,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix (= vector) datasheet peak: 256 CU x 4 SIMD x 2048 flop / 64 clk x 2.4 GHz
-# What v_mfma_f64_16x16x4_f64 actually sustains on this chip, every SIMD saturated with 4-8 waves of
-# nothing but independent MFMAs (profiles/r01_mfma_f64_rate_sweep.txt): ~105 cycles per MFMA per SIMD.
-FP64_MFMA_MEASURED_TFLOPS = 47.0
+# What v_mfma_f64_16x16x4_f64 sustains on this chip with every SIMD issuing nothing but independent MFMAs from
+# registers, 4 waves per SIMD (tools/coexec_f64_rate.hip, profiles/r01_coexec_f64_rate.txt): the pipe takes one per
+# 64 cycles and the chip then holds 2.15-2.2 GHz: 66.5 TFLOP/s on one device of the pool, 70.9 on another.  A kernel that also moves data holds a lower clock.
+FP64_MFMA_MEASURED_TFLOPS = 67.0
 
 
 def flops_per_eval_solve(n):
@@ -155,6 +156,7 @@ def main():
     assert np.all(np.isfinite(result)), "in-box walkers must give a finite log-probability"
 
     if rank == 0:
+        solve_kernel = "tri_gemm_chi2_kernel" if eng.info()["solve_mode"] == pkg.CF_SOLVE_INVERSE_GEMM else "trsm_chi2_kernel"
         resid_ms = float(np.mean([a for a, _ in kms]))
         solve_ms = float(np.mean([b for _, b in kms]))
         solve_flops = flops_per_eval_solve(args.n_sn) * Wl
@@ -183,19 +185,19 @@ def main():
                 "parallelism": f"walkers sharded over {world} GPU(s)" + (", RCCL all-gather of positions per step" if world > 1 else ""),
             },
             "roofline": {
-                "kernel": "trsm_chi2_kernel",
+                "kernel": solve_kernel,
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                "traffic": pmc_traffic(args.n_sn, Wl),
+                "traffic": pmc_traffic(args.n_sn, Wl, solve_kernel),
                 "flops_per_launch": solve_flops,
                 "avg_kernel_ms": solve_ms,
                 "measured_mfma_f64_ceiling": FP64_MFMA_MEASURED_TFLOPS,
                 "frac_of_measured_ceiling": achieved / FP64_MFMA_MEASURED_TFLOPS,
             },
-            "kernels_ms": {"walker_kernel": resid_ms, "trsm_chi2_kernel": solve_ms},
+            "kernels_ms": {"walker_kernel": resid_ms, solve_kernel: solve_ms},
         }
         if world == 1 and args.workload == "pantheon":
             # the ctypes boundary as emcee / nautilus call it: host numpy in, host numpy out (PCIe + sync included).
@@ -217,13 +219,13 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(n_sn, walkers):
-    """HBM bytes per launch of trsm_chi2_kernel from the committed PMC profile of THIS configuration
+def pmc_traffic(n_sn, walkers, kernel):
+    """HBM bytes per launch of the solve kernel from the committed PMC profile of THIS configuration
     (tools/pmc_profile.sh: separate --pmc passes, gfx950 FETCH_SIZE correction); None when there is none."""
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
         if prof["config"]["n_sn"] == n_sn and prof["config"]["walkers_per_gpu"] == walkers:
-            return prof["kernels"]["trsm_chi2_kernel"]["hbm_bytes_per_launch"]
+            return prof["kernels"][kernel]["hbm_bytes_per_launch"]
     except Exception:
         pass
     return None

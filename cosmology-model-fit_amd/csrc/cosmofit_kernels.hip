@@ -808,8 +808,9 @@ __device__ double finalize_value(const cf_dev_desc& d, const double* __restrict_
 // C/D register r: row = (l>>4) + 4r, col = l&15.  Hence register r of a solved 16x16 tile IS the
 // B fragment of K-step r of that tile: Y tiles go back into the product with no lane movement.
 //
-// One wave issues an independent f64 MFMA only every ~140 cycles while the pipe takes one per 64
-// (profiles/r01_mfma_f64_rate.txt), so the workgroup runs NW = 4*KS waves (KS = 2: two per SIMD):
+// A panel is one dependent chain of block rows, so it stays on one CU; the workgroup runs NW = 4*KS
+// waves (KS = 2: two per SIMD, the MFMA pipe takes one instruction per 64 cycles and a single wave's
+// loads and LDS round trips leave it idle):
 // in the update phase wave (wq = wave&3, g = wave>>2) owns the tiles wq, wq+4, wq+8, wq+12 of the
 // 256-row block row and the K range [g, g+1) * (r0/KS); the KS partial right-hand sides meet in
 // LDS, and the diagonal phase (rhs times the pre-inverted diagonal block) is spread over all NW

@@ -6,6 +6,6 @@ for grp in "$@"; do
   python - <<PY
 import json
 d=json.load(open("gpurun_out/gg_$grp.json"))
-print("[group $grp] evals/s=%.3e ms/step=%.3f walker=%.3f ms solve=%.3f ms (%.1f TF)"%(d["value"],d["ms_per_step"],d["kernels_ms"]["walker_kernel"],d["kernels_ms"]["trsm_chi2_kernel"],d["roofline"]["achieved"]))
+print("[group $grp] evals/s=%.3e ms/step=%.3f walker=%.3f ms solve=%.3f ms (%.1f TF)"%(d["value"],d["ms_per_step"],d["kernels_ms"]["walker_kernel"],d["kernels_ms"][d["roofline"]["kernel"]],d["roofline"]["achieved"]))
 PY
 done

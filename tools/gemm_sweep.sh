@@ -6,7 +6,7 @@ python - <<PY
 import json
 try:
     d=json.load(open("gpurun_out/gs_$tag.json"))
-    print("[$tag] evals/s=%.3e ms/step=%.3f walker=%.3f ms solve=%.3f ms (%.1f TF)"%(d["value"],d["ms_per_step"],d["kernels_ms"]["walker_kernel"],d["kernels_ms"]["trsm_chi2_kernel"],d["roofline"]["achieved"]))
+    print("[$tag] evals/s=%.3e ms/step=%.3f walker=%.3f ms solve=%.3f ms (%.1f TF)"%(d["value"],d["ms_per_step"],d["kernels_ms"]["walker_kernel"],d["kernels_ms"][d["roofline"]["kernel"]],d["roofline"]["achieved"]))
 except Exception as e: print("[$tag] no result", e)
 PY
 }

@@ -24,7 +24,7 @@ import json
 traffic = {}
 for k, cs in acc.items():
     if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
-        name = "trsm_chi2_kernel" if "trsm" in k else ("walker_kernel" if ("sn_residual" in k or "walker" in k) else None)
+        name = "trsm_chi2_kernel" if "trsm" in k else ("tri_gemm_chi2_kernel" if "tri_gemm" in k else ("walker_kernel" if "walker" in k else None))
         if name:
             f = cs["FETCH_SIZE"][2:] or cs["FETCH_SIZE"]
             w = cs["WRITE_SIZE"][2:] or cs["WRITE_SIZE"]

@@ -17,5 +17,5 @@ timeout -k 10 300 python bench.py --steps 30 --warmup 3 --no-cpu-baseline > gpur
 python - <<PY
 import json
 d=json.load(open("gpurun_out/qb_$tag.json"))
-print("[$tag] evals/s=%.3e ms/step=%.3f resid=%.3f ms solve=%.3f ms (%.1f TF, %.1f%%)"%(d["value"],d["ms_per_step"],d["kernels_ms"]["walker_kernel"],d["kernels_ms"]["trsm_chi2_kernel"],d["roofline"]["achieved"],100*d["roofline"]["frac"]))
+print("[$tag] evals/s=%.3e ms/step=%.3f resid=%.3f ms solve=%.3f ms (%.1f TF, %.1f%%)"%(d["value"],d["ms_per_step"],d["kernels_ms"]["walker_kernel"],d["kernels_ms"][d["roofline"]["kernel"]],d["roofline"]["achieved"],100*d["roofline"]["frac"]))
 PY
