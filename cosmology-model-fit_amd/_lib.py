@@ -105,6 +105,7 @@ EXPORTS = {
     "cf_solve_triangular": (C.c_int, [_VP, _I64, _I64, _VP, _I64, _VP]),
     "cf_selftest_invpack_host": (C.c_int, [_VP, _I64, _I64, _VP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "cf_selftest_log10": (C.c_int, [_VP, _I64, _VP]),
+    "cf_selftest_log10_tab": (C.c_int, [_VP, _I64, _VP]),
     "cf_selftest_pack_host": (C.c_int, [_VP, _I64, _I64, _VP, C.POINTER(C.c_double), C.POINTER(_I64)]),
 }
 

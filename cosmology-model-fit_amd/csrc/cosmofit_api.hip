@@ -69,7 +69,7 @@ extern "C" __global__ void finalize_kernel(cf_dev_desc d, const double* theta, i
                                            double* out, int out_kind, unsigned long long* nonfinite);
 extern "C" __global__ void interp_kernel(const double* xq, int64_t nq, const double* x, const double* y,
                                          const double* yp, int64_t n, double* out, int mode);
-extern "C" __global__ void log10_selftest_kernel(const double* x, int64_t n, double* out);
+extern "C" __global__ void log10_selftest_kernel(const double* x, int64_t n, double* out, int mode, const cf_d2* tab);
 extern "C" __global__ void pad_rhs_kernel(const double* b, int64_t nrhs, int64_t n, int64_t n_ld, double* delta);
 
 // ------------------------------------------------------------------------------------------------
@@ -198,7 +198,7 @@ struct cf_handle {
   int64_t timed_calls = 0;
   cf_dev_desc d{};
   PackedFactor pack;
-  DevBuf z_cmb, z_hel, obs, sn_step, sn_rec;
+  DevBuf z_cmb, z_hel, obs, sn_step, sn_rec, log10_tab;
   DevBuf bao_z, bao_val, bao_inv_cov, bao_qty, gl_x, gl_w, fixed_mu, cc_z, cc_h, cc_inv_cov, nu_grid;
   DevBuf theta, out, delta, ypk, chi2_extra, nonfinite;
   bool has_small_blocks = false;  // BAO and / or CMB block present
@@ -222,6 +222,20 @@ extern "C" int cf_device_count(void) {
 static int upload_vec(DevBuf& b, const double* src, int64_t n) {
   if (b.ensure((size_t)n * 8)) return CF_ERR_HIP;
   HIP_TRY(hipMemcpy(b.p, src, (size_t)n * 8, hipMemcpyHostToDevice));
+  return 0;
+}
+
+// Reduction table of log10_tab (cosmofit_kernels.hip): 64 cells of [0.5, 1), {1 / centre, log10 centre}, each
+// correctly rounded from extended precision.
+static int upload_log10_table(DevBuf& b) {
+  cf_d2 t[64];
+  for (int j = 0; j < 64; ++j) {
+    const long double c = 0.5L * (1.0L + ((long double)j + 0.5L) / 64.0L);
+    t[j].x = (double)(1.0L / c);
+    t[j].y = (double)log10l(c);
+  }
+  if (b.ensure(sizeof(t))) return CF_ERR_HIP;
+  HIP_TRY(hipMemcpy(b.p, t, sizeof(t), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -415,12 +429,16 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
     d.sn_step = h->sn_step.as<const double>();
     {
       // one record per SN for the production loop; 512 spare records so that its look-ahead needs no bounds check
-      std::vector<cf_d4> rec((size_t)d.n_ld + 512, cf_d4{0.0, 1.0, 0.0, 0.0});
-      for (int64_t i = 0; i < c->n_sn; ++i) rec[i] = cf_d4{c->sn_z_cmb[i], step[i], c->sn_z_hel[i], c->sn_obs[i]};
+      std::vector<cf_d4> rec((size_t)d.n_ld + 512, cf_d4{1.0, 1.0, 1.0, 0.0});
+      for (int64_t i = 0; i < c->n_sn; ++i)
+        rec[i] = cf_d4{d.has_vstep ? 1.0 + c->sn_z_cmb[i] : c->sn_z_cmb[i], step[i], 1.0 + c->sn_z_hel[i], c->sn_obs[i]};
       if (h->sn_rec.ensure(rec.size() * sizeof(cf_d4))) return bail(CF_ERR_HIP);
       if (hipMemcpy(h->sn_rec.p, rec.data(), rec.size() * sizeof(cf_d4), hipMemcpyHostToDevice) != hipSuccess)
         return bail(fail(CF_ERR_HIP, "hipMemcpy(sn_rec) failed"));
       d.sn_rec = h->sn_rec.as<const cf_d4>();
+      int rc2;
+      if ((rc2 = upload_log10_table(h->log10_tab))) return bail(rc2);
+      d.log10_tab = h->log10_tab.p;
     }
     for (int64_t i = 0; i < c->n_sn; ++i) {
       const double piv = c->sn_chol[i * c->sn_chol_ld + i];
@@ -875,19 +893,25 @@ extern "C" int cf_selftest_invpack_host(const double* L, int64_t n, int64_t ld, 
   return CF_OK;
 }
 
-// Self-test of the in-kernel log10 (device): out[k] = log10_pos(x[k]).
-extern "C" int cf_selftest_log10(const double* x, int64_t n, double* out) {
-  if (!x || !out || n < 0) return fail(CF_ERR_INVALID, "cf_selftest_log10: bad argument");
-  if (cf_device_count() == 0) return fail(CF_ERR_NO_DEVICE, "cf_selftest_log10: no HIP device visible");
+// Self-tests of the in-kernel log10 routines (device): out[k] = log10_pos(x[k]) / log10_tab(x[k]).
+static int selftest_log10(const double* x, int64_t n, double* out, int mode, const char* fn) {
+  if (!x || !out || n < 0) return fail(CF_ERR_INVALID, std::string(fn) + ": bad argument");
+  if (cf_device_count() == 0) return fail(CF_ERR_NO_DEVICE, std::string(fn) + ": no HIP device visible");
   if (n == 0) return CF_OK;
-  DevBuf dx, dout;
+  DevBuf dx, dout, tab;
   if (dx.ensure((size_t)n * 8) || dout.ensure((size_t)n * 8)) return CF_ERR_HIP;
+  int rc;
+  if ((rc = upload_log10_table(tab))) return rc;
   HIP_TRY(hipMemcpy(dx.p, x, (size_t)n * 8, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(log10_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dx.as<const double>(), n,
-                     dout.as<double>());
+                     dout.as<double>(), mode, tab.as<const cf_d2>());
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * 8, hipMemcpyDeviceToHost));
   return CF_OK;
+}
+extern "C" int cf_selftest_log10(const double* x, int64_t n, double* out) { return selftest_log10(x, n, out, 0, "cf_selftest_log10"); }
+extern "C" int cf_selftest_log10_tab(const double* x, int64_t n, double* out) {
+  return selftest_log10(x, n, out, 1, "cf_selftest_log10_tab");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -66,7 +66,9 @@ struct cf_dev_desc {
   const double* z_hel;
   const double* obs;
   const double* sn_step;
-  const cf_d4* sn_rec;  // [n_ld + 512] {z_cmb, step, z_hel, obs} per SN, one 32-byte record (the production SN loop); padding {0, 1, 0, 0}
+  const cf_d4* sn_rec;  // [n_ld + 512] {has_vstep ? 1 + z_cmb : z_cmb, step, 1 + z_hel, obs} per SN, one 32-byte record (the
+                        // production SN loop); padding {1, 1, 1, 0}
+  const void* log10_tab;  // cf_d2[64] {1 / c_j, log10 c_j}: reduction table of the production loop's log10
   int32_t has_vstep;  // 0: the likelihood has no peculiar-velocity step (z_cosmo = z_cmb)
   int32_t step_pm1;   // 1: every sn_step entry is +1 or -1
   const double* sn_fixed_mu;  // [n_sn] or null; non-NaN entries replace mu_theory (SH0ES calibrators)

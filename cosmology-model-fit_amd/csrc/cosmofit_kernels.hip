@@ -204,7 +204,8 @@ __device__ __forceinline__ double hermite_tab(const DistTable& T, double xi) {
 // x[i] < xi <= x[i+1] at the ulp level: at a node both neighbouring cubics give the node value (C1 interpolant), so
 // an xi within rounding of a node may use either; t = xi/step - i instead of (xi - x_i)/h_i and h = step also in
 // the last interval (z_max vs (G-1)*step: a rounding apart) move the result by ~1e-14 relative, far inside the
-// 1e-10 bar (tests/test_gpu_parity.py).  ~45 instructions fewer per supernova than hermite_tab.
+// 1e-10 bar (tests/test_gpu_parity.py).  With the cubic in Horner form ~55 instructions fewer per supernova than
+// hermite_tab.
 __device__ __forceinline__ double hermite_fast(const DistTable& T, double xi) {
   const int G = T.G;
   if (xi <= 0.0) {
@@ -219,13 +220,13 @@ __device__ __forceinline__ double hermite_fast(const DistTable& T, double xi) {
   int i = (int)u;
   i = i > G - 2 ? G - 2 : i;
   const double t = u - (double)i;
-  const double t2 = t * t, t3 = t2 * t;
-  const double h00 = 2 * t3 - 3 * t2 + 1;
-  const double h10 = t3 - 2 * t2 + t;
-  const double h01 = -2 * t3 + 3 * t2;
-  const double h11 = t3 - t2;
   const d2 e0 = T.at(i), e1 = T.at(i + 1);
-  return h00 * e0.x + h10 * T.step * e0.y + h01 * e1.x + h11 * T.step * e1.y;
+  // the same cubic in powers of t: y0 + t (h m0 + t (c + t d)), c = 3 dy - h (2 m0 + m1), d = h (m0 + m1) - 2 dy
+  const double b = T.step * e0.y, hm1 = T.step * e1.y, dy = e1.x - e0.x;
+  const double sm = b + hm1;
+  const double dd = fma(-2.0, dy, sm);
+  const double cc = fma(3.0, dy, -(sm + b));
+  return fma(t, fma(t, fma(t, dd, cc), b), e0.x);
 }
 
 // log10 for positive, finite, normal arguments (distances in Mpc): the fdlibm / msun algorithm
@@ -267,6 +268,34 @@ __device__ __forceinline__ double log10_pos(double x) {
   const double ww = y2 + val_hi;
   val_lo += (y2 - ww) + val_hi;
   return val_lo + ww;
+}
+
+// log10 for the production SN loop (distances in Mpc): table-driven reduction instead of the long polynomial.
+// x = m 2^e, m in [0.5, 1); c_j = centre of the j-th of 64 equal cells of [0.5, 1); r = m / c_j - 1, |r| <= 1/128;
+//   log10 x = e log10(2) + log10(c_j) + log1p(r) / ln 10,      log1p by its Taylor series to r^8 (next term 5e-21).
+// tab[j] = {1 / c_j, log10 c_j}, correctly rounded from long double on the host (cf_create), 1 KiB, staged in LDS.
+// Absolute error <= ~2e-16 max(1, |log10 x|) (cf_selftest_log10, mode 1): what a distance modulus needs.  Near x = 1
+// the RELATIVE error is not bounded by ulps (e log10(2) + log10 c_j cancel), which is why mu_corr = 5 log10(ratio ~ 1)
+// of the accessor / calibrator paths stays on log10_pos.  ~20 instructions instead of ~48.
+__device__ __forceinline__ double log10_tab(double x, const d2* __restrict__ tab) {
+  if (!(x > 2.2250738585072014e-308 && x < 1.7976931348623157e308)) return log10(x);
+  const double C1 = 4.34294481903251827651e-01, C2 = -2.17147240951625913826e-01, C3 = 1.44764827301083942550e-01,
+               C4 = -1.08573620475812956913e-01, C5 = 8.68588963806503655303e-02, C6 = -7.23824136505419712752e-02,
+               C7 = 6.20420688433216896645e-02, C8 = -5.42868102379064784564e-02;
+  const double log10_2hi = 3.01029995663611771306e-01, log10_2lo = 3.69423907715893078616e-13;
+  const int e = __builtin_amdgcn_frexp_exp(x);
+  const double m = __builtin_amdgcn_frexp_mant(x);
+  const d2 t = tab[(__double2hiint(m) >> 14) & 63];
+  const double r = fma(m, t.x, -1.0);
+  double p = fma(C8, r, C7);
+  p = fma(p, r, C6);
+  p = fma(p, r, C5);
+  p = fma(p, r, C4);
+  p = fma(p, r, C3);
+  p = fma(p, r, C2);
+  p = fma(p, r, C1);
+  const double ek = (double)e;
+  return fma(ek, log10_2hi, t.y) + fma(r, p, ek * log10_2lo);
 }
 
 // Inclusive scan across the 64 lanes of a wave on DPP row operations (no LDS round trips, unlike
@@ -323,16 +352,27 @@ __device__ __forceinline__ double chunk_eval(const cf_dev_desc& d, const WalkerC
     }
   }
   double prev = dpp_move<0x138, 0xF>(dh[CH - 1]);  // wave_shr:1; lane 0 gets 0 and skips its first interval
-  double z_prev = (double)(g0 - 1) * d.step;       // g0 - 1 is never the last node
   double run = 0.0;
+  if (INTERIOR) {
+    // the reference's np.diff(z_grid) is `step` up to the rounding of i*step (1 ulp of z, i.e. <= 4e-13 of step,
+    // and the deviations telescope): half the nominal step as one factor saves three operations per node
+    const double half = 0.5 * d.step;
 #pragma unroll
-  for (int k = 0; k < CH; ++k) {
-    const double inc = (prev + dh[k]) / 2 * (z[k] - z_prev);
-    const bool take = INTERIOR ? (k > 0 || lane > 0) : ((k > 0 || lane > 0) && g0 + k < G);
-    run += take ? inc : 0.0;
-    loc[k] = run;
-    prev = dh[k];
-    z_prev = z[k];
+    for (int k = 0; k < CH; ++k) {
+      run = (k > 0 || lane > 0) ? fma(prev + dh[k], half, run) : run;
+      loc[k] = run;
+      prev = dh[k];
+    }
+  } else {
+    double z_prev = (double)(g0 - 1) * d.step;  // g0 - 1 is never the last node
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const double inc = (prev + dh[k]) / 2 * (z[k] - z_prev);
+      run += ((k > 0 || lane > 0) && g0 + k < G) ? inc : 0.0;
+      loc[k] = run;
+      prev = dh[k];
+      z_prev = z[k];
+    }
   }
   return run;
 }
@@ -495,30 +535,31 @@ __device__ double r_drag_fit(const double* f, double wb, double wm) {
 // (<= 1 ulp of 1+z_cosmo away from the quotient form).
 // ------------------------------------------------------------------------------------------------
 template <bool PM1>
-__device__ __forceinline__ void sn_fast_loop(const cf_dev_desc& d, const DistTable& T, double* __restrict__ out,
-                                             double off, double v100, int tid) {
+__device__ __forceinline__ void sn_fast_loop(const cf_dev_desc& d, const DistTable& T, const d2* __restrict__ log_tab,
+                                             double* __restrict__ out, double off, double v100, int tid) {
   const int n_sn = d.n_sn;
   double r_pos = 1.0, r_neg = 1.0;
   if (PM1 && d.has_vstep) {
     r_pos = 1.0 / (1.0 + v100 / d.c);
     r_neg = 1.0 / (1.0 + (-v100) / d.c);
   }
-  const d4* __restrict__ rec = reinterpret_cast<const d4*>(d.sn_rec) + tid;  // {z_cmb, step, z_hel, obs}
+  // {has_vstep ? 1 + z_cmb : z_cmb, step, 1 + z_hel, obs}: the two sums are the reference's own first operations
+  const d4* __restrict__ rec = reinterpret_cast<const d4*>(d.sn_rec) + tid;
   d4 cur = rec[0];
   for (int i = tid; i < d.n_ld; i += CF_TPB_A) {
     rec += CF_TPB_A;
     const d4 nxt = rec[0];  // the record array carries 512 spare entries
-    const double zc = cur[0], st = cur[1], zh = cur[2], ob = cur[3];
-    double z_cosmo = zc;
+    const double za = cur[0], st = cur[1], zhp1 = cur[2], ob = cur[3];
+    double z_cosmo = za;
     if (d.has_vstep) {
       if (PM1) {
-        z_cosmo = -1.0 + (1.0 + zc) * (st > 0.0 ? r_pos : r_neg);
+        z_cosmo = -1.0 + za * (st > 0.0 ? r_pos : r_neg);
       } else {  // general weights (dipole fits): sn/pantheon.py:43-48 as written
         const double z_pec = (v100 * st) / d.c;
-        z_cosmo = -1.0 + (1.0 + zc) / (1.0 + z_pec);
+        z_cosmo = -1.0 + za / (1.0 + z_pec);
       }
     }
-    const double res = ob - off - (25.0 + 5 * log10_pos((1.0 + zh) * hermite_fast(T, z_cosmo)));
+    const double res = ob - off - (25.0 + 5 * log10_tab(zhp1 * hermite_fast(T, z_cosmo), log_tab));
     out[i] = i < n_sn ? res : 0.0;  // rows >= n_sn are zero padding for the MFMA tiles / the 64-row blocks of the inverse-GEMM solve
     cur = nxt;
   }
@@ -548,6 +589,7 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
   extern __shared__ __align__(16) d2 lds_tab[];
   __shared__ __align__(16) d4 wave_pub[CF_TPB_A / 64];  // per-wave {interval sum, first dh, last dh} of the table build
   __shared__ double scratch[2 * CF_MAX_GL + 2 * CF_MAX_BAO + 2 * CF_MAX_CC + 8];
+  __shared__ __align__(16) d2 log_tab[64];  // log10_tab's reduction table; the table build's barriers order the fill
 
   const int64_t w = blockIdx.x;
   if (w >= W) return;
@@ -555,6 +597,7 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
   const int tid = threadIdx.x;
 
   CF_WSTAMP(0);
+  if (tid < 64 && d.n_sn > 0) log_tab[tid] = reinterpret_cast<const d2*>(d.log10_tab)[tid];
   const WalkerCosmo wc = make_cosmo(d, th);
   DistTable T;
   T.tab = lds_tab;
@@ -576,8 +619,8 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
     const double v100 = 100 * slot_get(d, CF_P_V_D, th);
     const bool parts = dm_out != nullptr || mucorr_out != nullptr;
     if (!parts && !d.sn_fixed_mu) {
-      if (d.step_pm1) sn_fast_loop<true>(d, T, out, off, v100, tid);
-      else sn_fast_loop<false>(d, T, out, off, v100, tid);
+      if (d.step_pm1) sn_fast_loop<true>(d, T, log_tab, out, off, v100, tid);
+      else sn_fast_loop<false>(d, T, log_tab, out, off, v100, tid);
     } else
     for (int i = tid; i < d.n_ld; i += CF_TPB_A) {
       double res = 0.0;
@@ -1283,9 +1326,11 @@ extern "C" __global__ void interp_kernel(const double* __restrict__ xq, int64_t 
 }
 
 // Self-test hook: the in-kernel log10 on arbitrary inputs (tests/test_gpu_parity.py checks its ulp error).
-extern "C" __global__ void log10_selftest_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ out) {
+// mode 0: log10_pos; mode 1: log10_tab with the table at `tab`
+extern "C" __global__ void log10_selftest_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ out, int mode,
+                                                 const cf_d2* __restrict__ tab) {
   const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (k < n) out[k] = log10_pos(x[k]);
+  if (k < n) out[k] = mode == 0 ? log10_pos(x[k]) : log10_tab(x[k], reinterpret_cast<const d2*>(tab));
 }
 
 // Copy right-hand sides b[nrhs][n] into the padded residual layout Delta[nrhs_pad][n_pad].

@@ -300,8 +300,11 @@ int cf_selftest_pack_host(const double* L, int64_t n, int64_t ld, const double* 
 int cf_selftest_invpack_host(const double* L, int64_t n, int64_t ld, const double* b, double* chi2_out,
                              double* probe_out);
 
-/* Device self-test of the in-kernel log10 used for the distance moduli: out[k] = log10(x[k]). */
+/* Device self-tests of the two in-kernel log10 routines: out[k] = log10(x[k]).  cf_selftest_log10: the <= 1 ulp
+ * routine of the accessor / calibrator paths (mu_corr = 5 log10 of a ratio near 1); cf_selftest_log10_tab: the
+ * table-driven routine of the production SN loop (absolute error ~2e-16 max(1, |log10 x|)). */
 int cf_selftest_log10(const double* x, int64_t n, double* out);
+int cf_selftest_log10_tab(const double* x, int64_t n, double* out);
 
 #ifdef __cplusplus
 }

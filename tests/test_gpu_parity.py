@@ -252,6 +252,31 @@ def test_in_kernel_log10_is_within_one_ulp(gpu):
     assert out[-5] == -np.inf and np.isnan(out[-4]) and out[-3] == np.inf and np.isnan(out[-2])
 
 
+def test_production_loop_log10_absolute_error(gpu):
+    """log10_tab (table-driven, production SN loop): what a distance modulus needs is ABSOLUTE accuracy of 5 log10(d)
+    at the 1e-15 level on mu ~ 25..45; bound it at 3e-16 max(1, |log10 x|) over the whole double range."""
+    import ctypes as C
+    from decimal import Decimal, getcontext
+    rng = np.random.default_rng(1)
+    x = np.concatenate([np.exp(rng.uniform(np.log(1e-3), np.log(1e6), 400000)), np.exp(rng.uniform(-700, 700, 100000)),
+                        1.0 + rng.uniform(-1e-3, 1e-3, 2000), [1.0, 10.0, 1e5, 0.5, 2.0, 0.999999, 1.000001],
+                        [0.0, -1.0, np.inf, np.nan, 5e-324]])
+    out = np.empty_like(x)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    gpu._lib.check(gpu.lib().cf_selftest_log10_tab(p(x), x.size, p(out)))
+    with np.errstate(all="ignore"):
+        ref = np.log10(x)
+    fin = np.isfinite(ref)
+    err = np.abs(out[fin] - ref[fin]) / np.maximum(1.0, np.abs(ref[fin]))
+    assert err.max() <= 3e-16, f"max scaled error {err.max():.3e}"
+    # numpy's own log10 is good to ~1 ulp; pin a handful of points against 40-digit arithmetic
+    getcontext().prec = 40
+    for k in rng.integers(0, 400000, 50):
+        exact = float(Decimal(float(x[k])).log10())
+        assert abs(out[k] - exact) <= 3e-16 * max(1.0, abs(exact))
+    assert out[-5] == -np.inf and np.isnan(out[-4]) and out[-3] == np.inf and np.isnan(out[-2])
+
+
 def test_ill_conditioned_factor_is_refused_not_silently_wrong(gpu, config2):
     lk, _, _ = config2
     assert lk.engine.info()["pack_probe_rel"] < 1e-13  # well-conditioned synthetic Pantheon+ factor
