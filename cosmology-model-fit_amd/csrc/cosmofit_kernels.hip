@@ -398,21 +398,24 @@ __device__ __forceinline__ void build_distance_table_regs(const cf_dev_desc& d, 
   if (lane == 63) wave_pub[wave] = (d4){incl, first_dh, dh[CH - 1], 0.0};
   __syncthreads();
   CF_WSTAMP(3);
-  // exclusive prefix inside the wave + the earlier waves' sums + the wave-boundary intervals up to this wave
-  double carry = incl - run;
-  d4 pub[CF_TPB_A / 64];
-#pragma unroll
-  for (int v = 0; v < CF_TPB_A / 64; ++v) pub[v] = wave_pub[v];
-#pragma unroll
-  for (int v = 0; v < CF_TPB_A / 64; ++v) {
-    if (v >= 1) {
-      const int gb = v * 64 * CH;  // first node of wave v; the interval (gb - 1, gb) exists if gb < G
+  // exclusive prefix inside the wave + the earlier waves' sums + the wave-boundary intervals up to this wave:
+  // lane v < 8 forms wave v's contribution, a DPP row reduction adds the eight, lane 7 broadcasts the sum
+  double term = 0.0;
+  if (lane < CF_TPB_A / 64) {
+    const d4 pv = wave_pub[lane];
+    term = lane < wave ? pv[0] : 0.0;
+    if (lane >= 1) {
+      const int gb = lane * 64 * CH;  // first node of wave `lane`; the interval (gb - 1, gb) exists if gb < G
       const double zb = gb == G - 1 ? d.z_max : (double)gb * d.step;
-      const double bnd = (pub[v - 1][2] + pub[v][1]) / 2 * (zb - (double)(gb - 1) * d.step);
-      carry += (v <= wave && gb < G) ? bnd : 0.0;
+      const double bnd = (wave_pub[lane - 1][2] + pv[1]) / 2 * (zb - (double)(gb - 1) * d.step);
+      term += (lane <= wave && gb < G) ? bnd : 0.0;
     }
-    carry += v < wave ? pub[v][0] : 0.0;
   }
+  term += dpp_move<0x111, 0xF>(term);  // row_shr:1
+  term += dpp_move<0x112, 0xF>(term);  // row_shr:2
+  term += dpp_move<0x114, 0xF>(term);  // row_shr:4 -> lane 7 holds lanes 0..7
+  const double carry = (incl - run) + __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(term), 7),
+                                                       __builtin_amdgcn_readlane(__double2loint(term), 7));
 #pragma unroll
   for (int k = 0; k < CH; ++k)
     if (g0 + k < G) tab[base + k] = (d2){loc[k] + carry, dh[k]};
