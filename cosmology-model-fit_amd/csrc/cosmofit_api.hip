@@ -23,20 +23,32 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define CF_YPK_SLACK 8192
 #define CF_DELTA_SLACK 4096  // the inverse-GEMM pipeline prefetches a few K-step pairs past the last residual row
 
+#define CF_BAO_NODES 6  // table nodes copied out per BAO datum (cosmofit_kernels.hip)
 template <int MODEL, int FDE>
-__global__ void walker_kernel(cf_dev_desc d, const double* theta, int64_t W, double* delta, double* chi2_extra,
-                              double* dm_out, double* mucorr_out, double* blocks_out, double* bao_out);
-#define CF_DECLARE_WALKER(M, F)                                                                                        \
-  extern template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, \
-                                                      double*, double*, double*);
+__global__ void walker_kernel(cf_dev_desc d, const double* theta, int64_t W, double* delta, double* dm_out, double* mucorr_out,
+                              d2* bao_nodes);
+template <int MODEL, int FDE>
+__global__ void small_blocks_kernel(cf_dev_desc d, const double* theta, int64_t W, const d2* bao_nodes, double* chi2_extra,
+                                    double* blocks_out, double* bao_out);
+#define CF_DECLARE_WALKER(M, F)                                                                                            \
+  extern template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*); \
+  extern template __global__ void small_blocks_kernel<M, F>(cf_dev_desc, const double*, int64_t, const d2*, double*,       \
+                                                            double*, double*);
 CF_DECLARE_WALKER(0, 0) CF_DECLARE_WALKER(0, 1) CF_DECLARE_WALKER(0, 2) CF_DECLARE_WALKER(0, 3)
 CF_DECLARE_WALKER(1, 0) CF_DECLARE_WALKER(1, 1) CF_DECLARE_WALKER(1, 2) CF_DECLARE_WALKER(1, 3)
 
-typedef void (*walker_fn)(cf_dev_desc, const double*, int64_t, double*, double*, double*, double*, double*, double*);
+typedef void (*walker_fn)(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*);
 static walker_fn pick_walker(int model, int fde) {
   static const walker_fn table[2][4] = {
       {walker_kernel<0, 0>, walker_kernel<0, 1>, walker_kernel<0, 2>, walker_kernel<0, 3>},
       {walker_kernel<1, 0>, walker_kernel<1, 1>, walker_kernel<1, 2>, walker_kernel<1, 3>}};
+  return table[model][fde];
+}
+typedef void (*small_blocks_fn)(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, double*);
+static small_blocks_fn pick_small_blocks(int model, int fde) {
+  static const small_blocks_fn table[2][4] = {
+      {small_blocks_kernel<0, 0>, small_blocks_kernel<0, 1>, small_blocks_kernel<0, 2>, small_blocks_kernel<0, 3>},
+      {small_blocks_kernel<1, 0>, small_blocks_kernel<1, 1>, small_blocks_kernel<1, 2>, small_blocks_kernel<1, 3>}};
   return table[model][fde];
 }
 template <int KS, int TC>
@@ -201,6 +213,7 @@ struct cf_handle {
   DevBuf z_cmb, z_hel, obs, sn_step, sn_rec, log10_tab;
   DevBuf bao_z, bao_val, bao_inv_cov, bao_qty, gl_x, gl_w, fixed_mu, cc_z, cc_h, cc_inv_cov, nu_grid;
   DevBuf theta, out, delta, ypk, chi2_extra, nonfinite;
+  DevBuf bao_nodes, bao_base;  // [max_walkers][n_bao][CF_BAO_NODES] table nodes for small_blocks_kernel; first node per datum
   bool has_small_blocks = false;  // BAO and / or CMB block present
   int64_t max_walkers = 0;
   double pack_probe_rel = 0.0;
@@ -250,6 +263,7 @@ static int ensure_workspace(cf_handle* h, int64_t W) {
   if (h->stage_in.ensure((size_t)w_pad * (h->d.ndim > 0 ? h->d.ndim : 1) * 8)) return CF_ERR_HIP;
   if (h->stage_out.ensure((size_t)w_pad * 8)) return CF_ERR_HIP;
   if (h->chi2_extra.ensure((size_t)w_pad * 8)) return CF_ERR_HIP;
+  if (h->d.n_bao > 0 && h->bao_nodes.ensure((size_t)w_pad * h->d.n_bao * CF_BAO_NODES * sizeof(d2))) return CF_ERR_HIP;
   if (h->d.n_sn > 0 && h->solve_mode == CF_SOLVE_INVERSE_GEMM) {
     if (h->partial.ensure((size_t)w_pad * h->ipack.dev.n_rowblocks * 8)) return CF_ERR_HIP;
     if (h->arrivals.ensure((size_t)(w_pad / 16) * 4)) return CF_ERR_HIP;
@@ -285,6 +299,7 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
   if (c->fde < CF_FDE_LCDM || c->fde > CF_FDE_CPL) return fail(CF_ERR_INVALID, "cf_create: bad fde");
   if (c->n_bao < 0 || c->n_bao > CF_MAX_BAO) return fail(CF_ERR_INVALID, "cf_create: n_bao must be in 0..64");
   if (c->n_bao > 0) {
+    if (c->n_grid < CF_BAO_NODES) return fail(CF_ERR_INVALID, "cf_create: a BAO block needs n_grid >= 6");
     if (!c->bao_z || !c->bao_val || !c->bao_qty || !c->bao_inv_cov)
       return fail(CF_ERR_INVALID, "cf_create: BAO block arrays must not be null");
     for (int k = 0; k < c->n_bao; ++k)
@@ -488,6 +503,27 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
     d.bao_val = h->bao_val.as<const double>();
     d.bao_inv_cov = h->bao_inv_cov.as<const double>();
     d.bao_qty = h->bao_qty.as<const int32_t>();
+    {
+      // interval of each BAO redshift on the grid, by the arithmetic of hermite_tab (cosmofit_kernels.hip); the copy
+      // of CF_BAO_NODES nodes starts two nodes below it, so that the kernel's own interval search, the Hermite pair
+      // and the two 3-point PCHIP stencils all stay inside the copy
+      std::vector<int32_t> base((size_t)c->n_bao);
+      const int G = d.n_grid;
+      for (int k = 0; k < c->n_bao; ++k) {
+        const double xi = c->bao_z[k];
+        int i = (int)(xi * d.inv_step);
+        i = i > G - 2 ? G - 2 : (i < 0 ? 0 : i);
+        if (i > 0 && (double)i * d.step >= xi) --i;
+        if (i < G - 2 && (double)(i + 1) * d.step < xi) ++i;
+        int b = i - 2;
+        b = b < 0 ? 0 : (b > G - CF_BAO_NODES ? G - CF_BAO_NODES : b);
+        base[k] = b;
+      }
+      if (h->bao_base.ensure(base.size() * 4)) return bail(CF_ERR_HIP);
+      if (hipMemcpy(h->bao_base.p, base.data(), base.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+        return bail(fail(CF_ERR_HIP, "hipMemcpy(bao_base) failed"));
+      d.bao_base = h->bao_base.as<const int32_t>();
+    }
   }
   if (c->ez_model == CF_EZ_PHYSICAL) {
     // massive-neutrino density at the grid nodes, cmb/data_planck_act_compression.py:53-66 -- independent of theta
@@ -697,7 +733,10 @@ static int launch_path(cf_handle* h, const double* d_theta, int64_t W, double* d
     // skewed {cum, dh} table: one spare 16-byte slot per 2^chunk_shift nodes
     const size_t lds = ((size_t)d.n_grid + (d.n_grid >> d.chunk_shift) + 2) * 16;
     hipLaunchKernelGGL(pick_walker(d.ez_model, d.fde), dim3((unsigned)W), dim3(512), lds, st, d, d_theta, W,
-                       h->delta.as<double>(), extra, dm_out, mucorr_out, blocks_out, bao_out);
+                       h->delta.as<double>(), dm_out, mucorr_out, h->bao_nodes.as<d2>());
+    if (h->has_small_blocks)  // one wave per walker, four walkers per workgroup
+      hipLaunchKernelGGL(pick_small_blocks(d.ez_model, d.fde), dim3((unsigned)((W + 3) / 4)), dim3(256), 0, st, d, d_theta, W,
+                         h->bao_nodes.as<const d2>(), extra, blocks_out, bao_out);
   }
   if (ev) HIP_TRY(hipEventRecord(ev[1], st));
   if (d.n_sn > 0 && h->solve_mode == CF_SOLVE_INVERSE_GEMM) {

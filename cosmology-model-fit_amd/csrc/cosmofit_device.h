@@ -88,6 +88,7 @@ struct cf_dev_desc {
   const double* bao_val;
   const double* bao_inv_cov;
   const int32_t* bao_qty;
+  const int32_t* bao_base;  // [n_bao] first of the CF_BAO_NODES table nodes copied out for datum k (small_blocks_kernel)
   double rd_fit[11];
   // compressed-CMB block
   int32_t cmb_mode, n_gl;

@@ -162,10 +162,25 @@ struct DistTable {
   __device__ __forceinline__ d2 at(int g) const { return tab[g + (g >> chs)]; }
 };
 
+// The CF_BAO_NODES table nodes around one BAO redshift, copied out of a walker's LDS table by walker_kernel
+// (node `base` first): the same readers as for the full table, used by small_blocks_kernel.
+#define CF_BAO_NODES 6
+struct NodeView {
+  const d2* p;
+  int base, G;
+  double step, inv_step, inv_last, z_max;
+  __device__ __forceinline__ d2 at(int g) const {
+    int o = g - base;
+    o = o < 0 ? 0 : (o > CF_BAO_NODES - 1 ? CF_BAO_NODES - 1 : o);  // never outside the copy
+    return p[o];
+  }
+};
+
 // Cubic Hermite on the uniform grid (nodes cum_dm, slopes dh).  interpolator.py:71-108 with
 // exact=True: interval i = searchsorted_left(x, xi) - 1, i.e. x[i] < xi <= x[i+1]; linear
 // extrapolation outside.  t = (xi - x_i)/h_i is formed with the precomputed 1/h_i (<= 1 ulp).
-__device__ __forceinline__ double hermite_tab(const DistTable& T, double xi) {
+template <class TAB>
+__device__ __forceinline__ double hermite_tab(const TAB& T, double xi) {
   const int G = T.G;
   if (xi <= 0.0) {
     const d2 e = T.at(0);
@@ -472,7 +487,8 @@ __device__ __forceinline__ void build_distance_table(const cf_dev_desc& d, const
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double sgn_d(double v) { return (double)((v > 0) - (v < 0)); }
 
-__device__ double pchip_slope_tab(const DistTable& T, int i) {
+template <class TAB>
+__device__ double pchip_slope_tab(const TAB& T, int i) {
   const int n = T.G;
   auto X = [&](int k) { return grid_z(k, n, T.step, T.z_max); };
   auto Y = [&](int k) { return T.at(k).y; };
@@ -499,7 +515,8 @@ __device__ double pchip_slope_tab(const DistTable& T, int i) {
   return e;
 }
 
-__device__ double pchip_dh_tab(const DistTable& T, double xi) {
+template <class TAB>
+__device__ double pchip_dh_tab(const TAB& T, double xi) {
   const int G = T.G;
   if (xi <= 0.0) return T.at(0).y;            // clamped outside (exact=False), interpolator.py:80-85
   if (xi >= T.z_max) return T.at(G - 1).y;
@@ -569,8 +586,7 @@ __device__ __forceinline__ void sn_fast_loop(const cf_dev_desc& d, const DistTab
 }
 
 // ------------------------------------------------------------------------------------------------
-// Kernel A: one 512-thread workgroup per walker: distance table, SN residual vector, and the small
-// BAO / compressed-CMB blocks of the joint likelihoods.
+// Kernel A: one 512-thread workgroup per walker: distance table and SN residual vector.
 //
 // SN fast path (dm_out == mucorr_out == NULL): the two magnitude terms of the reference,
 //   mu_corr + mu_theory = 5 log10(DM(z_cosmo)/DM(z_cmb)) + 25 + 5 log10((1+z_hel) DM(z_cmb)),
@@ -578,20 +594,15 @@ __device__ __forceinline__ void sn_fast_loop(const cf_dev_desc& d, const DistTab
 // and one log10 per SN instead of two and two (difference ~1e-15 mag, tests/test_gpu_parity.py).
 // The accessor path (cf_eval_parts) keeps the reference's exact sequence  sn/pantheon.py:43-61.
 //
-// BAO (bao/desi_cmb_des5y.py:82-100,132-135): thread k < n_bao evaluates datum k; thread 0 forms
-// the quadratic form with the explicit inverse covariance.  CMB (cmb/data_planck_act_compression.py
-// :160-212): thread t < n_gl evaluates node t of the sound-horizon integral, thread n_gl + t node t
-// of the distance integral; thread 0 adds them in node order like the reference's loop.
-// chi2_extra[w] = chi2_bao + chi2_cmb + chi2_cc;  blocks_out[w] = (bao, cmb, cmb vector[3], cc), bao_out[w][k] optional.
+// The small blocks of the joint likelihoods (BAO, compressed CMB, cosmic chronometers) are evaluated by
+// small_blocks_kernel after this kernel; the BAO block needs a few table nodes per datum, copied out here.
 // ------------------------------------------------------------------------------------------------
 template <int MODEL, int FDE>
 __global__ void __launch_bounds__(CF_TPB_A, 4)
 walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double* __restrict__ delta,
-              double* __restrict__ chi2_extra, double* __restrict__ dm_out, double* __restrict__ mucorr_out,
-              double* __restrict__ blocks_out, double* __restrict__ bao_out) {
+              double* __restrict__ dm_out, double* __restrict__ mucorr_out, d2* __restrict__ bao_nodes) {
   extern __shared__ __align__(16) d2 lds_tab[];
   __shared__ __align__(16) d4 wave_pub[CF_TPB_A / 64];  // per-wave {interval sum, first dh, last dh} of the table build
-  __shared__ double scratch[2 * CF_MAX_GL + 2 * CF_MAX_BAO + 2 * CF_MAX_CC + 8];
   __shared__ __align__(16) d2 log_tab[64];  // log10_tab's reduction table; the table build's barriers order the fill
 
   const int64_t w = blockIdx.x;
@@ -614,6 +625,12 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
   CF_WSTAMP(1);
   if (d.n_sn > 0 || d.n_bao > 0) build_distance_table<MODEL, FDE>(d, wc, lds_tab, wave_pub);
   CF_WSTAMP(4);
+  // the table nodes around each BAO redshift go to small_blocks_kernel (the BAO block is evaluated there, one wave
+  // per walker); copied by the last threads of the workgroup, whose waves have the lightest share of the SN loop
+  if (tid >= CF_TPB_A - CF_BAO_NODES * d.n_bao) {
+    const int e = CF_TPB_A - 1 - tid, k = e / CF_BAO_NODES, o = e % CF_BAO_NODES;
+    bao_nodes[(w * d.n_bao + k) * CF_BAO_NODES + o] = T.at(d.bao_base[k] + o);
+  }
 
   // ---- SN residual vector ----
   if (d.n_sn > 0) {
@@ -658,31 +675,52 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
     }
   }
   CF_WSTAMP(5);
-  if (d.n_bao == 0 && d.cmb_mode == 0 && d.n_cc == 0) {
-    if (tid == 0 && chi2_extra) chi2_extra[w] = 0.0;
-    return;
-  }
+}
 
-  // ---- scalars shared by the two small blocks ----
-  double* gl_terms = scratch;                   // [2*n_gl]
-  double* bao_delta = scratch + 2 * CF_MAX_GL;  // [n_bao]
-  double* cc_delta = bao_delta + CF_MAX_BAO;    // [n_cc]
-  double* shared = cc_delta + CF_MAX_CC;        // [0] = z_star, [1] = r_d
+// ------------------------------------------------------------------------------------------------
+// The small blocks of the joint likelihoods -- z* / r_drag fitting formulae, compressed CMB (2 x n_gl
+// Gauss-Legendre nodes), cosmic chronometers, BAO -- one WAVE per walker, after walker_kernel.  Only the BAO
+// block needs the distance table, and of it only the few nodes around each BAO redshift, which walker_kernel
+// copies out; so thousands of walkers fill the chip here (inside walker_kernel these serial sections held a
+// 72 KB table workgroup for as long as the table build and the SN loop together).
+// chi2_extra[w] = chi2_bao + chi2_cmb + chi2_cc;  blocks_out[w] = (bao, cmb, cmb vector[3], cc), bao_out[w][k] optional.
+//   z* / r_drag: sums of products of powers (14 calls of pow), one power per lane, two dependent rounds;
+//   lane 0 combines them in the reference's order        cmb/data_planck_act_compression.py:86-124
+//   CMB: lane l takes nodes l, l + 64, ... of r_s(z*) (in a) and D_M(z*) (in z), a butterfly adds the lanes
+//   (the reference adds in node order: differs at the 1e-16 level)   cmb/data_planck_act_compression.py:160-212
+//   CC: lane k forms H_obs - H(z_k), lane j column j of delta @ inv_cov  bao/desi_union3_cc_theta_star.py:129-139
+//   BAO: lane k evaluates datum k (Hermite D_M; D_H by PCHIP with the two Fritsch-Carlson slopes it needs, or
+//   exactly as c/H), lane j column j of delta @ inv_cov    bao/desi_cmb_des5y.py:82-100,132-135
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, CF_WAVE);
+  return v;
+}
+
+template <int MODEL, int FDE>
+__global__ void __launch_bounds__(256)
+small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, const d2* __restrict__ bao_nodes,
+                    double* __restrict__ chi2_extra, double* __restrict__ blocks_out, double* __restrict__ bao_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= W) return;  // wave-uniform; nothing below synchronises across waves
+  const double* th = theta + w * d.ndim;
+  const WalkerCosmo wc = make_cosmo(d, th);
   const double Ob = slot_get(d, CF_P_OBH2_D, th), Oc = slot_get(d, CF_P_OCH2_D, th);
-  // z_star and r_drag are sums of products of powers (14 calls of pow): one power per lane of wave 0, two
-  // dependent rounds (the inner wb^b, wm^m first), then lane 0 combines them in the reference's order.
-  if (tid < 64) {
+  double z_star = 0.0, r_d = 0.0;
+  if (d.cmb_mode || d.rd_from_fit) {
     const double wm_z = Oc + Ob + d.omnu_h2, wm_r = Ob + Oc + d.omnu_h2;
     const double* fz = d.zstar_fit;  // s1 s2 b m e0 c1 e1 e2 c2 e3 e4
     const double* fr = d.rd_fit;     // b m a1..a9
     // round 1: lane 0 wb^b(z*), 1 wm^m(z*), 2 wb^b(rd), 3 wm^m(rd)
-    double base1 = (tid & 1) ? ((tid & 2) ? wm_r : wm_z) : Ob;
-    double exp1 = tid == 0 ? fz[2] : tid == 1 ? fz[3] : tid == 2 ? fr[0] : fr[1];
-    const double p1 = tid < 4 ? pow(base1, exp1) : 0.0;
+    const double base1 = (lane & 1) ? ((lane & 2) ? wm_r : wm_z) : Ob;
+    const double exp1 = lane == 0 ? fz[2] : lane == 1 ? fz[3] : lane == 2 ? fr[0] : fr[1];
+    const double p1 = lane < 4 ? pow(base1, exp1) : 0.0;
     const double wbz = __shfl(p1, 0, CF_WAVE), wmz = __shfl(p1, 1, CF_WAVE), wbr = __shfl(p1, 2, CF_WAVE), wmr = __shfl(p1, 3, CF_WAVE);
     // round 2: lanes 0-4 the z* powers, 5-9 the r_drag powers
     double base2 = 1.0, exp2 = 1.0;
-    switch (tid) {
+    switch (lane) {
       case 0: base2 = wmz; exp2 = fz[4]; break;
       case 1: base2 = wbz; exp2 = fz[6]; break;
       case 2: base2 = wmz; exp2 = fz[7]; break;
@@ -695,120 +733,112 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
       case 9: base2 = wmr; exp2 = fr[10]; break;
       default: break;
     }
-    const double p2 = tid < 10 ? pow(base2, exp2) : 0.0;
+    const double p2 = lane < 10 ? pow(base2, exp2) : 0.0;
     double q[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) q[k] = __shfl(p2, k, CF_WAVE);
-    if (tid == 0) {
-      // cmb/data_planck_act_compression.py:94-99
-      shared[0] = q[0] + fz[0] * fz[5] * q[1] * q[2] + fz[1] * fz[8] * q[3] * q[4];
-      // cmb/data_planck_act_compression.py:121-124
-      const double den = (fr[2] * q[5]) + (fr[4] * q[6] * q[7]) + (fr[7] * q[8]);
-      shared[1] = d.rd_from_fit ? 1.0 / den - fr[9] / q[9] : slot_get(d, CF_P_RD_D, th);
-    }
+    // cmb/data_planck_act_compression.py:94-99
+    z_star = q[0] + fz[0] * fz[5] * q[1] * q[2] + fz[1] * fz[8] * q[3] * q[4];
+    // cmb/data_planck_act_compression.py:121-124
+    const double den = (fr[2] * q[5]) + (fr[4] * q[6] * q[7]) + (fr[7] * q[8]);
+    r_d = 1.0 / den - fr[9] / q[9];
   }
-  // ---- cosmic chronometers: H_obs - H(z), bao/desi_union3_cc_theta_star.py:129 (last threads of the block) ----
-  if (tid >= CF_TPB_A - d.n_cc) {
-    const int k = CF_TPB_A - 1 - tid;
-    cc_delta[k] = d.cc_h[k] - H_of_z<MODEL, FDE>(d, wc, d.cc_z[k]);
-  }
-  __syncthreads();
+  if (!d.rd_from_fit) r_d = slot_get(d, CF_P_RD_D, th);
 
-  // ---- BAO theory vector ----
-  if (tid < d.n_bao) {
-    const double z = d.bao_z[tid], rd = shared[1];
-    const double DM = hermite_tab(T, z);
-    const double DH = d.bao_dh_exact ? d.c / H_of_z<MODEL, FDE>(d, wc, z) : pchip_dh_tab(T, z);
-    double t;
-    switch (d.bao_qty[tid]) {
-      case 2: t = DH / rd; break;
-      case 1: t = DM / rd; break;
-      case 0: t = pow(z * DH * (DM * DM), 1.0 / 3) / rd; break;
-      default: t = DM / DH; break;
-    }
-    bao_delta[tid] = d.bao_val[tid] - t;
-    if (bao_out) bao_out[w * d.n_bao + tid] = t;
-  }
-  // ---- Gauss-Legendre terms of r_s(z*) (in a) and D_M(z*) (in z) ----
-  if (d.cmb_mode && tid < 2 * d.n_gl) {
-    const double zstar = shared[0];
-    if (tid < d.n_gl) {
-      const double half = (1.0 / (1.0 + zstar)) / 2.0;
-      const double a = half * d.gl_x[tid] + half;
+  double c_cmb = 0.0, vec[3] = {0.0, 0.0, 0.0};
+  if (d.cmb_mode) {
+    double s_rs = 0.0, s_dm = 0.0;
+    const double half_a = (1.0 / (1.0 + z_star)) / 2.0, half_z = z_star / 2.0;
+    for (int k = lane; k < d.n_gl; k += 64) {
+      const double a = half_a * d.gl_x[k] + half_a;
       const double z = (1.0 / a) - 1.0;
       const double Rb = (3.0 / 4.0) * (Ob / d.o_gamma_h2) * a;
-      gl_terms[tid] = d.gl_w[tid] * (d.c / (a * a * H_of_z<MODEL, FDE>(d, wc, z) * sqrt(3.0 * (1.0 + Rb))));
+      s_rs += d.gl_w[k] * (d.c / (a * a * H_of_z<MODEL, FDE>(d, wc, z) * sqrt(3.0 * (1.0 + Rb))));
+      s_dm += d.gl_w[k] * (d.c / H_of_z<MODEL, FDE>(d, wc, half_z * d.gl_x[k] + half_z));
+    }
+    const double i_rs = wave_sum(s_rs), i_dm = wave_sum(s_dm);
+    const double rs_star = half_a * i_rs;
+    const double DM_star = half_z * i_dm;
+    const double Om_h2 = Oc + Ob + d.omnu_h2;
+    if (d.cmb_mode == 3) {  // (theta*, wb, wm)  cmb/data_early_lcdm_compression.py:206-207
+      vec[0] = rs_star / DM_star; vec[1] = Ob; vec[2] = Om_h2;
+    } else {                // (R, lA, wb)       cmb/data_planck_act_compression.py:209-212
+      vec[0] = 100 * sqrt(Om_h2) * DM_star / d.c; vec[1] = 3.14159265358979323846 * DM_star / rs_star; vec[2] = Ob;
+    }
+    double dl[3];
+    for (int i = 0; i < 3; ++i) dl[i] = d.cmb_prior[i] - vec[i];
+    if (d.cmb_mode == 2) {
+      c_cmb = dl[1] * dl[1] * d.cmb_inv_cov[4];  // bao/desi_des5y_bbn_theta_star.py:110-111
     } else {
-      const int k = tid - d.n_gl;
-      const double half = zstar / 2.0;
-      gl_terms[tid] = d.gl_w[k] * (d.c / H_of_z<MODEL, FDE>(d, wc, half * d.gl_x[k] + half));
-    }
-  }
-  __syncthreads();
-  // (delta @ inv_cov)[j] by thread j -- the reference's own order of operations, one column per thread
-  double* bao_t = shared + 2;          // [n_bao]
-  double* cc_t = bao_t + CF_MAX_BAO;   // [n_cc]
-  if (tid < d.n_bao) {
-    double t = 0.0;
-    for (int i = 0; i < d.n_bao; ++i) t += bao_delta[i] * d.bao_inv_cov[i * d.n_bao + tid];
-    bao_t[tid] = t;
-  }
-  if (tid >= 64 && tid < 64 + d.n_cc) {
-    const int j = tid - 64;
-    double t = 0.0;
-    for (int i = 0; i < d.n_cc; ++i) t += cc_delta[i] * d.cc_inv_cov[i * d.n_cc + j];
-    cc_t[j] = t;
-  }
-  // the two Gauss-Legendre sums in node order, on two different waves
-  if (d.cmb_mode && (tid == 128 || tid == 192)) {
-    const int o = tid == 128 ? 0 : d.n_gl;
-    double acc = 0.0;
-    for (int k = 0; k < d.n_gl; ++k) acc += gl_terms[o + k];
-    shared[tid == 128 ? 130 : 131] = acc;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    double c_bao = 0.0, c_cmb = 0.0;
-    for (int j = 0; j < d.n_bao; ++j) c_bao += bao_t[j] * bao_delta[j];  // ... @ delta
-    if (d.cmb_mode) {
-      const double zstar = shared[0];
-      const double i_rs = shared[130], i_dm = shared[131];
-      const double rs_star = ((1.0 / (1.0 + zstar)) / 2.0) * i_rs;
-      const double DM_star = (zstar / 2.0) * i_dm;
-      const double Om_h2 = Oc + Ob + d.omnu_h2;
-      double vec[3];
-      if (d.cmb_mode == 3) {  // (theta*, wb, wm)  cmb/data_early_lcdm_compression.py:206-207
-        vec[0] = rs_star / DM_star; vec[1] = Ob; vec[2] = Om_h2;
-      } else {                // (R, lA, wb)       cmb/data_planck_act_compression.py:209-212
-        vec[0] = 100 * sqrt(Om_h2) * DM_star / d.c; vec[1] = 3.14159265358979323846 * DM_star / rs_star; vec[2] = Ob;
+      for (int j = 0; j < 3; ++j) {
+        double t = 0.0;
+        for (int i = 0; i < 3; ++i) t += dl[i] * d.cmb_inv_cov[3 * i + j];
+        c_cmb += t * dl[j];
       }
-      double dl[3];
-      for (int i = 0; i < 3; ++i) dl[i] = d.cmb_prior[i] - vec[i];
-      if (d.cmb_mode == 2) {
-        c_cmb = dl[1] * dl[1] * d.cmb_inv_cov[4];  // bao/desi_des5y_bbn_theta_star.py:110-111
-      } else {
-        for (int j = 0; j < 3; ++j) {
-          double t = 0.0;
-          for (int i = 0; i < 3; ++i) t += dl[i] * d.cmb_inv_cov[3 * i + j];
-          c_cmb += t * dl[j];
-        }
+    }
+  }
+
+  double c_cc = 0.0;
+  if (d.n_cc > 0) {  // delta @ inv_cov @ delta * f_cc^2
+    const double dk = lane < d.n_cc ? d.cc_h[lane] - H_of_z<MODEL, FDE>(d, wc, d.cc_z[lane]) : 0.0;
+    double t = 0.0;
+    for (int i = 0; i < d.n_cc; ++i) {
+      const double di = __shfl(dk, i, CF_WAVE);
+      if (lane < d.n_cc) t += di * d.cc_inv_cov[i * d.n_cc + lane];
+    }
+    // the reference adds t_j delta_j in index order; lane 0 does the same over the lanes' products
+    const double prod = t * dk;
+    for (int j = 0; j < d.n_cc; ++j) c_cc += __shfl(prod, j, CF_WAVE);
+    const double f = slot_get(d, CF_P_FCC_D, th);
+    c_cc *= f * f;
+  }
+  double c_bao = 0.0;
+  if (d.n_bao > 0) {
+    double dk = 0.0;
+    if (lane < d.n_bao) {
+      NodeView T;
+      T.p = bao_nodes + (w * d.n_bao + lane) * CF_BAO_NODES;
+      T.base = d.bao_base[lane];
+      T.G = d.n_grid;
+      T.step = d.step;
+      T.inv_step = d.inv_step;
+      T.inv_last = d.inv_last;
+      T.z_max = d.z_max;
+      const double z = d.bao_z[lane];
+      const double DM = hermite_tab(T, z);
+      const double DH = d.bao_dh_exact ? d.c / H_of_z<MODEL, FDE>(d, wc, z) : pchip_dh_tab(T, z);
+      double t;
+      switch (d.bao_qty[lane]) {
+        case 2: t = DH / r_d; break;
+        case 1: t = DM / r_d; break;
+        case 0: t = pow(z * DH * (DM * DM), 1.0 / 3) / r_d; break;
+        default: t = DM / DH; break;
       }
-      if (blocks_out) { blocks_out[6 * w + 2] = vec[0]; blocks_out[6 * w + 3] = vec[1]; blocks_out[6 * w + 4] = vec[2]; }
+      dk = d.bao_val[lane] - t;
+      if (bao_out) bao_out[w * d.n_bao + lane] = t;
     }
-    double c_cc = 0.0;
-    if (d.n_cc > 0) {  // delta @ inv_cov @ delta * f_cc^2
-      for (int j = 0; j < d.n_cc; ++j) c_cc += cc_t[j] * cc_delta[j];
-      const double f = slot_get(d, CF_P_FCC_D, th);
-      c_cc *= f * f;
+    // (delta @ inv_cov)[j] by lane j, then ... @ delta in index order: the reference's own order of operations
+    double t = 0.0;
+    for (int i = 0; i < d.n_bao; ++i) {
+      const double di = __shfl(dk, i, CF_WAVE);
+      if (lane < d.n_bao) t += di * d.bao_inv_cov[i * d.n_bao + lane];
     }
-    if (chi2_extra) chi2_extra[w] = c_cmb + c_bao + c_cc;
-    if (blocks_out) { blocks_out[6 * w + 0] = c_bao; blocks_out[6 * w + 1] = c_cmb; blocks_out[6 * w + 5] = c_cc; }
+    const double prod = t * dk;
+    for (int j = 0; j < d.n_bao; ++j) c_bao += __shfl(prod, j, CF_WAVE);
+  }
+  if (lane == 0) {
+    chi2_extra[w] = c_cmb + c_bao + c_cc;
+    if (blocks_out) {
+      blocks_out[6 * w + 0] = c_bao; blocks_out[6 * w + 1] = c_cmb; blocks_out[6 * w + 5] = c_cc;
+      if (d.cmb_mode) { blocks_out[6 * w + 2] = vec[0]; blocks_out[6 * w + 3] = vec[1]; blocks_out[6 * w + 4] = vec[2]; }
+    }
   }
 }
 
 #define CF_INSTANTIATE_WALKER(M, F)                                                                              \
-  template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, \
-                                               double*, double*, double*);
+  template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*); \
+  template __global__ void small_blocks_kernel<M, F>(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, \
+                                                     double*);
 CF_INSTANTIATE_WALKER(0, 0) CF_INSTANTIATE_WALKER(0, 1) CF_INSTANTIATE_WALKER(0, 2) CF_INSTANTIATE_WALKER(0, 3)
 CF_INSTANTIATE_WALKER(1, 0) CF_INSTANTIATE_WALKER(1, 1) CF_INSTANTIATE_WALKER(1, 2) CF_INSTANTIATE_WALKER(1, 3)
 
