@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("cosmology-model-fit_amd")
 syn = pkg.synthetic.pantheon_like(n_sn=1701, seed=0)
 th = pkg.synthetic.walkers(pkg.sn_pantheon.bounds, 4096, seed=0)
-for name, lat in (("blocked TRSM", False), ("latency mode", True)):
+for name, lat in (("blocked TRSM", False), ("inverse GEMM", True)):
     lk = pkg.sn_pantheon.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"], latency_mode=lat)
     lk.log_probs_vectorized(th)
     lk.engine.enable_timing(8)
