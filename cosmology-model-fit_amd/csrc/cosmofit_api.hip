@@ -918,7 +918,7 @@ extern "C" int cf_solve_triangular(const double* L, int64_t n, int64_t ld, const
   return CF_OK;
 }
 
-// Host-only self-test of the latency-mode packing (explicit inverse): chi^2 of one right-hand side by
+// Host-only self-test of the inverse-GEMM packing (explicit inverse): chi^2 of one right-hand side by
 // replaying the fragment streams, and the create-time probe value.  CPU test-suite only.
 extern "C" int cf_selftest_invpack_host(const double* L, int64_t n, int64_t ld, const double* b, double* chi2_out,
                                         double* probe_out) {

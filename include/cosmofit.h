@@ -295,7 +295,7 @@ int cf_solve_triangular(const double* L, int64_t n, int64_t ld, const double* b,
 int cf_selftest_pack_host(const double* L, int64_t n, int64_t ld, const double* b, double* chi2_out,
                           int64_t* packed_bytes);
 
-/* The same for the latency-mode packing (explicit inverse); probe_out (may be NULL) receives the value
+/* The same for the inverse-GEMM packing (explicit inverse); probe_out (may be NULL) receives the value
  * cf_create compares with 1e-11. */
 int cf_selftest_invpack_host(const double* L, int64_t n, int64_t ld, const double* b, double* chi2_out,
                              double* probe_out);
