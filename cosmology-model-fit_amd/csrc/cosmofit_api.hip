@@ -734,8 +734,8 @@ static int launch_path(cf_handle* h, const double* d_theta, int64_t W, double* d
     const size_t lds = ((size_t)d.n_grid + (d.n_grid >> d.chunk_shift) + 2) * 16;
     hipLaunchKernelGGL(pick_walker(d.ez_model, d.fde), dim3((unsigned)W), dim3(512), lds, st, d, d_theta, W,
                        h->delta.as<double>(), dm_out, mucorr_out, h->bao_nodes.as<d2>());
-    if (h->has_small_blocks)  // one wave per walker, four walkers per workgroup
-      hipLaunchKernelGGL(pick_small_blocks(d.ez_model, d.fde), dim3((unsigned)((W + 3) / 4)), dim3(256), 0, st, d, d_theta, W,
+    if (h->has_small_blocks)  // sixteen lanes per walker, sixteen walkers per workgroup
+      hipLaunchKernelGGL(pick_small_blocks(d.ez_model, d.fde), dim3((unsigned)((W + 15) / 16)), dim3(256), 0, st, d, d_theta, W,
                          h->bao_nodes.as<const d2>(), extra, blocks_out, bao_out);
   }
   if (ev) HIP_TRY(hipEventRecord(ev[1], st));

@@ -679,48 +679,68 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
 
 // ------------------------------------------------------------------------------------------------
 // The small blocks of the joint likelihoods -- z* / r_drag fitting formulae, compressed CMB (2 x n_gl
-// Gauss-Legendre nodes), cosmic chronometers, BAO -- one WAVE per walker, after walker_kernel.  Only the BAO
-// block needs the distance table, and of it only the few nodes around each BAO redshift, which walker_kernel
-// copies out; so thousands of walkers fill the chip here (inside walker_kernel these serial sections held a
-// 72 KB table workgroup for as long as the table build and the SN loop together).
+// Gauss-Legendre nodes), cosmic chronometers, BAO -- after walker_kernel, SIXTEEN LANES per walker (four walkers
+// per wave, sixteen per 256-thread workgroup).  Only the BAO block needs the distance table, and of it only the few
+// nodes around each BAO redshift, which walker_kernel copies out; so thousands of walkers fill the chip here
+// (inside walker_kernel these serial sections held a 72 KB table workgroup for as long as the table build and the
+// SN loop together).  Sixteen lanes, not a wave: the powers and the BAO data occupy 4-14 lanes per walker, and a
+// SIMD spends a whole wave-instruction on them however many lanes are active.
 // chi2_extra[w] = chi2_bao + chi2_cmb + chi2_cc;  blocks_out[w] = (bao, cmb, cmb vector[3], cc), bao_out[w][k] optional.
-//   z* / r_drag: sums of products of powers (14 calls of pow), one power per lane, two dependent rounds;
-//   lane 0 combines them in the reference's order        cmb/data_planck_act_compression.py:86-124
-//   CMB: lane l takes nodes l, l + 64, ... of r_s(z*) (in a) and D_M(z*) (in z), a butterfly adds the lanes
+//   z* / r_drag: sums of products of powers (14 calls of pow), one power per lane, two dependent rounds, combined
+//   in the reference's order                               cmb/data_planck_act_compression.py:86-124
+//   CMB: lane l takes nodes l, l + 16, ... of r_s(z*) (in a) and D_M(z*) (in z), a butterfly adds the lanes
 //   (the reference adds in node order: differs at the 1e-16 level)   cmb/data_planck_act_compression.py:160-212
-//   CC: lane k forms H_obs - H(z_k), lane j column j of delta @ inv_cov  bao/desi_union3_cc_theta_star.py:129-139
-//   BAO: lane k evaluates datum k (Hermite D_M; D_H by PCHIP with the two Fritsch-Carlson slopes it needs, or
-//   exactly as c/H), lane j column j of delta @ inv_cov    bao/desi_cmb_des5y.py:82-100,132-135
+//   CC / BAO: lane k (+16, ...) forms delta_k -- H_obs - H(z_k) (bao/desi_union3_cc_theta_star.py:129-139), or BAO
+//   datum k: Hermite D_M; D_H by PCHIP with the two Fritsch-Carlson slopes it needs, or exactly as c/H
+//   (bao/desi_cmb_des5y.py:82-100,132-135) -- then column j of delta @ inv_cov, then ... @ delta by a butterfly
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
+#define CF_SB_LANES 16
+__device__ __forceinline__ double group_sum(double v) {  // over the 16 lanes of a walker
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, CF_WAVE);
+  for (int o = CF_SB_LANES / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o, CF_SB_LANES);
   return v;
+}
+
+// delta @ inv_cov @ delta for a vector held in LDS (n <= 64): lane j, j + 16, ... forms column j in the
+// reference's order of operations, the lanes' products meet in a butterfly
+__device__ __forceinline__ double group_quadratic_form(const double* __restrict__ dl, const double* __restrict__ inv_cov, int n,
+                                                       int sl) {
+  double acc = 0.0;
+  for (int j = sl; j < n; j += CF_SB_LANES) {
+    double t = 0.0;
+    for (int i = 0; i < n; ++i) t += dl[i] * inv_cov[i * n + j];
+    acc += t * dl[j];
+  }
+  return group_sum(acc);
 }
 
 template <int MODEL, int FDE>
 __global__ void __launch_bounds__(256)
 small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, const d2* __restrict__ bao_nodes,
                     double* __restrict__ chi2_extra, double* __restrict__ blocks_out, double* __restrict__ bao_out) {
-  const int lane = threadIdx.x & 63;
-  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (w >= W) return;  // wave-uniform; nothing below synchronises across waves
+  __shared__ double delta_s[256 / CF_SB_LANES][CF_MAX_BAO > CF_MAX_CC ? CF_MAX_BAO : CF_MAX_CC];
+  const int grp = threadIdx.x / CF_SB_LANES, sl = threadIdx.x % CF_SB_LANES;
+  const int64_t w_raw = (int64_t)blockIdx.x * (256 / CF_SB_LANES) + grp;
+  const bool live = w_raw < W;
+  const int64_t w = live ? w_raw : W - 1;  // spare groups of the last workgroup shadow the last walker and write nothing
   const double* th = theta + w * d.ndim;
   const WalkerCosmo wc = make_cosmo(d, th);
   const double Ob = slot_get(d, CF_P_OBH2_D, th), Oc = slot_get(d, CF_P_OCH2_D, th);
+  double* dl = delta_s[grp];
   double z_star = 0.0, r_d = 0.0;
   if (d.cmb_mode || d.rd_from_fit) {
     const double wm_z = Oc + Ob + d.omnu_h2, wm_r = Ob + Oc + d.omnu_h2;
     const double* fz = d.zstar_fit;  // s1 s2 b m e0 c1 e1 e2 c2 e3 e4
     const double* fr = d.rd_fit;     // b m a1..a9
     // round 1: lane 0 wb^b(z*), 1 wm^m(z*), 2 wb^b(rd), 3 wm^m(rd)
-    const double base1 = (lane & 1) ? ((lane & 2) ? wm_r : wm_z) : Ob;
-    const double exp1 = lane == 0 ? fz[2] : lane == 1 ? fz[3] : lane == 2 ? fr[0] : fr[1];
-    const double p1 = lane < 4 ? pow(base1, exp1) : 0.0;
-    const double wbz = __shfl(p1, 0, CF_WAVE), wmz = __shfl(p1, 1, CF_WAVE), wbr = __shfl(p1, 2, CF_WAVE), wmr = __shfl(p1, 3, CF_WAVE);
+    const double base1 = (sl & 1) ? ((sl & 2) ? wm_r : wm_z) : Ob;
+    const double exp1 = sl == 0 ? fz[2] : sl == 1 ? fz[3] : sl == 2 ? fr[0] : fr[1];
+    const double p1 = sl < 4 ? pow(base1, exp1) : 0.0;
+    const double wbz = __shfl(p1, 0, CF_SB_LANES), wmz = __shfl(p1, 1, CF_SB_LANES), wbr = __shfl(p1, 2, CF_SB_LANES),
+                 wmr = __shfl(p1, 3, CF_SB_LANES);
     // round 2: lanes 0-4 the z* powers, 5-9 the r_drag powers
     double base2 = 1.0, exp2 = 1.0;
-    switch (lane) {
+    switch (sl) {
       case 0: base2 = wmz; exp2 = fz[4]; break;
       case 1: base2 = wbz; exp2 = fz[6]; break;
       case 2: base2 = wmz; exp2 = fz[7]; break;
@@ -733,10 +753,10 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
       case 9: base2 = wmr; exp2 = fr[10]; break;
       default: break;
     }
-    const double p2 = lane < 10 ? pow(base2, exp2) : 0.0;
+    const double p2 = sl < 10 ? pow(base2, exp2) : 0.0;
     double q[10];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) q[k] = __shfl(p2, k, CF_WAVE);
+    for (int k = 0; k < 10; ++k) q[k] = __shfl(p2, k, CF_SB_LANES);
     // cmb/data_planck_act_compression.py:94-99
     z_star = q[0] + fz[0] * fz[5] * q[1] * q[2] + fz[1] * fz[8] * q[3] * q[4];
     // cmb/data_planck_act_compression.py:121-124
@@ -749,14 +769,14 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
   if (d.cmb_mode) {
     double s_rs = 0.0, s_dm = 0.0;
     const double half_a = (1.0 / (1.0 + z_star)) / 2.0, half_z = z_star / 2.0;
-    for (int k = lane; k < d.n_gl; k += 64) {
+    for (int k = sl; k < d.n_gl; k += CF_SB_LANES) {
       const double a = half_a * d.gl_x[k] + half_a;
       const double z = (1.0 / a) - 1.0;
       const double Rb = (3.0 / 4.0) * (Ob / d.o_gamma_h2) * a;
       s_rs += d.gl_w[k] * (d.c / (a * a * H_of_z<MODEL, FDE>(d, wc, z) * sqrt(3.0 * (1.0 + Rb))));
       s_dm += d.gl_w[k] * (d.c / H_of_z<MODEL, FDE>(d, wc, half_z * d.gl_x[k] + half_z));
     }
-    const double i_rs = wave_sum(s_rs), i_dm = wave_sum(s_dm);
+    const double i_rs = group_sum(s_rs), i_dm = group_sum(s_dm);
     const double rs_star = half_a * i_rs;
     const double DM_star = half_z * i_dm;
     const double Om_h2 = Oc + Ob + d.omnu_h2;
@@ -765,68 +785,57 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
     } else {                // (R, lA, wb)       cmb/data_planck_act_compression.py:209-212
       vec[0] = 100 * sqrt(Om_h2) * DM_star / d.c; vec[1] = 3.14159265358979323846 * DM_star / rs_star; vec[2] = Ob;
     }
-    double dl[3];
-    for (int i = 0; i < 3; ++i) dl[i] = d.cmb_prior[i] - vec[i];
+    double dv[3];
+    for (int i = 0; i < 3; ++i) dv[i] = d.cmb_prior[i] - vec[i];
     if (d.cmb_mode == 2) {
-      c_cmb = dl[1] * dl[1] * d.cmb_inv_cov[4];  // bao/desi_des5y_bbn_theta_star.py:110-111
+      c_cmb = dv[1] * dv[1] * d.cmb_inv_cov[4];  // bao/desi_des5y_bbn_theta_star.py:110-111
     } else {
       for (int j = 0; j < 3; ++j) {
         double t = 0.0;
-        for (int i = 0; i < 3; ++i) t += dl[i] * d.cmb_inv_cov[3 * i + j];
-        c_cmb += t * dl[j];
+        for (int i = 0; i < 3; ++i) t += dv[i] * d.cmb_inv_cov[3 * i + j];
+        c_cmb += t * dv[j];
       }
     }
   }
 
   double c_cc = 0.0;
   if (d.n_cc > 0) {  // delta @ inv_cov @ delta * f_cc^2
-    const double dk = lane < d.n_cc ? d.cc_h[lane] - H_of_z<MODEL, FDE>(d, wc, d.cc_z[lane]) : 0.0;
-    double t = 0.0;
-    for (int i = 0; i < d.n_cc; ++i) {
-      const double di = __shfl(dk, i, CF_WAVE);
-      if (lane < d.n_cc) t += di * d.cc_inv_cov[i * d.n_cc + lane];
-    }
-    // the reference adds t_j delta_j in index order; lane 0 does the same over the lanes' products
-    const double prod = t * dk;
-    for (int j = 0; j < d.n_cc; ++j) c_cc += __shfl(prod, j, CF_WAVE);
+    for (int k = sl; k < d.n_cc; k += CF_SB_LANES) dl[k] = d.cc_h[k] - H_of_z<MODEL, FDE>(d, wc, d.cc_z[k]);
+    __syncthreads();
+    c_cc = group_quadratic_form(dl, d.cc_inv_cov, d.n_cc, sl);
     const double f = slot_get(d, CF_P_FCC_D, th);
     c_cc *= f * f;
+    __syncthreads();  // dl is reused by the BAO block
   }
+
   double c_bao = 0.0;
   if (d.n_bao > 0) {
-    double dk = 0.0;
-    if (lane < d.n_bao) {
+    for (int k = sl; k < d.n_bao; k += CF_SB_LANES) {
       NodeView T;
-      T.p = bao_nodes + (w * d.n_bao + lane) * CF_BAO_NODES;
-      T.base = d.bao_base[lane];
+      T.p = bao_nodes + (w * d.n_bao + k) * CF_BAO_NODES;
+      T.base = d.bao_base[k];
       T.G = d.n_grid;
       T.step = d.step;
       T.inv_step = d.inv_step;
       T.inv_last = d.inv_last;
       T.z_max = d.z_max;
-      const double z = d.bao_z[lane];
+      const double z = d.bao_z[k];
       const double DM = hermite_tab(T, z);
       const double DH = d.bao_dh_exact ? d.c / H_of_z<MODEL, FDE>(d, wc, z) : pchip_dh_tab(T, z);
       double t;
-      switch (d.bao_qty[lane]) {
+      switch (d.bao_qty[k]) {
         case 2: t = DH / r_d; break;
         case 1: t = DM / r_d; break;
         case 0: t = pow(z * DH * (DM * DM), 1.0 / 3) / r_d; break;
         default: t = DM / DH; break;
       }
-      dk = d.bao_val[lane] - t;
-      if (bao_out) bao_out[w * d.n_bao + lane] = t;
+      dl[k] = d.bao_val[k] - t;
+      if (bao_out && live) bao_out[w * d.n_bao + k] = t;
     }
-    // (delta @ inv_cov)[j] by lane j, then ... @ delta in index order: the reference's own order of operations
-    double t = 0.0;
-    for (int i = 0; i < d.n_bao; ++i) {
-      const double di = __shfl(dk, i, CF_WAVE);
-      if (lane < d.n_bao) t += di * d.bao_inv_cov[i * d.n_bao + lane];
-    }
-    const double prod = t * dk;
-    for (int j = 0; j < d.n_bao; ++j) c_bao += __shfl(prod, j, CF_WAVE);
+    __syncthreads();
+    c_bao = group_quadratic_form(dl, d.bao_inv_cov, d.n_bao, sl);
   }
-  if (lane == 0) {
+  if (sl == 0 && live) {
     chi2_extra[w] = c_cmb + c_bao + c_cc;
     if (blocks_out) {
       blocks_out[6 * w + 0] = c_bao; blocks_out[6 * w + 1] = c_cmb; blocks_out[6 * w + 5] = c_cc;
