@@ -254,7 +254,10 @@ int cf_eval(cf_handle* h, const double* theta, int64_t W, double* out, int32_t o
 
 /* Device buffers on the handle's device; asynchronous on `hip_stream` (a hipStream_t; NULL = HIP's
  * default stream, which is what torch.cuda.current_stream().cuda_stream reports as 0), ordered like any
- * other work on that stream. Grows the workspace if needed (then it synchronises once). */
+ * other work on that stream. Grows the workspace if needed (then it synchronises once).
+ * A handle owns ONE workspace (residual rows, chi^2 shares, arrival counters): evaluations of one handle must be
+ * ordered with respect to each other -- same stream, or streams the caller has ordered with events; for concurrent
+ * evaluations create one handle per stream. */
 int cf_eval_device(cf_handle* h, const double* d_theta, int64_t W, double* d_out,
                    int32_t out_kind, void* hip_stream);
 
@@ -270,8 +273,8 @@ int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, double* dm_obs, 
 
 /* Per-kernel timing with HIP events recorded on the stream the kernels are launched on.
  * cf_enable_timing(h, slots): keep events for the last `slots` evaluation calls (0 = off, the
- * default) and reset the call counter.  cf_kernel_ms(h, call, t): t[0] = distance+residual
- * kernel, t[1] = triangular solve + chi^2 kernel of evaluation number `call` (0-based since
+ * default) and reset the call counter.  cf_kernel_ms(h, call, t): t[0] = distance + residual
+ * kernel (and the small-blocks kernel of a joint likelihood), t[1] = solve + chi^2 kernel of evaluation number `call` (0-based since
  * cf_enable_timing); waits for that call.  cf_last_kernel_ms = the most recent call. */
 int cf_enable_timing(cf_handle* h, int slots);
 int64_t cf_timed_calls(cf_handle* h);
