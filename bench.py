@@ -199,6 +199,15 @@ def main():
             },
             "kernels_ms": {"walker_kernel": resid_ms, solve_kernel: solve_ms},
         }
+        # the HBM view next to the matrix-core view.  `hbm_gbps_measured` = PMC bytes of the solve
+        # kernel / its duration (small by design: the factor is reused by every walker from L2 / Infinity Cache);
+        # `trsv_equivalent_gbps` = what a design without reuse would have to stream (8 N (N+1) / 2 bytes per eval),
+        # quoted for comparison with the CPU path only -- it exceeds the 8 TB/s HBM peak because of the reuse.
+        traffic = out["roofline"]["traffic"]
+        out["roofline"]["hbm_gbps_measured"] = traffic / (solve_ms * 1e-3) / 1e9 if traffic else None
+        out["roofline"]["trsv_equivalent_gbps"] = 8.0 * args.n_sn * (args.n_sn + 1) / 2 * out["value"] / 1e9
+        if world == 1:
+            out["roofline"]["hbm_stream_triad_gbps"] = stream_triad_gbps(torch, dev)
         if world == 1 and args.workload == "pantheon":
             # the ctypes boundary as emcee / nautilus call it: host numpy in, host numpy out (PCIe + sync included).
             # Reported for DESIGN.md; never the headline `value`.
@@ -217,6 +226,22 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def stream_triad_gbps(torch, dev, n=1 << 27, reps=10):
+    """What this device's HBM delivers on a STREAM triad a = b + s * c (3 x 1 GiB of float64), after the timed region."""
+    b = torch.ones(n, dtype=torch.float64, device=dev)
+    c = torch.ones(n, dtype=torch.float64, device=dev)
+    a = torch.empty_like(b)
+    torch.add(b, c, alpha=0.5, out=a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        torch.add(b, c, alpha=0.5, out=a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 3 * 8 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def pmc_traffic(n_sn, walkers, kernel):
