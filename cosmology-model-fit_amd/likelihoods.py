@@ -121,6 +121,34 @@ class DesiCmbDes5y(_Base):
             solve_mode=solve_mode_of(solve, latency_mode))
 
 
+class DesiCmbDes5yH0Trgb(_Base):
+    """bao/desi_cmb_des5y_H0trgb.py: theta = (dM, H0, wb, wc, v); SN with velocity step at z = 0.11 (:110), DESI DR2 BAO
+    and the single 6dF D_V point as one block-diagonal BAO block (:139-144), exact D_H (:63-64), Planck+ACT
+    (R, l_A, wb), and the TRGB chi^2 term ((H0 - 70.39) / 1.80)^2 (:149); dark energy = Lambda as shipped (:52)."""
+    H0_TRGB = (70.39, 1.80)
+
+    def __init__(self, z_cmb, z_hel, mu_values, cov_sn, bao_z, bao_val, bao_qty, bao_inv_cov, sixdf_z, sixdf_val, sixdf_qty,
+                 sixdf_inv_cov, *, chol=None, comp=None, device=0, solve="auto"):
+        from scipy.linalg import block_diag
+
+        comp = cmb_data.PLANCK_ACT if comp is None else comp
+        if chol is None:
+            chol = cho_factor(cov_sn, lower=True)[0]  # :18
+        z_all = np.concatenate([np.asarray(bao_z, float), np.atleast_1d(np.asarray(sixdf_z, float))])
+        self.z_max = float(max(np.max(z_cmb), np.max(bao_z)) + 0.1)  # :22 (the 6dF point lies below the DESI ones)
+        self.engine = LikelihoodEngine(
+            ndim=5, z_max=self.z_max, n_grid=N_GRID, ez_model=L.CF_EZ_PHYSICAL, fde=L.CF_FDE_LCDM,
+            params=dict(offset=Param(0), H0=Param(1), obh2=Param(2), och2=Param(3), v=Param(4)),
+            sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=mu_values, chol=chol, z_turn=0.11),
+            bao=dict(z=z_all, val=np.concatenate([np.asarray(bao_val, float), np.atleast_1d(np.asarray(sixdf_val, float))]),
+                     qty=np.concatenate([np.asarray(bao_qty), np.atleast_1d(np.asarray(sixdf_qty))]),
+                     inv_cov=block_diag(np.asarray(bao_inv_cov, float), np.atleast_2d(np.asarray(sixdf_inv_cov, float))),
+                     dh_exact=True, rd_fit=comp["rd_fit"]),
+            cmb=dict(mode=comp["cmb_mode"], prior=comp["cmb_prior"], inv_cov=comp["cmb_inv_cov"], zstar_fit=comp["zstar_fit"]),
+            physical=_physical(comp), chi2_gauss=[(1, self.H0_TRGB[0], self.H0_TRGB[1])], device=device,
+            solve_mode=solve_mode_of(solve))
+
+
 class DesiDes5yBbnThetaStar(_Base):
     """bao/desi_des5y_bbn_theta_star.py: theta = (dM, H0, wb, wc, w0); no velocity step, exact D_H, l_A only
     (delta^2 / covariance[1,1], :110-111), BBN prior on wb (:139); bounds :122-130."""

@@ -283,6 +283,35 @@ def case_bao_desi_cmb_des5y():
     print("bao_desi_cmb_des5y.npz chi2[:3] =", out["chi2"][:3])
 
 
+def case_bao_desi_cmb_des5y_h0trgb():
+    """bao/desi_cmb_des5y_H0trgb.py: SN (N=1820, velocity step at z = 0.11) + DESI DR2 BAO (exact D_H) + the single
+    6dF D_V point with its own covariance + Planck+ACT CMB + the TRGB H0 chi^2 term."""
+    _enter_reference()
+    z, zh, mu, sig = _inject_dovekie()
+    import bao.desi_cmb_des5y_H0trgb as m
+    from scipy.linalg import block_diag
+
+    cmb = m.cmb
+    rng = np.random.default_rng(16)
+    box = [(-0.5, 0.5), (60.0, 75.0), (0.010, 0.030), (0.01, 0.25), (-6.0, 2.0)]  # nautilus prior of main() (:165-169)
+    thetas = np.vstack([_uniform(box, 14, rng), [[0.0, 67.5, 0.0224, 0.119, 0.0], [0.03, 70.39, 0.0225, 0.118, -1.2]]])
+    bao_z = np.concatenate([m.bao_data["z"], m.sixdF_bao_data["z"]])
+    bao_val = np.concatenate([m.bao_data["value"], m.sixdF_bao_data["value"]])
+    bao_qty = np.concatenate([m.desi_qty, m.sixdF_qty]).astype(np.int32)
+    out = dict(bao_z=bao_z, bao_val=bao_val, bao_qty=bao_qty,
+               bao_cov=block_diag(m.bao_cov_matrix, m.sixdF_bao_cov_matrix),
+               bao_inv_cov=block_diag(m.inv_cov_bao, m.inv_cov_6dF_bao), n_desi=np.int64(m.bao_data["z"].size))
+    out.update(_cmb_consts(cmb))
+    theory = np.array([np.concatenate([m.bao_theory(m.bao_data["z"], m.desi_qty, t),
+                                       m.bao_theory(m.sixdF_bao_data["z"], m.sixdF_qty, t)]) for t in thetas[:4]])
+    out.update(z_cmb=z, z_hel=zh, obs=mu, sigma=sig, thetas=thetas, z_max=np.float64(m.z_grid[-1]),
+               chi2=np.array([m.chi_squared(t) for t in thetas]), logl=np.array([m.log_likelihood(t) for t in thetas]),
+               theory=theory, cmb_dist=np.array([cmb.cmb_distances(t[2], t[3], t) for t in thetas[:4]]),
+               h0_prior=np.array([70.39, 1.80]))
+    np.savez_compressed(os.path.join(HERE, "bao_desi_cmb_des5y_H0trgb.npz"), **out)
+    print("bao_desi_cmb_des5y_H0trgb.npz chi2[:3] =", out["chi2"][:3])
+
+
 def case_bao_desi_des5y_bbn_theta_star():
     """bao/desi_des5y_bbn_theta_star.py (BASELINE config 5 as shipped): SN (no velocity step) + BAO (exact D_H) +
     l_A only + BBN prior on wb, thawing w0; scipy's solve_triangular."""
@@ -403,6 +432,7 @@ CASES = {
     "bao_desi_cmb": case_bao_desi_cmb,
     "bao_desi_fs_lya_cmb": case_bao_desi_fs_lya_cmb,
     "bao_desi_cmb_des5y": case_bao_desi_cmb_des5y,
+    "bao_desi_cmb_des5y_H0trgb": case_bao_desi_cmb_des5y_h0trgb,
     "bao_desi_des5y_bbn_theta_star": case_bao_desi_des5y_bbn_theta_star,
     "sn_union3_1": case_sn_union3_1,
     "sn_pantheon_dipole": case_sn_pantheon_dipole,

@@ -95,6 +95,22 @@ def test_config3_desi_cmb_des5y_golden(des5y):
     np.testing.assert_allclose(parts["cmb_vector"][:4], g["cmb_dist"], rtol=1e-12)
 
 
+def test_desi_cmb_des5y_h0trgb_golden(gpu):
+    """bao/desi_cmb_des5y_H0trgb.py: DESI + the single 6dF BAO point, TRGB H0 chi^2 term, step at z = 0.11."""
+    g = dict(golden("bao_desi_cmb_des5y_H0trgb"))
+    n = int(g["n_desi"])
+    lk = gpu.likelihoods.DesiCmbDes5yH0Trgb(
+        g["z_cmb"], g["z_hel"], g["obs"], None, g["bao_z"][:n], g["bao_val"][:n], g["bao_qty"][:n], g["bao_inv_cov"][:n, :n],
+        g["bao_z"][n:], g["bao_val"][n:], g["bao_qty"][n:], g["bao_inv_cov"][n:, n:], chol=_chol_of(g))
+    assert lk.z_max == float(g["z_max"])
+    np.testing.assert_allclose(lk.chi_squared(g["thetas"]), g["chi2"], rtol=RTOL)
+    np.testing.assert_allclose(lk.log_likelihood(g["thetas"]), g["logl"], rtol=RTOL)
+    parts = lk.engine.parts(g["thetas"][:4])
+    np.testing.assert_allclose(parts["bao_theory"], g["theory"], rtol=1e-12)
+    np.testing.assert_allclose(parts["cmb_vector"], g["cmb_dist"], rtol=1e-12)
+    lk.engine.close()
+
+
 def test_config3_full_batch_vs_c_oracle(gpu, des5y):
     """BASELINE config 3 shape at full size: N = 1820 SNe + 14 BAO + CMB, 4096 walkers."""
     from oracle import oracle_c as oc

@@ -189,6 +189,16 @@ def lk_bao_desi_cmb_des5y(g, chol):
                           cmb_prior=d["cmb_prior"], cmb_inv_cov=d["cmb_inv_cov"], zstar_fit=d["zstar_fit"], **_phys(d))
 
 
+def lk_bao_desi_cmb_des5y_H0trgb(g, chol):
+    d = _cmbdata("PLANCK_ACT")
+    return onp.Likelihood(ndim=5, z_max=float(g["z_max"]), ez_model=onp.EZ_PHYSICAL, fde=onp.FDE_LCDM, offset=onp.Slot(0),
+                          H0=onp.Slot(1), obh2=onp.Slot(2), och2=onp.Slot(3), v=onp.Slot(4), z_cmb=g["z_cmb"],
+                          z_hel=g["z_hel"], obs=g["obs"], z_turn=0.11, chol=chol, bao_z=g["bao_z"], bao_val=g["bao_val"],
+                          bao_qty=g["bao_qty"], bao_inv_cov=g["bao_inv_cov"], bao_dh_exact=True, rd_fit=d["rd_fit"], cmb_mode=1,
+                          cmb_prior=d["cmb_prior"], cmb_inv_cov=d["cmb_inv_cov"], zstar_fit=d["zstar_fit"],
+                          chi2_gauss=[(1, float(g["h0_prior"][0]), float(g["h0_prior"][1]))], **_phys(d))
+
+
 def lk_bao_desi_des5y_bbn_theta_star(g, chol):
     d = _cmbdata("PLANCK_ACT")
     inv = np.zeros((3, 3))
@@ -275,6 +285,19 @@ def test_oracle_bao_desi_cmb_des5y():
         assert onp.log_likelihood(lk, th) == pytest.approx(ll, rel=1e-11)
 
 
+def test_oracle_bao_desi_cmb_des5y_h0trgb():
+    """bao/desi_cmb_des5y_H0trgb.py: two BAO blocks (DESI + the 6dF point) as one block-diagonal block + TRGB H0 term."""
+    g = golden("bao_desi_cmb_des5y_H0trgb")
+    lk = lk_bao_desi_cmb_des5y_H0trgb(g, _chol_of(g))
+    for k in range(4):
+        th = g["thetas"][k]
+        np.testing.assert_allclose(onp.cmb_distances(lk, th), g["cmb_dist"][k], rtol=1e-13)
+        np.testing.assert_allclose(onp.bao_theory(lk, th), g["theory"][k], rtol=1e-12)
+    for th, c2, ll in zip(g["thetas"][:8], g["chi2"][:8], g["logl"][:8]):
+        assert onp.chi_squared(lk, th) == pytest.approx(c2, rel=1e-11)
+        assert onp.log_likelihood(lk, th) == pytest.approx(ll, rel=1e-11)
+
+
 def test_oracle_bao_desi_des5y_bbn_theta_star():
     g = golden("bao_desi_des5y_bbn_theta_star")
     lk = lk_bao_desi_des5y_bbn_theta_star(g, _chol_of(g))
@@ -293,7 +316,7 @@ def test_oracle_bao_desi_des5y_bbn_theta_star():
 
 # ---- the C restatement on the joint likelihoods -----------------------------------------------------------
 @pytest.mark.parametrize("name", ["bao_desi", "bao_desi_cmb", "bao_desi_fs_lya_cmb", "bao_desi_cmb_des5y",
-                                  "bao_desi_des5y_bbn_theta_star"])
+                                  "bao_desi_cmb_des5y_H0trgb", "bao_desi_des5y_bbn_theta_star"])
 def test_c_oracle_joint_likelihoods(name):
     from oracle import oracle_c as oc
 
