@@ -119,6 +119,7 @@ static int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
 }
+int cf_set_error(int code, const std::string& msg) { return fail(code, msg); }  // for cosmofit_ensemble.hip
 
 #define HIP_TRY(expr)                                                                              \
   do {                                                                                             \

@@ -19,6 +19,11 @@ tests check.
 
 `log_prob_fn(theta[W, ndim] tensor) -> tensor[W]` is pluggable: on a GPU it is
 ``LikelihoodEngine.torch_log_prob`` (HIP kernels through cf_eval_device on the current stream).
+
+On a GPU the proposal and accept arithmetic runs in the library's own kernels (cf_ens_kde_prepare / cf_ens_propose /
+cf_ens_accept, csrc/cosmofit_ensemble.hip: the same counter-based random numbers and formulae as the tensor code
+below, two or three launches per half-step and no host round trip); the tensor code is the CPU path of the gloo
+tests and the statement of what those kernels compute.
 """
 from __future__ import annotations
 
@@ -57,10 +62,14 @@ def _mix(x: torch.Tensor) -> torch.Tensor:
     return x ^ _lsr(x, 31)
 
 
+def stream_key(seed: int, step: int, half: int, stream: int = 0) -> int:
+    """Unsigned 64-bit key of random stream `stream` for (seed, step, half); stream s has key(stream 0) + s."""
+    return ((seed * 1000003 + step) * 8 + half * 4 + stream + 0x5851F42D4C957F2D) & 0xFFFFFFFFFFFFFFFF
+
+
 def uniform01(seed: int, step: int, half: int, walker_ids: torch.Tensor, stream: int) -> torch.Tensor:
     """float64 uniforms in [0, 1), a pure function of its arguments (walker_ids: int64 tensor)."""
-    key = (seed * 1000003 + step) * 8 + half * 4 + stream
-    key = ((key + 0x5851F42D4C957F2D) & 0xFFFFFFFFFFFFFFFF)
+    key = stream_key(seed, step, half, stream)
     key = key - (1 << 64) if key >= (1 << 63) else key  # as signed int64
     x = _mix(walker_ids * _M1 + key)
     x = _mix(x + _M1)
@@ -102,12 +111,27 @@ class ShardedEnsemble:
         self.ids = torch.arange(self.start, self.stop, dtype=torch.int64, device=self.x.device)
         self.seed, self.a, self.step_count = seed, a, 0
         self.logp = self.log_prob_fn(self.x)
-        self.n_accepted = 0
-        self.n_proposed = 0
+        self._n_accepted = 0
+        self._n_proposed = 0
         counts = [shard_bounds(self.n_total, self.world, r) for r in range(self.world)]
         self._equal = len({b - a_ for a_, b in counts}) == 1
         self._max_local = max(b - a_ for a_, b in counts)
         self._counts = counts
+        # the two halves of this rank's shard: local indices and global ids, fixed for the life of the ensemble
+        self._act_idx = [torch.nonzero((self.ids % 2) == h, as_tuple=False)[:, 0].contiguous() for h in (0, 1)]
+        self._act_ids = [self.ids[i].contiguous() for i in self._act_idx]
+        self._native = self.x.is_cuda
+        if self._native:
+            from . import _lib as L
+
+            self._L = L
+            self._lib = L.lib()  # raises if the HIP library is missing: no silent tensor-code fallback on a GPU
+            dev, nmax = self.x.device, max(int(i.numel()) for i in self._act_idx)
+            self._y = torch.empty((max(nmax, 1), self.ndim), dtype=torch.float64, device=dev)
+            self._logfac = torch.empty(max(nmax, 1), dtype=torch.float64, device=dev)
+            self._kde_params = torch.empty(2 * self.ndim * self.ndim + 1, dtype=torch.float64, device=dev)
+            self._kde_wc = torch.empty((self.n_total // 2, self.ndim), dtype=torch.float64, device=dev)
+            self._n_acc_dev = torch.zeros(1, dtype=torch.int64, device=dev)
 
     # ---- the exchange step ---------------------------------------------------------------------------
     def gather_positions(self) -> torch.Tensor:
@@ -179,8 +203,36 @@ class ShardedEnsemble:
         return self.moves[-1][0]
 
     # ---- one ensemble step = two red/blue half-steps --------------------------------------------------------
+    def _step_native(self, move: str):
+        """One step with the library's kernels: per half-step all-gather -> [KDE fit] -> propose -> log P -> accept,
+        everything asynchronous on the current stream."""
+        L, lib = self._L, self._lib
+        kind = {"stretch": 0, "de": 1, "kde": 2}[move]
+        stream = torch.cuda.current_stream(self.x.device).cuda_stream
+        for half in (0, 1):
+            allpos = self.gather_positions()
+            ids, idx = self._act_ids[half], self._act_idx[half]
+            n = int(ids.numel())
+            if n == 0:
+                continue
+            key0 = stream_key(self.seed, self.step_count, half)
+            if kind == 2:
+                L.check(lib.cf_ens_kde_prepare(allpos.data_ptr(), self.n_total, self.ndim, half, self._kde_params.data_ptr(),
+                                               self._kde_wc.data_ptr(), stream))
+            y, logfac = self._y[:n], self._logfac[:n]
+            L.check(lib.cf_ens_propose(kind, allpos.data_ptr(), self.n_total, self.ndim, half, ids.data_ptr(), n, key0,
+                                       float(self.a), float(self.de_sigma), self._kde_params.data_ptr(), self._kde_wc.data_ptr(),
+                                       y.data_ptr(), logfac.data_ptr(), stream))
+            lp_new = self.log_prob_fn(y)
+            L.check(lib.cf_ens_accept(ids.data_ptr(), idx.data_ptr(), n, self.ndim, key0, y.data_ptr(), lp_new.data_ptr(),
+                                      logfac.data_ptr(), self.x.data_ptr(), self.logp.data_ptr(), self._n_acc_dev.data_ptr(), stream))
+            self._n_proposed += n
+        self.step_count += 1
+
     def step(self):
         move = self._pick_move()
+        if self._native:
+            return self._step_native(move)
         propose = {"stretch": self._propose_stretch, "de": self._propose_de, "kde": self._propose_kde}[move]
         for half in (0, 1):
             allpos = self.gather_positions()
@@ -197,9 +249,18 @@ class ShardedEnsemble:
                 idx = torch.nonzero(active, as_tuple=False)[:, 0][accept]
                 self.x[idx] = y[accept]
                 self.logp[idx] = lp_new[accept]
-                self.n_accepted += int(accept.sum())
-                self.n_proposed += int(active.sum())
+                self._n_accepted += int(accept.sum())
+                self._n_proposed += int(active.sum())
         self.step_count += 1
+
+    @property
+    def n_accepted(self) -> int:
+        """Accepted moves of this rank's walkers so far (reads the device counter: synchronises)."""
+        return int(self._n_acc_dev.item()) if self._native else self._n_accepted
+
+    @property
+    def n_proposed(self) -> int:
+        return self._n_proposed
 
     def run(self, n_steps: int):
         for _ in range(n_steps):

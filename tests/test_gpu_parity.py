@@ -234,6 +234,50 @@ def test_device_ensemble_stretch_move_matches_oracle_driven_chain(gpu):
     lk.engine.close()
 
 
+@pytest.mark.parametrize("ndim,n_total", [(4, 512), (6, 130), (1, 64)])
+def test_native_ensemble_moves_match_the_tensor_code(gpu, ndim, n_total):
+    """cf_ens_kde_prepare / cf_ens_propose / cf_ens_accept against ensemble.py's tensor formulation of the same moves
+    (same counter-based random numbers): proposals, Hastings factors, KDE fit, accept decisions."""
+    torch = pytest.importorskip("torch")
+    E = gpu.ensemble
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(ndim)
+    pos = torch.from_numpy(rng.standard_normal((n_total, ndim)) * np.linspace(0.5, 2.0, ndim) + 3.0).to(dev)
+    f = lambda t: -0.5 * ((t - 3.0) ** 2).sum(dim=1)
+    ens = E.ShardedEnsemble(f, pos, seed=11, moves=E.REFERENCE_MOVES)
+    assert ens._native
+    lib, L, stream = gpu.lib(), gpu._lib, torch.cuda.current_stream(dev).cuda_stream
+    for step in (0, 5):
+        ens.step_count = step
+        for half in (0, 1):
+            ids, idx = ens._act_ids[half], ens._act_idx[half]
+            n, comp, key0 = int(ids.numel()), pos[(1 - half)::2], E.stream_key(ens.seed, step, half)
+            for kind, name in enumerate(("stretch", "de", "kde")):
+                want_y, want_lf = getattr(ens, "_propose_" + name)(pos[ids], ids, comp, half)
+                if kind == 2:
+                    L.check(lib.cf_ens_kde_prepare(pos.data_ptr(), n_total, ndim, half, ens._kde_params.data_ptr(),
+                                                   ens._kde_wc.data_ptr(), stream))
+                y, lf = torch.empty((n, ndim), dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev)
+                L.check(lib.cf_ens_propose(kind, pos.data_ptr(), n_total, ndim, half, ids.data_ptr(), n, key0, ens.a, ens.de_sigma,
+                                           ens._kde_params.data_ptr(), ens._kde_wc.data_ptr(), y.data_ptr(), lf.data_ptr(), stream))
+                torch.cuda.synchronize()
+                np.testing.assert_allclose(y.cpu().numpy(), want_y.cpu().numpy(), rtol=1e-11, atol=1e-12, err_msg=name)
+                np.testing.assert_allclose(lf.cpu().numpy(), want_lf.cpu().numpy(), rtol=1e-9, atol=1e-9, err_msg=name)
+                # accept: same decisions as log(u) < log_factor + lp_new - lp_old, counted on the device
+                x_loc, lp_loc = ens.x.clone(), ens.logp.clone()
+                lp_new = f(y)
+                u = E.uniform01(ens.seed, step, half, ids, 2)
+                want_acc = torch.log(u) < (lf + lp_new - lp_loc[idx])
+                count = torch.zeros(1, dtype=torch.int64, device=dev)
+                L.check(lib.cf_ens_accept(ids.data_ptr(), idx.data_ptr(), n, ndim, key0, y.data_ptr(), lp_new.data_ptr(),
+                                          lf.data_ptr(), x_loc.data_ptr(), lp_loc.data_ptr(), count.data_ptr(), stream))
+                torch.cuda.synchronize()
+                assert int(count.item()) == int(want_acc.sum())
+                exp_x = ens.x.clone()
+                exp_x[idx[want_acc]] = y[want_acc]
+                assert torch.equal(x_loc, exp_x)
+
+
 def test_in_kernel_log10_is_within_one_ulp(gpu):
     import ctypes as C
     rng = np.random.default_rng(0)
