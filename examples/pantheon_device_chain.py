@@ -47,12 +47,12 @@ def main():
     ens = amd.ensemble.ShardedEnsemble(lk.engine.torch_log_prob(), torch.from_numpy(start).to(dev), seed=7,
                                        moves=amd.ensemble.REFERENCE_MOVES)
     ens.run(args.burn)
+    acc = torch.zeros(4, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    acc = torch.zeros(4, dtype=torch.float64, device=dev)
     for _ in range(args.steps):
         ens.step()
-        acc += ens.x.sum(0)
+        acc.add_(ens.x.sum(0))  # running sum of the positions, on the device
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:

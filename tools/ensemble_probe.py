@@ -19,3 +19,10 @@ for name in ("stretch", "de", "kde"):
     e.run(5); torch.cuda.synchronize(); t0 = time.perf_counter()
     e.run(30); torch.cuda.synchronize()
     print(f"{name:8s}: {(time.perf_counter() - t0) / 30 * 1e3:.3f} ms per step (2 half-steps of {W // 2} walkers), acceptance {e.acceptance_fraction():.2f}")
+e = amd.ensemble.ShardedEnsemble(f, x0, seed=3, moves=amd.ensemble.REFERENCE_MOVES)
+e.run(5); torch.cuda.synchronize(); t0 = time.perf_counter()
+e.run(100); torch.cuda.synchronize()
+print(f"reference mixture (KDE 30 % + DE 70 %): {(time.perf_counter() - t0) / 100 * 1e3:.3f} ms per step")
+t0 = time.perf_counter()
+for _ in range(100): e._pick_move()
+print(f"host side of one step: _pick_move {(time.perf_counter() - t0) / 100 * 1e6:.0f} us")
