@@ -565,11 +565,10 @@ __device__ __forceinline__ void sn_fast_loop(const cf_dev_desc& d, const DistTab
   }
   // {has_vstep ? 1 + z_cmb : z_cmb, step, 1 + z_hel, obs}: the two sums are the reference's own first operations
   const d4* __restrict__ rec = reinterpret_cast<const d4*>(d.sn_rec) + tid;
-  d4 cur = rec[0];
-  for (int i = tid; i < d.n_ld; i += CF_TPB_A) {
-    rec += CF_TPB_A;
-    const d4 nxt = rec[0];  // the record array carries 512 spare entries
-    const double za = cur[0], st = cur[1], zhp1 = cur[2], ob = cur[3];
+  // rows n_sn .. n_ld - 1 are zero padding for the MFMA tiles / the 64-row blocks of the inverse-GEMM solve
+  if (tid < d.n_ld - n_sn) out[n_sn + tid] = 0.0;
+  auto one_sn = [&](const d4& r, int i) {
+    const double za = r[0], st = r[1], zhp1 = r[2], ob = r[3];
     double z_cosmo = za;
     if (d.has_vstep) {
       if (PM1) {
@@ -579,9 +578,20 @@ __device__ __forceinline__ void sn_fast_loop(const cf_dev_desc& d, const DistTab
         z_cosmo = -1.0 + za / (1.0 + z_pec);
       }
     }
-    const double res = ob - off - (25.0 + 5 * log10_tab(zhp1 * hermite_fast(T, z_cosmo), log_tab));
-    out[i] = i < n_sn ? res : 0.0;  // rows >= n_sn are zero padding for the MFMA tiles / the 64-row blocks of the inverse-GEMM solve
-    cur = nxt;
+    out[i] = ob - off - (25.0 + 5 * log10_tab(zhp1 * hermite_fast(T, z_cosmo), log_tab));
+  };
+  // two records in flight, ping-pong (no register copies); the record array carries 512 spare entries past n_ld
+  d4 ra = rec[0], rb;
+  int i = tid;
+  while (i < n_sn) {
+    rb = rec[CF_TPB_A];
+    one_sn(ra, i);
+    i += CF_TPB_A;
+    if (i >= n_sn) break;
+    rec += 2 * CF_TPB_A;
+    ra = rec[0];
+    one_sn(rb, i);
+    i += CF_TPB_A;
   }
 }
 
