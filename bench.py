@@ -206,7 +206,7 @@ def main():
         traffic = out["roofline"]["traffic"]
         out["roofline"]["hbm_gbps_measured"] = traffic / (solve_ms * 1e-3) / 1e9 if traffic else None
         out["roofline"]["trsv_equivalent_gbps"] = 8.0 * args.n_sn * (args.n_sn + 1) / 2 * out["value"] / 1e9
-        if world == 1:
+        if world == 1 and not args.no_cpu_baseline:  # context probes (this and cpu_baseline) stay out of profiled runs
             out["roofline"]["hbm_stream_triad_gbps"] = stream_triad_gbps(torch, dev)
         if world == 1 and args.workload == "pantheon":
             # the ctypes boundary as emcee / nautilus call it: host numpy in, host numpy out (PCIe + sync included).
