@@ -117,6 +117,7 @@ class ShardedEnsemble:
         self._equal = len({b - a_ for a_, b in counts}) == 1
         self._max_local = max(b - a_ for a_, b in counts)
         self._counts = counts
+        self._allpos = None
         # the two halves of this rank's shard: local indices and global ids, fixed for the life of the ensemble
         self._act_idx = [torch.nonzero((self.ids % 2) == h, as_tuple=False)[:, 0].contiguous() for h in (0, 1)]
         self._act_ids = [self.ids[i].contiguous() for i in self._act_idx]
@@ -139,9 +140,10 @@ class ShardedEnsemble:
         if self.world == 1:
             return self.x
         if self._equal:
-            out = torch.empty((self.n_total, self.ndim), dtype=self.x.dtype, device=self.x.device)
-            dist.all_gather_into_tensor(out, self.x, group=self.group)
-            return out
+            if self._allpos is None:  # one buffer for the life of the ensemble: the collective runs every half-step
+                self._allpos = torch.empty((self.n_total, self.ndim), dtype=self.x.dtype, device=self.x.device)
+            dist.all_gather_into_tensor(self._allpos, self.x, group=self.group)
+            return self._allpos
         # ragged shards: pad to the largest shard, gather, strip
         pad = torch.zeros((self._max_local, self.ndim), dtype=self.x.dtype, device=self.x.device)
         pad[: self.x.shape[0]] = self.x
