@@ -102,3 +102,25 @@ def test_gpu_interpolators_random_grids(pkg, seed, n, nq):
     xq = np.concatenate([rng.uniform(x[0] - 1, x[-1] + 1, nq), x[:: max(1, n // 7)]])
     np.testing.assert_allclose(pkg.interpolator.interp_hermite(xq, x, y, yp), onp.interp_hermite(xq, x, y, yp), rtol=1e-13, atol=1e-13)
     np.testing.assert_allclose(pkg.interpolator.interp_pchip(xq, x, y), onp.interp_pchip(xq, x, y), rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.gpu
+@settings(max_examples=8, **SET)
+@given(st.integers(0, 10**6), st.integers(1, 400), st.integers(1, 90), st.sampled_from(["inverse", "blocked"]))
+def test_gpu_sn_likelihood_random_sizes_both_solves(pkg, seed, n_sn, n_walkers, solve):
+    """Full path (walker kernel + either solve kernel) at ragged sizes: N not a multiple of 16 / 64, W not a multiple
+    of 16 / 32, against the C oracle at the 1e-10 bar."""
+    if pkg.lib().cf_device_count() < 1:
+        pytest.fail("needs an MI355X")
+    from oracle import oracle_np as onp
+
+    syn = pkg.synthetic.pantheon_like(n_sn=n_sn, seed=seed)
+    lk = pkg.sn_pantheon.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"], solve=solve)
+    ref = oc.COracle(onp.Likelihood(
+        ndim=4, z_max=lk.z_max, offset=onp.Slot(0), H0=onp.Slot(1), Om=onp.Slot(2), v=onp.Slot(3),
+        z_cmb=syn["z_cmb"], z_hel=syn["z_hel"], obs=syn["obs"], chol=syn["chol"],
+        bounds=pkg.sn_pantheon.bounds, gauss=[pkg.sn_pantheon.H0_PRIOR]))
+    theta = pkg.synthetic.walkers(pkg.sn_pantheon.bounds, n_walkers, seed=seed + 1)
+    np.testing.assert_allclose(lk.chi_squared(theta), ref.chi2(theta), rtol=1e-10)
+    np.testing.assert_allclose(lk.log_probs_vectorized(theta), ref.logp(theta), rtol=1e-10)
+    lk.engine.close()
