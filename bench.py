@@ -50,9 +50,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--solve", default="default", choices=["default", "blocked", "inverse"],
                     help="solve kernel: blocked TRSM or the inverse-GEMM form (default: the library's choice)")
-    ap.add_argument("--workload", default="pantheon", choices=["pantheon", "desi_cmb_des5y"],
+    ap.add_argument("--workload", default="pantheon", choices=["pantheon", "desi_cmb_des5y", "desi_des5y_bbn_theta_star"],
                     help="pantheon = BASELINE configs[1] (the headline, default); desi_cmb_des5y = configs[2] shape "
-                         "(N=1820 SN + 14 BAO + Planck/ACT CMB, physical-density E(z)) on the committed fixture data")
+                         "(N=1820 SN + 14 BAO + Planck/ACT CMB, physical-density E(z)); desi_des5y_bbn_theta_star = "
+                         "configs[4] shape (N=1820 SN + 13 BAO + l_A + BBN prior, thawing dark energy, log P as nautilus "
+                         "would batch it); both on the committed fixture data")
     args = ap.parse_args()
 
     import torch
@@ -103,6 +105,16 @@ def main():
                                           g["bao_inv_cov"], chol=chol, device=local_rank, **solve_kw)
         box = np.array([(-0.5, 0.5), (60.0, 75.0), (0.010, 0.030), (0.01, 0.25), (-4.5, 4.5)])  # bao/desi_cmb_des5y.py:156-161
         args.n_sn, ndim, kind = int(g["z_cmb"].size), 5, pkg.CF_OUT_LOGL
+        args.no_cpu_baseline = True
+    elif args.workload == "desi_des5y_bbn_theta_star":
+        g = np.load(os.path.join(ROOT, "tests", "golden", "bao_desi_des5y_bbn_theta_star.npz"))
+        rng = np.random.default_rng(0)
+        A = 0.01 * rng.standard_normal((g["sigma"].size, 40))
+        chol = np.linalg.cholesky(np.diag(g["sigma"] ** 2) + A @ A.T)
+        lk = pkg.likelihoods.DesiDes5yBbnThetaStar(g["z_cmb"], g["z_hel"], g["obs"], None, g["bao_z"], g["bao_val"], g["bao_qty"],
+                                                   g["bao_inv_cov"], chol=chol, device=local_rank)
+        box = g["bounds"]  # bao/desi_des5y_bbn_theta_star.py:122-130
+        args.n_sn, ndim, kind = int(g["z_cmb"].size), 5, pkg.CF_OUT_LOGP
         args.no_cpu_baseline = True
     else:
         syn = pkg.synthetic.pantheon_like(n_sn=args.n_sn, seed=0)
@@ -162,8 +174,10 @@ def main():
         solve_flops = flops_per_eval_solve(args.n_sn) * Wl
         achieved = solve_flops / (solve_ms * 1e-3) / 1e12
         out = {
-            "metric": "walker-logL evals/s, Pantheon+ 1701-SN full-cov chi2" if args.workload == "pantheon" else
-                      "walker-logL evals/s, DESI BAO + Planck/ACT CMB + DES-SN joint chi2 (config 3 shape)",
+            "metric": {"pantheon": "walker-logL evals/s, Pantheon+ 1701-SN full-cov chi2",
+                       "desi_cmb_des5y": "walker-logL evals/s, DESI BAO + Planck/ACT CMB + DES-SN joint chi2 (config 3 shape)",
+                       "desi_des5y_bbn_theta_star": "walker-logL evals/s, DESI BAO + l_A + BBN + DES-SN joint log P (config 5 shape)",
+                       }[args.workload],
             "value": W_total * args.steps / dt,
             "unit": "evals/s",
             "n_gpus": world,
@@ -180,7 +194,9 @@ def main():
                              f"{Wl} walkers per GPU per step (BASELINE configs[1] at N=1), G=4000, theta resident in HBM")
                 if args.workload == "pantheon" else
                 (f"bao/desi_cmb_des5y.py joint log L: {args.n_sn} SNe (velocity step) + 14 BAO (PCHIP D_H, F_AP) + Planck/ACT "
-                 f"(R, l_A, wb), physical-density E(z), {Wl} walkers per GPU per step"),
+                 f"(R, l_A, wb), physical-density E(z), {Wl} walkers per GPU per step") if args.workload == "desi_cmb_des5y" else
+                (f"bao/desi_des5y_bbn_theta_star.py joint log P: {args.n_sn} SNe + 13 BAO (exact D_H) + l_A + BBN prior, "
+                 f"physical-density E(z) with thawing dark energy, {Wl} walkers per GPU per step"),
                 "walkers_per_gpu": Wl, "walkers_total": W_total, "n_sn": args.n_sn, "n_grid": 4000, "ndim": ndim,
                 "parallelism": f"walkers sharded over {world} GPU(s)" + (", RCCL all-gather of positions per step" if world > 1 else ""),
             },
