@@ -149,6 +149,26 @@ class DesiCmbDes5yH0Trgb(_Base):
             solve_mode=solve_mode_of(solve))
 
 
+class SnCmb(_Base):
+    """sn/pantheon_cmb.py and sn/des5y_cmb.py: theta = (M or dM, H0, wb, wc, v); SN with velocity step at z_turn (0.15,
+    sn/pantheon_cmb.py:65; 0.11, sn/des5y_cmb.py:71) + Planck+ACT (R, l_A, wb), physical densities with Lambda as shipped;
+    box prior of sn/pantheon_cmb.py:91-99 when `bounds` is given (the DES script samples with nautilus: log L only)."""
+    PANTHEON_BOUNDS = np.array([(-20.0, -19.0), (60.0, 75.0), (0.010, 0.030), (0.010, 0.25), (-2.5, 2.5)])
+
+    def __init__(self, z_cmb, z_hel, obs, cov_sn, *, z_turn, chol=None, comp=None, bounds=None, device=0, solve="auto"):
+        comp = cmb_data.PLANCK_ACT if comp is None else comp
+        if chol is None:
+            chol = cho_factor(cov_sn, lower=True)[0]
+        self.bounds = None if bounds is None else np.asarray(bounds, float)
+        self.z_max = float(np.max(z_cmb) + 0.1)
+        self.engine = LikelihoodEngine(
+            ndim=5, z_max=self.z_max, n_grid=N_GRID, ez_model=L.CF_EZ_PHYSICAL, fde=L.CF_FDE_LCDM,
+            params=dict(offset=Param(0), H0=Param(1), obh2=Param(2), och2=Param(3), v=Param(4)),
+            sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=obs, chol=chol, z_turn=z_turn),
+            cmb=dict(mode=comp["cmb_mode"], prior=comp["cmb_prior"], inv_cov=comp["cmb_inv_cov"], zstar_fit=comp["zstar_fit"]),
+            physical=_physical(comp), bounds=self.bounds, device=device, solve_mode=solve_mode_of(solve))
+
+
 class DesiDes5yBbnThetaStar(_Base):
     """bao/desi_des5y_bbn_theta_star.py: theta = (dM, H0, wb, wc, w0); no velocity step, exact D_H, l_A only
     (delta^2 / covariance[1,1], :110-111), BBN prior on wb (:139); bounds :122-130."""

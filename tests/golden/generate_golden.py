@@ -335,6 +335,58 @@ def case_bao_desi_des5y_bbn_theta_star():
 
 
 
+def case_sn_des5y():
+    """sn/des5y.py: the flat-LCDM SN likelihood on DES-Dovekie (N = 1820), velocity step at z = 0.11, log L only."""
+    _enter_reference()
+    z, zh, mu, sig = _inject_dovekie()
+    import sn.des5y as m
+
+    rng = np.random.default_rng(21)
+    box = [(-1.0, 1.0), (60.0, 80.0), (0.0, 0.8), (-5.0, 5.0)]  # nautilus prior of main() (:76-80; H0 is normal(70.39, 1.80))
+    thetas = np.vstack([_uniform(box, 14, rng), [[0.0, 70.39, 0.33, 0.0], [0.05, 68.0, 0.30, -1.5]]])
+    out = dict(z_cmb=z, z_hel=zh, obs=mu, sigma=sig, thetas=thetas, z_max=np.float64(m.z_grid[-1]),
+               chi2=np.array([m.chi_squared(t) for t in thetas]), logl=np.array([m.log_likelihood(t) for t in thetas]))
+    np.savez_compressed(os.path.join(HERE, "sn_des5y.npz"), **out)
+    print("sn_des5y.npz chi2[:3] =", out["chi2"][:3])
+
+
+def case_sn_des5y_cmb():
+    """sn/des5y_cmb.py: DES-Dovekie SNe (step at z = 0.11) + Planck+ACT compressed CMB, physical-density LCDM."""
+    _enter_reference()
+    z, zh, mu, sig = _inject_dovekie()
+    import sn.des5y_cmb as m
+
+    cmb = m.cmb
+    rng = np.random.default_rng(22)
+    box = [(-0.7, 0.7), (55.0, 75.0), (0.01, 0.03), (0.01, 0.25), (-4.5, 4.5)]  # nautilus prior of main() (:113-117)
+    thetas = np.vstack([_uniform(box, 12, rng), [[0.0, 67.5, 0.0224, 0.119, 0.0], [0.03, 68.0, 0.0225, 0.118, -1.2]]])
+    out = _cmb_consts(cmb)
+    out.update(z_cmb=z, z_hel=zh, obs=mu, sigma=sig, thetas=thetas, z_max=np.float64(m.z_grid[-1]),
+               chi2=np.array([m.chi_squared(t) for t in thetas]), logl=np.array([m.log_likelihood(t) for t in thetas]),
+               chi2_sn=np.array([m.chi2_sn(t) for t in thetas]), chi2_cmb=np.array([m.chi2_cmb(t) for t in thetas]),
+               cmb_dist=np.array([cmb.cmb_distances(t[2], t[3], t) for t in thetas[:4]]))
+    np.savez_compressed(os.path.join(HERE, "sn_des5y_cmb.npz"), **out)
+    print("sn_des5y_cmb.npz chi2[:3] =", out["chi2"][:3])
+
+
+def case_sn_pantheon_cmb():
+    """sn/pantheon_cmb.py: Pantheon+ SNe (step at z = 0.15) + Planck+ACT compressed CMB, box prior (:91-99)."""
+    _enter_reference()
+    z, zh, mb, sig = _inject_pantheon()
+    import sn.pantheon_cmb as m
+
+    cmb = m.cmb
+    rng = np.random.default_rng(23)
+    thetas = theta_batch(m.bounds, 12, rng)
+    out = _cmb_consts(cmb)
+    with np.errstate(all="ignore"):
+        out.update(z_cmb=z, z_hel=zh, obs=mb, sigma=sig, bounds=m.bounds, thetas=thetas, z_max=np.float64(m.z_grid[-1]),
+                   chi2=np.array([m.chi_squared(t) for t in thetas]), logp=np.array([m.log_probability(t) for t in thetas]),
+                   cmb_dist=np.array([cmb.cmb_distances(t[2], t[3], t) for t in thetas[:4]]))
+    np.savez_compressed(os.path.join(HERE, "sn_pantheon_cmb.npz"), **out)
+    print("sn_pantheon_cmb.npz chi2[:3] =", out["chi2"][:3])
+
+
 def case_sn_union3_1():
     """sn/union3_1.py: 22 binned distances with the REAL covariance (explicit inverse), H0 fixed to 70, velocity
     step at z = 0.2.  Everything it needs is in the snapshot."""
@@ -434,6 +486,9 @@ CASES = {
     "bao_desi_cmb_des5y": case_bao_desi_cmb_des5y,
     "bao_desi_cmb_des5y_H0trgb": case_bao_desi_cmb_des5y_h0trgb,
     "bao_desi_des5y_bbn_theta_star": case_bao_desi_des5y_bbn_theta_star,
+    "sn_des5y": case_sn_des5y,
+    "sn_des5y_cmb": case_sn_des5y_cmb,
+    "sn_pantheon_cmb": case_sn_pantheon_cmb,
     "sn_union3_1": case_sn_union3_1,
     "sn_pantheon_dipole": case_sn_pantheon_dipole,
     "sn_pantheon_and_sh0es": case_sn_pantheon_and_sh0es,

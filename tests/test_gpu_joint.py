@@ -111,6 +111,37 @@ def test_desi_cmb_des5y_h0trgb_golden(gpu):
     lk.engine.close()
 
 
+def test_sn_des5y_and_the_two_sn_cmb_scripts_golden(gpu):
+    """sn/des5y.py through the Pantheon mirror (step at z = 0.11, no H0 prior), sn/des5y_cmb.py and sn/pantheon_cmb.py
+    through likelihoods.SnCmb."""
+    g = golden("sn_des5y")
+    box = np.array([(-1.0, 1.0), (60.0, 80.0), (0.0, 0.8), (-5.0, 5.0)])
+    lk = gpu.sn_pantheon.PantheonLikelihood(g["z_cmb"], g["z_hel"], g["obs"], chol=_chol_of(g), z_turn=0.11, h0_prior=None, bounds=box)
+    assert lk.z_max == float(g["z_max"])
+    np.testing.assert_allclose(lk.chi_squared(g["thetas"]), g["chi2"], rtol=RTOL)
+    np.testing.assert_allclose(lk.log_likelihood(g["thetas"]), g["logl"], rtol=RTOL)
+    lk.engine.close()
+
+    g = golden("sn_des5y_cmb")
+    lk = gpu.likelihoods.SnCmb(g["z_cmb"], g["z_hel"], g["obs"], None, z_turn=0.11, chol=_chol_of(g))
+    np.testing.assert_allclose(lk.chi_squared(g["thetas"]), g["chi2"], rtol=RTOL)
+    np.testing.assert_allclose(lk.log_likelihood(g["thetas"]), g["logl"], rtol=RTOL)
+    parts = lk.engine.parts(g["thetas"])
+    np.testing.assert_allclose(parts["chi2_blocks"][:, 0], g["chi2_sn"], rtol=RTOL)
+    np.testing.assert_allclose(parts["chi2_blocks"][:, 2], g["chi2_cmb"], rtol=1e-9)
+    np.testing.assert_allclose(parts["cmb_vector"][:4], g["cmb_dist"], rtol=1e-12)
+    lk.engine.close()
+
+    g = golden("sn_pantheon_cmb")
+    lk = gpu.likelihoods.SnCmb(g["z_cmb"], g["z_hel"], g["obs"], None, z_turn=0.15, chol=_chol_of(g), bounds=g["bounds"])
+    fin = np.isfinite(g["logp"])
+    got = lk.log_probs_vectorized(g["thetas"])
+    np.testing.assert_allclose(got[fin], g["logp"][fin], rtol=RTOL)
+    assert np.all(got[~fin] == -np.inf)
+    np.testing.assert_allclose(lk.chi_squared(g["thetas"])[fin], g["chi2"][fin], rtol=RTOL)
+    lk.engine.close()
+
+
 def test_config3_full_batch_vs_c_oracle(gpu, des5y):
     """BASELINE config 3 shape at full size: N = 1820 SNe + 14 BAO + CMB, 4096 walkers."""
     from oracle import oracle_c as oc

@@ -298,6 +298,46 @@ def test_oracle_bao_desi_cmb_des5y_h0trgb():
         assert onp.log_likelihood(lk, th) == pytest.approx(ll, rel=1e-11)
 
 
+def lk_sn_cmb(g, chol, z_turn, bounds=None):
+    d = _cmbdata("PLANCK_ACT")
+    return onp.Likelihood(ndim=5, z_max=float(g["z_max"]), ez_model=onp.EZ_PHYSICAL, fde=onp.FDE_LCDM, offset=onp.Slot(0),
+                          H0=onp.Slot(1), obh2=onp.Slot(2), och2=onp.Slot(3), v=onp.Slot(4), z_cmb=g["z_cmb"],
+                          z_hel=g["z_hel"], obs=g["obs"], z_turn=z_turn, chol=chol, cmb_mode=1, cmb_prior=d["cmb_prior"],
+                          cmb_inv_cov=d["cmb_inv_cov"], zstar_fit=d["zstar_fit"], bounds=bounds, **_phys(d))
+
+
+def test_oracles_sn_des5y_and_the_two_sn_cmb_scripts():
+    """sn/des5y.py (flat LCDM on DES-Dovekie, step at z = 0.11), sn/des5y_cmb.py and sn/pantheon_cmb.py (SN + Planck/ACT)."""
+    from oracle import oracle_c as oc
+
+    g = golden("sn_des5y")
+    lk = onp.Likelihood(ndim=4, z_max=float(g["z_max"]), offset=onp.Slot(0), H0=onp.Slot(1), Om=onp.Slot(2), v=onp.Slot(3),
+                        z_cmb=g["z_cmb"], z_hel=g["z_hel"], obs=g["obs"], z_turn=0.11, chol=_chol_of(g))
+    for th, c2 in zip(g["thetas"][:4], g["chi2"][:4]):
+        assert onp.chi_squared(lk, th) == pytest.approx(c2, rel=1e-11)
+    co = oc.COracle(lk)
+    np.testing.assert_allclose(co.chi2(g["thetas"]), g["chi2"], rtol=1e-10)
+    np.testing.assert_allclose(co.logl(g["thetas"]), g["logl"], rtol=1e-10)
+
+    g = golden("sn_des5y_cmb")
+    lk = lk_sn_cmb(g, _chol_of(g), 0.11)
+    for k in range(3):
+        np.testing.assert_allclose(onp.cmb_distances(lk, g["thetas"][k]), g["cmb_dist"][k], rtol=1e-13)
+        assert onp.chi_squared(lk, g["thetas"][k]) == pytest.approx(g["chi2"][k], rel=1e-11)
+    co = oc.COracle(lk)
+    np.testing.assert_allclose(co.chi2(g["thetas"]), g["chi2"], rtol=1e-10)
+
+    g = golden("sn_pantheon_cmb")
+    lk = lk_sn_cmb(g, _chol_of(g), 0.15, bounds=g["bounds"])
+    fin = np.isfinite(g["logp"])
+    co = oc.COracle(lk)
+    got = co.logp(g["thetas"])
+    np.testing.assert_allclose(got[fin], g["logp"][fin], rtol=1e-10)
+    assert np.all(got[~fin] == -np.inf) and (~fin).sum() >= 10
+    k = int(np.flatnonzero(fin)[0])
+    assert onp.log_probability(lk, g["thetas"][k]) == pytest.approx(g["logp"][k], rel=1e-11)
+
+
 def test_oracle_bao_desi_des5y_bbn_theta_star():
     g = golden("bao_desi_des5y_bbn_theta_star")
     lk = lk_bao_desi_des5y_bbn_theta_star(g, _chol_of(g))
