@@ -103,10 +103,12 @@ class DesiFsLyaCmb(_Base):
 
 class DesiCmbDes5y(_Base):
     """bao/desi_cmb_des5y.py: theta = (dM, H0, wb, wc, v); SN with velocity step at z = 0.10563 (:105), BAO with
-    PCHIP D_H and F_AP, Planck+ACT (R, l_A, wb); dark energy = Lambda as shipped (:46)."""
+    PCHIP D_H and F_AP, Planck+ACT (R, l_A, wb); dark energy = Lambda as shipped (:46).
+    bao/desi_cmb_pantheon.py is the same likelihood on Pantheon+ with the step at z = 0.15 (:102) and D_H = c / H
+    exactly (:62-63): ``DesiCmbDes5y(..., z_turn=0.15, dh_exact=True)`` (alias DesiCmbPantheon)."""
 
     def __init__(self, z_cmb, z_hel, mu_values, cov_sn, bao_z, bao_val, bao_qty, bao_inv_cov, *, chol=None, comp=None,
-                 device=0, solve="auto", latency_mode=None):
+                 device=0, solve="auto", latency_mode=None, z_turn=0.10563, dh_exact=False):
         comp = cmb_data.PLANCK_ACT if comp is None else comp
         if chol is None:
             chol = cho_factor(cov_sn, lower=True)[0]  # bao/desi_cmb_des5y.py:17
@@ -114,11 +116,20 @@ class DesiCmbDes5y(_Base):
         self.engine = LikelihoodEngine(
             ndim=5, z_max=self.z_max, n_grid=N_GRID, ez_model=L.CF_EZ_PHYSICAL, fde=L.CF_FDE_LCDM,
             params=dict(offset=Param(0), H0=Param(1), obh2=Param(2), och2=Param(3), v=Param(4)),
-            sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=mu_values, chol=chol, z_turn=0.10563),
-            bao=dict(z=bao_z, val=bao_val, qty=bao_qty, inv_cov=bao_inv_cov, rd_fit=comp["rd_fit"]),
+            sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=mu_values, chol=chol, z_turn=z_turn),
+            bao=dict(z=bao_z, val=bao_val, qty=bao_qty, inv_cov=bao_inv_cov, rd_fit=comp["rd_fit"], dh_exact=dh_exact),
             cmb=dict(mode=comp["cmb_mode"], prior=comp["cmb_prior"], inv_cov=comp["cmb_inv_cov"], zstar_fit=comp["zstar_fit"]),
             physical=_physical(comp), device=device,
             solve_mode=solve_mode_of(solve, latency_mode))
+
+
+class DesiCmbPantheon(DesiCmbDes5y):
+    """bao/desi_cmb_pantheon.py: theta = (M, H0, wb, wc, v)."""
+
+    def __init__(self, z_cmb, z_hel, mb_values, cov_sn, bao_z, bao_val, bao_qty, bao_inv_cov, **kw):
+        kw.setdefault("z_turn", 0.15)
+        kw.setdefault("dh_exact", True)
+        super().__init__(z_cmb, z_hel, mb_values, cov_sn, bao_z, bao_val, bao_qty, bao_inv_cov, **kw)
 
 
 class DesiCmbDes5yH0Trgb(_Base):

@@ -312,6 +312,26 @@ def case_bao_desi_cmb_des5y_h0trgb():
     print("bao_desi_cmb_des5y_H0trgb.npz chi2[:3] =", out["chi2"][:3])
 
 
+def case_bao_desi_cmb_pantheon():
+    """bao/desi_cmb_pantheon.py: Pantheon+ SNe (step at z = 0.15) + DESI DR2 BAO (exact D_H) + Planck+ACT CMB."""
+    _enter_reference()
+    z, zh, mb, sig = _inject_pantheon()
+    import bao.desi_cmb_pantheon as m
+
+    cmb = m.cmb
+    rng = np.random.default_rng(24)
+    box = [(-20.0, -19.0), (60.0, 75.0), (0.019, 0.025), (0.01, 0.25), (-3.0, 1.5)]  # nautilus prior of main() (:147-151)
+    thetas = np.vstack([_uniform(box, 12, rng), [[-19.4, 67.5, 0.0224, 0.119, 0.0], [-19.35, 68.0, 0.0225, 0.118, -1.2]]])
+    out = _bao_inputs(m.bao_data, m.bao_cov_matrix, m.quantities, m.inv_cov_bao)
+    out.update(_cmb_consts(cmb))
+    out.update(z_cmb=z, z_hel=zh, obs=mb, sigma=sig, thetas=thetas, z_max=np.float64(m.z_grid[-1]),
+               chi2=np.array([m.chi_squared(t) for t in thetas]), logl=np.array([m.log_likelihood(t) for t in thetas]),
+               theory=np.array([m.bao_theory(m.bao_data["z"], m.quantities, t) for t in thetas[:4]]),
+               cmb_dist=np.array([cmb.cmb_distances(t[2], t[3], t) for t in thetas[:4]]))
+    np.savez_compressed(os.path.join(HERE, "bao_desi_cmb_pantheon.npz"), **out)
+    print("bao_desi_cmb_pantheon.npz chi2[:3] =", out["chi2"][:3])
+
+
 def case_bao_desi_des5y_bbn_theta_star():
     """bao/desi_des5y_bbn_theta_star.py (BASELINE config 5 as shipped): SN (no velocity step) + BAO (exact D_H) +
     l_A only + BBN prior on wb, thawing w0; scipy's solve_triangular."""
@@ -485,6 +505,7 @@ CASES = {
     "bao_desi_fs_lya_cmb": case_bao_desi_fs_lya_cmb,
     "bao_desi_cmb_des5y": case_bao_desi_cmb_des5y,
     "bao_desi_cmb_des5y_H0trgb": case_bao_desi_cmb_des5y_h0trgb,
+    "bao_desi_cmb_pantheon": case_bao_desi_cmb_pantheon,
     "bao_desi_des5y_bbn_theta_star": case_bao_desi_des5y_bbn_theta_star,
     "sn_des5y": case_sn_des5y,
     "sn_des5y_cmb": case_sn_des5y_cmb,

@@ -142,6 +142,19 @@ def test_sn_des5y_and_the_two_sn_cmb_scripts_golden(gpu):
     lk.engine.close()
 
 
+def test_desi_cmb_pantheon_golden(gpu):
+    """bao/desi_cmb_pantheon.py: the config-3 likelihood on Pantheon+ (step at z = 0.15, exact D_H)."""
+    g = dict(golden("bao_desi_cmb_pantheon"))
+    lk = gpu.likelihoods.DesiCmbPantheon(g["z_cmb"], g["z_hel"], g["obs"], None, *_bao_args(g), chol=_chol_of(g))
+    assert lk.z_max == float(g["z_max"])
+    np.testing.assert_allclose(lk.chi_squared(g["thetas"]), g["chi2"], rtol=RTOL)
+    np.testing.assert_allclose(lk.log_likelihood(g["thetas"]), g["logl"], rtol=RTOL)
+    parts = lk.engine.parts(g["thetas"][:4])
+    np.testing.assert_allclose(parts["bao_theory"], g["theory"], rtol=1e-12)
+    np.testing.assert_allclose(parts["cmb_vector"], g["cmb_dist"], rtol=1e-12)
+    lk.engine.close()
+
+
 def test_config3_full_batch_vs_c_oracle(gpu, des5y):
     """BASELINE config 3 shape at full size: N = 1820 SNe + 14 BAO + CMB, 4096 walkers."""
     from oracle import oracle_c as oc

@@ -199,6 +199,15 @@ def lk_bao_desi_cmb_des5y_H0trgb(g, chol):
                           chi2_gauss=[(1, float(g["h0_prior"][0]), float(g["h0_prior"][1]))], **_phys(d))
 
 
+def lk_bao_desi_cmb_pantheon(g, chol):
+    d = _cmbdata("PLANCK_ACT")
+    return onp.Likelihood(ndim=5, z_max=float(g["z_max"]), ez_model=onp.EZ_PHYSICAL, fde=onp.FDE_LCDM, offset=onp.Slot(0),
+                          H0=onp.Slot(1), obh2=onp.Slot(2), och2=onp.Slot(3), v=onp.Slot(4), z_cmb=g["z_cmb"],
+                          z_hel=g["z_hel"], obs=g["obs"], z_turn=0.15, chol=chol, bao_z=g["bao_z"], bao_val=g["bao_val"],
+                          bao_qty=g["bao_qty"], bao_inv_cov=g["bao_inv_cov"], bao_dh_exact=True, rd_fit=d["rd_fit"], cmb_mode=1,
+                          cmb_prior=d["cmb_prior"], cmb_inv_cov=d["cmb_inv_cov"], zstar_fit=d["zstar_fit"], **_phys(d))
+
+
 def lk_bao_desi_des5y_bbn_theta_star(g, chol):
     d = _cmbdata("PLANCK_ACT")
     inv = np.zeros((3, 3))
@@ -356,7 +365,7 @@ def test_oracle_bao_desi_des5y_bbn_theta_star():
 
 # ---- the C restatement on the joint likelihoods -----------------------------------------------------------
 @pytest.mark.parametrize("name", ["bao_desi", "bao_desi_cmb", "bao_desi_fs_lya_cmb", "bao_desi_cmb_des5y",
-                                  "bao_desi_cmb_des5y_H0trgb", "bao_desi_des5y_bbn_theta_star"])
+                                  "bao_desi_cmb_des5y_H0trgb", "bao_desi_cmb_pantheon", "bao_desi_des5y_bbn_theta_star"])
 def test_c_oracle_joint_likelihoods(name):
     from oracle import oracle_c as oc
 
