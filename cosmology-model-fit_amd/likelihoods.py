@@ -215,6 +215,26 @@ class SnUnion3(_Base):
             sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=mu_vals, chol=np.linalg.cholesky(cov_matrix), z_turn=0.2), device=device)
 
 
+class CcSn(_Base):
+    """ohd/cc_des5y.py: theta = (f_cc, dM, H0, Om, w0); SN without a velocity step + cosmic chronometers with the
+    error-rescale parameter f_cc and the Gaussian normalisation in log L (:72-96), late-time flat wCDM (:24-35),
+    box prior (:59-68).  (ohd/cc_pantheon.py and ohd/cc_union3.py: the same blocks on the other SN sets.)"""
+    bounds = np.array([(0.2, 3.0), (-0.5, 0.5), (50.0, 85.0), (0.05, 0.6), (-1.0, -1.0 / 3)])
+
+    def __init__(self, z_cmb, z_hel, mu_values, cov_sn, z_cc, H_cc, cov_cc, *, chol=None, fde=L.CF_FDE_WCDM, bounds=None,
+                 device=0, solve="auto"):
+        if chol is None:
+            chol = cho_factor(cov_sn, lower=True)[0]
+        self.bounds = self.bounds if bounds is None else np.asarray(bounds, float)
+        self.z_max = float(np.max(z_cmb) + 0.1)  # :18
+        self.engine = LikelihoodEngine(
+            ndim=5, z_max=self.z_max, n_grid=N_GRID, ez_model=L.CF_EZ_LATE_FLAT, fde=fde,
+            params=dict(fcc=Param(0), offset=Param(1), H0=Param(2), Om=Param(3), w0=Param(4)),
+            sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=mu_values, chol=chol),
+            cc=dict(z=z_cc, h=H_cc, inv_cov=np.linalg.inv(cov_cc), logdet=np.linalg.slogdet(cov_cc)[1]),
+            bounds=self.bounds, device=device, solve_mode=solve_mode_of(solve))
+
+
 class DesiUnion3CcThetaStar(_Base):
     """bao/desi_union3_cc_theta_star.py: theta = (f_cc, dM, H0, wb, wc, v).  Union3.1 SN (explicit inverse in the
     reference), DESI BAO with exact D_H, l_A only, cosmic chronometers: chi2_cc * f_cc^2 and the Gaussian

@@ -477,6 +477,24 @@ def case_sn_pantheon_and_sh0es():
     print("sn_pantheon_and_sh0es.npz chi2[:3] =", out["chi2"][:3], "calibrators:", int(np.sum(ceph != -9)))
 
 
+def case_ohd_cc_des5y():
+    """ohd/cc_des5y.py: DES-Dovekie SNe (no velocity step) + cosmic chronometers with the error-rescale parameter f_cc
+    and the log-determinant term, late-time flat wCDM (Ode_z = (1+z)^(3(1+w0)), :24-28), box prior (:59-68)."""
+    _enter_reference()
+    z, zh, mu, sig = _inject_dovekie()
+    import ohd.cc_des5y as m
+
+    rng = np.random.default_rng(25)
+    thetas = theta_batch(m.bounds, 12, rng)
+    with np.errstate(all="ignore"):
+        out = dict(z_cmb=z, z_hel=zh, obs=mu, sigma=sig, cc_z=m.z_cc_vals, cc_h=m.H_cc_vals, cc_cov=m.cov_matrix_cc,
+                   cc_inv_cov=m.inv_cov_cc, cc_logdet=np.float64(m.logdet_cc), bounds=m.bounds, thetas=thetas,
+                   z_max=np.float64(m.grid[-1]), chi2=np.array([m.chi_squared(t) for t in thetas]),
+                   logl=np.array([m.log_likelihood(t) for t in thetas]), logp=np.array([m.log_probability(t) for t in thetas]))
+    np.savez_compressed(os.path.join(HERE, "ohd_cc_des5y.npz"), **out)
+    print("ohd_cc_des5y.npz chi2[:3] =", out["chi2"][:3], "logp[:3] =", out["logp"][:3])
+
+
 def case_bao_desi_union3_cc_theta_star():
     """bao/desi_union3_cc_theta_star.py: Union3.1 (explicit inverse) + DESI BAO (exact D_H) + l_A + cosmic
     chronometers with the error-rescale parameter f_cc and its log-determinant term (:129-139).  All data real."""
@@ -513,6 +531,7 @@ CASES = {
     "sn_union3_1": case_sn_union3_1,
     "sn_pantheon_dipole": case_sn_pantheon_dipole,
     "sn_pantheon_and_sh0es": case_sn_pantheon_and_sh0es,
+    "ohd_cc_des5y": case_ohd_cc_des5y,
     "bao_desi_union3_cc_theta_star": case_bao_desi_union3_cc_theta_star,
 }
 

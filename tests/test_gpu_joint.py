@@ -155,6 +155,21 @@ def test_desi_cmb_pantheon_golden(gpu):
     lk.engine.close()
 
 
+def test_ohd_cc_des5y_golden(gpu):
+    """ohd/cc_des5y.py: wCDM on the late-time flat family, SN without velocity step, chronometers with f_cc + log-det."""
+    g = golden("ohd_cc_des5y")
+    lk = gpu.likelihoods.CcSn(g["z_cmb"], g["z_hel"], g["obs"], None, g["cc_z"], g["cc_h"], g["cc_cov"], chol=_chol_of(g),
+                              bounds=g["bounds"])
+    assert lk.z_max == float(g["z_max"])
+    fin = np.isfinite(g["logp"])
+    got = lk.log_probs_vectorized(g["thetas"])
+    np.testing.assert_allclose(got[fin], g["logp"][fin], rtol=RTOL)
+    assert np.all(got[~fin] == -np.inf)
+    np.testing.assert_allclose(lk.chi_squared(g["thetas"])[fin], g["chi2"][fin], rtol=RTOL)
+    np.testing.assert_allclose(lk.log_likelihood(g["thetas"])[fin], g["logl"][fin], rtol=RTOL)
+    lk.engine.close()
+
+
 def test_config3_full_batch_vs_c_oracle(gpu, des5y):
     """BASELINE config 3 shape at full size: N = 1820 SNe + 14 BAO + CMB, 4096 walkers."""
     from oracle import oracle_c as oc

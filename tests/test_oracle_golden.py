@@ -347,6 +347,27 @@ def test_oracles_sn_des5y_and_the_two_sn_cmb_scripts():
     assert onp.log_probability(lk, g["thetas"][k]) == pytest.approx(g["logp"][k], rel=1e-11)
 
 
+def test_oracles_ohd_cc_des5y():
+    """ohd/cc_des5y.py: late-time flat wCDM, SN without velocity step, chronometers with f_cc and the log-det term."""
+    from oracle import oracle_c as oc
+
+    g = golden("ohd_cc_des5y")
+    lk = onp.Likelihood(ndim=5, z_max=float(g["z_max"]), ez_model=onp.EZ_LATE_FLAT, fde=onp.FDE_WCDM, fcc=onp.Slot(0),
+                        offset=onp.Slot(1), H0=onp.Slot(2), Om=onp.Slot(3), w0=onp.Slot(4), z_cmb=g["z_cmb"], z_hel=g["z_hel"],
+                        obs=g["obs"], has_vstep=False, chol=_chol_of(g), cc_z=g["cc_z"], cc_h=g["cc_h"],
+                        cc_inv_cov=g["cc_inv_cov"], cc_logdet=float(g["cc_logdet"]), bounds=g["bounds"])
+    fin = np.isfinite(g["logp"])
+    for k in np.flatnonzero(fin)[:4]:
+        assert onp.chi_squared(lk, g["thetas"][k]) == pytest.approx(g["chi2"][k], rel=1e-11)
+        assert onp.log_likelihood(lk, g["thetas"][k]) == pytest.approx(g["logl"][k], rel=1e-11)
+        assert onp.log_probability(lk, g["thetas"][k]) == pytest.approx(g["logp"][k], rel=1e-11)
+    co = oc.COracle(lk)
+    got = co.logp(g["thetas"])
+    np.testing.assert_allclose(got[fin], g["logp"][fin], rtol=1e-10)
+    assert np.all(got[~fin] == -np.inf) and (~fin).sum() >= 10
+    np.testing.assert_allclose(co.chi2(g["thetas"][fin]), g["chi2"][fin], rtol=1e-10)
+
+
 def test_oracle_bao_desi_des5y_bbn_theta_star():
     g = golden("bao_desi_des5y_bbn_theta_star")
     lk = lk_bao_desi_des5y_bbn_theta_star(g, _chol_of(g))
