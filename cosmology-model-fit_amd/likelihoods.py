@@ -207,12 +207,16 @@ class SnUnion3(_Base):
     """sn/union3_1.py: theta = (dM, Om, v); H0 fixed to 70 (:11), velocity step at z = 0.2 (:40).  The reference
     multiplies by the explicit inverse covariance (:57); the engine solves with its Cholesky factor (same chi^2)."""
 
-    def __init__(self, z_cmb, z_hel, mu_vals, cov_matrix, *, H0=70.0, device=0):
+    PRIOR_BOX = np.array([(-1.0, 1.0), (0.1, 0.7), (-9.0, 9.0)])  # the nautilus prior of main() (:77-79)
+
+    def __init__(self, z_cmb, z_hel, mu_vals, cov_matrix, *, H0=70.0, bounds=None, device=0):
         self.z_max = float(np.max(z_cmb) + 0.1)
+        self.bounds = None if bounds is None else np.asarray(bounds, float)
         self.engine = LikelihoodEngine(
             ndim=3, z_max=self.z_max, n_grid=N_GRID, fde=L.CF_FDE_LCDM,
             params=dict(offset=Param(0), H0=Param(fixed=H0), Om=Param(1), v=Param(2)),
-            sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=mu_vals, chol=np.linalg.cholesky(cov_matrix), z_turn=0.2), device=device)
+            sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=mu_vals, chol=np.linalg.cholesky(cov_matrix), z_turn=0.2),
+            bounds=self.bounds, device=device)
 
 
 class CcSn(_Base):
