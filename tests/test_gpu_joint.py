@@ -311,3 +311,19 @@ def test_union3_posterior_reproduces_the_reference_published_results(gpu):
     assert chi2_map == pytest.approx(22.15, abs=0.03)
     assert 0.15 < ens.acceptance_fraction() < 0.9
     lk.engine.close()
+
+
+def test_union3_laplace_evidence_matches_the_published_value(gpu):
+    """laplace.log_evidence (batched finite-difference stencils on the GPU likelihood) on the real Union3.1 data against
+    the log-evidence the reference publishes for this script with the velocity step (sn/union3_1.py:166: -20.5)."""
+    torch = pytest.importorskip("torch")
+    g = golden("sn_union3_1")
+    box = gpu.likelihoods.SnUnion3.PRIOR_BOX
+    lk = gpu.likelihoods.SnUnion3(g["z_cmb"], g["z_hel"], g["obs"], g["cov"], H0=float(g["H0"]), bounds=box)
+    start = np.array([0.0, 0.3, -3.0]) + np.array([0.02, 0.02, 1.0]) * np.random.default_rng(3).standard_normal((1024, 3))
+    ens = gpu.ensemble.ShardedEnsemble(lk.engine.torch_log_prob(), torch.from_numpy(start).to("cuda:0"), seed=9,
+                                       moves=gpu.ensemble.REFERENCE_MOVES)
+    ens.run(300)
+    ln_z = gpu.laplace.log_evidence(ens.x.cpu().numpy(), ens.logp.cpu().numpy(), lk.log_probs_vectorized, box)
+    assert ln_z == pytest.approx(-20.5, abs=0.06)
+    lk.engine.close()
