@@ -327,3 +327,30 @@ def test_union3_laplace_evidence_matches_the_published_value(gpu):
     ln_z = gpu.laplace.log_evidence(ens.x.cpu().numpy(), ens.logp.cpu().numpy(), lk.log_probs_vectorized, box)
     assert ln_z == pytest.approx(-20.5, abs=0.06)
     lk.engine.close()
+
+
+def test_bao_desi_posterior_reproduces_the_reference_published_results(gpu):
+    """bao/desi.py as shipped (thawing w(z), real DESI DR2 + DES BAO data and covariance): the device-resident sampler
+    against the posterior the reference publishes (bao/desi.py:220-231): h = 0.666 +0.014 -0.015, Om = 0.312 +- 0.012,
+    w0 = -0.768 +0.133 -0.130 (truncated at -1 by the prior), 16 / 50 / 84 percentiles."""
+    torch = pytest.importorskip("torch")
+    g = golden("bao_desi")
+    lk = gpu.likelihoods.DesiBao(*_bao_args(g), rd=float(g["rd"]), bounds=g["bounds"])
+    rng = np.random.default_rng(5)
+    start = np.array([0.67, 0.31, -0.75]) + np.array([0.01, 0.01, 0.08]) * rng.standard_normal((2048, 3))
+    start[:, 2] = np.clip(start[:, 2], -0.99, -0.01)
+    ens = gpu.ensemble.ShardedEnsemble(lk.engine.torch_log_prob(), torch.from_numpy(start).to("cuda:0"), seed=2,
+                                       moves=gpu.ensemble.REFERENCE_MOVES)
+    ens.run(400)
+    chain = []
+    for step in range(300):
+        ens.step()
+        if step % 10 == 0:
+            chain.append(ens.x.cpu().numpy().copy())
+    lo, med, hi = np.percentile(np.concatenate(chain), [15.87, 50.0, 84.13], axis=0)
+    ref_med = np.array([0.666, 0.312, -0.768])
+    ref_lo, ref_hi = ref_med - np.array([0.015, 0.012, 0.130]), ref_med + np.array([0.014, 0.012, 0.133])
+    sig = 0.5 * (ref_hi - ref_lo)
+    assert np.all(np.abs(med - ref_med) < 0.2 * sig), (lo, med, hi)
+    assert np.all(np.abs(lo - ref_lo) < 0.25 * sig) and np.all(np.abs(hi - ref_hi) < 0.25 * sig), (lo, med, hi)
+    lk.engine.close()
