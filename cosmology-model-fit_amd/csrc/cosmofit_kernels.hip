@@ -348,7 +348,7 @@ __device__ __forceinline__ double wave_inclusive_scan(double v) {
 // wave-boundary intervals with the carries.
 template <int MODEL, int FDE, int CH, bool INTERIOR>
 __device__ __forceinline__ double chunk_eval(const cf_dev_desc& d, const WalkerCosmo& wc, double c_over_H0, int g0, int lane,
-                                             double (&dh)[CH], double (&loc)[CH]) {
+                                             const double (&nu_pre)[CH], double (&dh)[CH], double (&loc)[CH]) {
   const int G = d.n_grid;
   double z[CH];
 #pragma unroll
@@ -356,13 +356,11 @@ __device__ __forceinline__ double chunk_eval(const cf_dev_desc& d, const WalkerC
     const int g = g0 + k;
     if (INTERIOR) {
       z[k] = (double)g * d.step;
-      const double nu = (MODEL == CF_EZ_PHYSICAL_D && d.nu_grid) ? d.nu_grid[g] : -1.0;
-      dh[k] = c_over_H0 * rsqrt_pos(e2_of_z<MODEL, FDE>(d, wc, z[k], nu));
+      dh[k] = c_over_H0 * rsqrt_pos(e2_of_z<MODEL, FDE>(d, wc, z[k], nu_pre[k]));
     } else {
       const int gc = g < G ? g : G - 1;  // evaluations past the grid repeat the last node and are discarded
       z[k] = gc == G - 1 ? d.z_max : (double)gc * d.step;
-      const double nu = (MODEL == CF_EZ_PHYSICAL_D && d.nu_grid) ? d.nu_grid[gc] : -1.0;
-      const double v = c_over_H0 * rsqrt_pos(e2_of_z<MODEL, FDE>(d, wc, z[k], nu));
+      const double v = c_over_H0 * rsqrt_pos(e2_of_z<MODEL, FDE>(d, wc, z[k], nu_pre[k]));
       dh[k] = g < G ? v : 0.0;
     }
   }
@@ -394,7 +392,7 @@ __device__ __forceinline__ double chunk_eval(const cf_dev_desc& d, const WalkerC
 
 template <int MODEL, int FDE, int CH>
 __device__ __forceinline__ void build_distance_table_regs(const cf_dev_desc& d, const WalkerCosmo& wc, d2* tab,
-                                                          d4* wave_pub) {
+                                                          d4* wave_pub, const double (&nu_pre)[CH]) {
   const int G = d.n_grid;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g0 = tid * CH;
@@ -403,8 +401,8 @@ __device__ __forceinline__ void build_distance_table_regs(const cf_dev_desc& d, 
   double dh[CH], loc[CH];
   const int wave_first = (tid - lane) * CH, wave_last = wave_first + 64 * CH - 1;
   const double run = (wave_first > 0 && wave_last < G - 1)
-                         ? chunk_eval<MODEL, FDE, CH, true>(d, wc, c_over_H0, g0, lane, dh, loc)
-                         : chunk_eval<MODEL, FDE, CH, false>(d, wc, c_over_H0, g0, lane, dh, loc);
+                         ? chunk_eval<MODEL, FDE, CH, true>(d, wc, c_over_H0, g0, lane, nu_pre, dh, loc)
+                         : chunk_eval<MODEL, FDE, CH, false>(d, wc, c_over_H0, g0, lane, nu_pre, dh, loc);
   CF_WSTAMP(2);
   const double incl = wave_inclusive_scan(run);
   // per wave: {sum of its intervals, dh of its first node, dh of its last node}
@@ -474,9 +472,9 @@ __device__ __forceinline__ void build_distance_table_lds(const cf_dev_desc& d, c
 
 template <int MODEL, int FDE>
 __device__ __forceinline__ void build_distance_table(const cf_dev_desc& d, const WalkerCosmo& wc, d2* tab,
-                                                     d4* wave_pub) {
+                                                     d4* wave_pub, const double (&nu_pre)[8]) {
   // grids up to 4096 nodes (the reference uses 4000) take the register path, 8 nodes per thread
-  if (d.chunk_shift == 3) build_distance_table_regs<MODEL, FDE, 8>(d, wc, tab, wave_pub);
+  if (d.chunk_shift == 3) build_distance_table_regs<MODEL, FDE, 8>(d, wc, tab, wave_pub, nu_pre);
   else build_distance_table_lds<MODEL, FDE>(d, wc, tab, wave_pub);
 }
 
@@ -622,6 +620,14 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
 
   CF_WSTAMP(0);
   if (tid < 64 && d.n_sn > 0) log_tab[tid] = reinterpret_cast<const d2*>(d.log10_tab)[tid];
+  // tabulated massive-neutrino density of this thread's 8 grid nodes (register path of the table build): fetched
+  // before anything else so that the loads fly while theta is read and the cosmology scalars are formed
+  double nu_pre[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int gc = min(tid * 8 + k, d.n_grid - 1);
+    nu_pre[k] = (MODEL == CF_EZ_PHYSICAL_D && d.nu_grid && d.chunk_shift == 3) ? d.nu_grid[gc] : -1.0;
+  }
   const WalkerCosmo wc = make_cosmo(d, th);
   DistTable T;
   T.tab = lds_tab;
@@ -633,7 +639,7 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
   T.z_max = d.z_max;
 
   CF_WSTAMP(1);
-  if (d.n_sn > 0 || d.n_bao > 0) build_distance_table<MODEL, FDE>(d, wc, lds_tab, wave_pub);
+  if (d.n_sn > 0 || d.n_bao > 0) build_distance_table<MODEL, FDE>(d, wc, lds_tab, wave_pub, nu_pre);
   CF_WSTAMP(4);
   // the table nodes around each BAO redshift go to small_blocks_kernel (the BAO block is evaluated there, one wave
   // per walker); copied by the last threads of the workgroup, whose waves have the lightest share of the SN loop
