@@ -28,7 +28,7 @@ tests and the statement of what those kernels compute.
 from __future__ import annotations
 
 import math
-from typing import Callable, Optional, Tuple
+from typing import Callable, Tuple
 
 import torch
 

@@ -6,8 +6,7 @@ import numpy as np
 import pytest
 
 from conftest import golden
-from test_oracle_golden import (_chol_of, lk_bao_desi, lk_bao_desi_cmb, lk_bao_desi_cmb_des5y,
-                                lk_bao_desi_des5y_bbn_theta_star, lk_bao_desi_fs_lya_cmb)
+from test_oracle_golden import _chol_of, lk_bao_desi_cmb_des5y, lk_bao_desi_des5y_bbn_theta_star
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-10

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Wall-clock latency of the ctypes boundary (host numpy in / out) vs batch size, both solve modes."""
 import importlib, sys, time, os
-import numpy as np
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("cosmology-model-fit_amd")
 syn = pkg.synthetic.pantheon_like(n_sn=1701, seed=0)
