@@ -272,10 +272,12 @@ static int ensure_workspace(cf_handle* h, int64_t W) {
   }
   if (h->d.n_sn > 0) {
     if (h->delta.ensure((size_t)w_pad * n_ld * 8 + CF_DELTA_SLACK)) return CF_ERR_HIP;
-    if (h->ypk.ensure((size_t)w_pad * n_pad * 8 + CF_YPK_SLACK)) return CF_ERR_HIP;
     // columns of a partly filled last panel must hold finite numbers
     HIP_TRY(hipMemsetAsync(h->delta.p, 0, (size_t)w_pad * n_ld * 8 + CF_DELTA_SLACK, h->stream));
-    HIP_TRY(hipMemsetAsync(h->ypk.p, 0, (size_t)w_pad * n_pad * 8 + CF_YPK_SLACK, h->stream));
+    if (h->solve_mode == CF_SOLVE_BLOCKED_TRSM) {  // solved panels Y, only the blocked solve stores them
+      if (h->ypk.ensure((size_t)w_pad * n_pad * 8 + CF_YPK_SLACK)) return CF_ERR_HIP;
+      HIP_TRY(hipMemsetAsync(h->ypk.p, 0, (size_t)w_pad * n_pad * 8 + CF_YPK_SLACK, h->stream));
+    }
     // the evaluation may be launched on a caller's stream: the fills must have landed before it starts
     HIP_TRY(hipStreamSynchronize(h->stream));
   }
@@ -587,7 +589,8 @@ extern "C" int cf_get_info(cf_handle* h, cf_info* info) {
   info->n_sn_pad = h->d.n_pad;
   info->packed_chol_bytes = h->pack.bytes + h->ipack.bytes;
   info->solve_mode = h->solve_mode;
-  info->workspace_bytes = (int64_t)(h->theta.bytes + h->out.bytes + h->delta.bytes + h->ypk.bytes);
+  info->workspace_bytes = (int64_t)(h->theta.bytes + h->out.bytes + h->delta.bytes + h->ypk.bytes + h->partial.bytes +
+                                    h->arrivals.bytes + h->bao_nodes.bytes + h->chi2_extra.bytes);
   info->max_walkers = h->max_walkers;
   info->device = h->device;
   info->cu_count = h->cu_count;
