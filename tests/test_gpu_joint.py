@@ -353,3 +353,31 @@ def test_bao_desi_posterior_reproduces_the_reference_published_results(gpu):
     assert np.all(np.abs(med - ref_med) < 0.2 * sig), (lo, med, hi)
     assert np.all(np.abs(lo - ref_lo) < 0.25 * sig) and np.all(np.abs(hi - ref_hi) < 0.25 * sig), (lo, med, hi)
     lk.engine.close()
+
+
+def test_bao_desi_cmb_posterior_reproduces_the_reference_published_results(gpu):
+    """bao/desi_cmb.py as shipped (DESI DR2 BAO + early-LCDM compressed CMB, thawing w(z), all data real): posterior
+    percentiles against bao/desi_cmb.py:272-285: H0 = 67.26 +0.81 -1.12, wb = 0.02241 +- 0.00012, wc = 0.1168 +- 0.0007,
+    w0 = -0.912 +0.087 -0.061 (truncated at -1 by the prior)."""
+    torch = pytest.importorskip("torch")
+    g = golden("bao_desi_cmb")
+    lk = gpu.likelihoods.DesiCmb(*_bao_args(g), bounds=g["bounds"])
+    rng = np.random.default_rng(6)
+    start = np.array([67.3, 0.0224, 0.1168, -0.9]) + np.array([0.5, 1e-4, 5e-4, 0.05]) * rng.standard_normal((2048, 4))
+    start[:, 3] = np.clip(start[:, 3], -0.995, -0.01)
+    ens = gpu.ensemble.ShardedEnsemble(lk.engine.torch_log_prob(), torch.from_numpy(start).to("cuda:0"), seed=4,
+                                       moves=gpu.ensemble.REFERENCE_MOVES)
+    ens.run(500)
+    chain = []
+    for step in range(300):
+        ens.step()
+        if step % 10 == 0:
+            chain.append(ens.x.cpu().numpy().copy())
+    lo, med, hi = np.percentile(np.concatenate(chain), [15.87, 50.0, 84.13], axis=0)
+    ref_med = np.array([67.26, 0.02241, 0.1168, -0.912])
+    ref_lo = ref_med - np.array([1.12, 0.00012, 0.0007, 0.061])
+    ref_hi = ref_med + np.array([0.81, 0.00012, 0.0007, 0.087])
+    sig = 0.5 * (ref_hi - ref_lo)
+    assert np.all(np.abs(med - ref_med) < 0.25 * sig), (lo, med, hi)
+    assert np.all(np.abs(lo - ref_lo) < 0.3 * sig) and np.all(np.abs(hi - ref_hi) < 0.3 * sig), (lo, med, hi)
+    lk.engine.close()
