@@ -214,6 +214,7 @@ def main():
                 "frac_of_measured_ceiling": achieved / FP64_MFMA_MEASURED_TFLOPS,
             },
             "kernels_ms": {"walker_kernel": resid_ms, solve_kernel: solve_ms},
+            "device": {k: eng.info()[k] for k in ("gcn_arch", "cu_count")},
         }
         # the HBM view next to the matrix-core view.  `hbm_gbps_measured` = PMC bytes of the solve
         # kernel / its duration (small by design: the factor is reused by every walker from L2 / Infinity Cache);
@@ -258,6 +259,19 @@ def stream_triad_gbps(torch, dev, n=1 << 27, reps=10):
     e1.record()
     torch.cuda.synchronize()
     return 3 * 8 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def host_cpu():
+    """CPU model and logical CPU count of the box the baseline ran on."""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"model": model, "logical_cpus": os.cpu_count(), "usable": len(os.sched_getaffinity(0))}
 
 
 def pmc_traffic(n_sn, walkers, kernel):
@@ -309,6 +323,7 @@ def cpu_baseline(pkg, syn, lk, theta, gpu_logp, budget_s):
                   f"single-thread: {n1 / dt1:.1f} evals/s on {n1} walkers",
         "single_thread_value": n1 / dt1,
         "parity_max_rel_logp": rel,
+        "host": host_cpu(),
     }
 
 
