@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <thread>
 #include <vector>
 
 #include "cosmofit_device.h"
@@ -183,22 +184,30 @@ static double cf_pack_replay_host(const cf_host_pack& pk, const double* b_in) {
   return chi;
 }
 
-// Accuracy probe of a packed factor: || L^-1 b ||^2 for a fixed pseudo-random b through the fragment
-// streams (blocked, diagonal blocks through their inverses) against plain row-by-row forward
-// substitution (solve_triangular.py:12-14).  Returns the relative difference; an ill-conditioned
-// diagonal block shows up here (cond(L_bb) * eps) before any walker is evaluated.
-static double cf_pack_probe(const cf_host_pack& pk, const double* L, int64_t ld) {
-  const int64_t n = pk.n;
-  std::vector<double> b((size_t)n), y((size_t)n);
-  uint64_t s = 0x9E3779B97F4A7C15ull;
-  for (int64_t i = 0; i < n; ++i) {  // splitmix64 -> uniform in [-1, 1)
+// Probe right-hand sides shared by both packings.  mode 0: pseudo-random in [-1, 1) (splitmix64); 1: all ones (an
+// offset-like residual); 2: residual-shaped -- what Delta = m - M - mu(z; theta) looks like for a theta away from
+// the truth on z-sorted supernovae: a smooth trend of a few tenths of a magnitude across the sample plus 0.15 mag of
+// scatter.  A smooth right-hand side is the hard case for an explicit inverse: neighbouring (strongly correlated)
+// supernovae make rows of L^-1 large and alternating, and the products cancel.
+#define CF_PROBE_MODES 3
+static void cf_probe_rhs(int mode, int64_t n, std::vector<double>& b) {
+  b.resize((size_t)n);
+  uint64_t s = 0x1234567ull;
+  for (int64_t i = 0; i < n; ++i) {
     s += 0x9E3779B97F4A7C15ull;
     uint64_t z = s;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     z ^= z >> 31;
-    b[i] = (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+    const double u = (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+    const double x = n > 1 ? (double)i / (double)(n - 1) : 0.0;
+    b[i] = mode == 0 ? u : mode == 1 ? 1.0 : 0.08 + 0.25 * x - 0.4 * x * x + 0.15 * u;
   }
+}
+
+// || L^-1 b ||^2 by plain row-by-row forward substitution (solve_triangular.py:12-14): what a probe compares with.
+static double cf_probe_reference(const double* L, int64_t n, int64_t ld, const std::vector<double>& b) {
+  std::vector<double> y((size_t)n);
   double ref = 0.0;
   for (int64_t i = 0; i < n; ++i) {
     const double* row = L + i * ld;
@@ -207,8 +216,23 @@ static double cf_pack_probe(const cf_host_pack& pk, const double* L, int64_t ld)
     y[i] = (b[i] - acc) / row[i];
     ref += y[i] * y[i];
   }
-  const double got = cf_pack_replay_host(pk, b.data());
-  return std::fabs(got - ref) / (std::fabs(ref) > 0 ? std::fabs(ref) : 1.0);
+  return ref;
+}
+
+// Accuracy probe of a packed factor: || L^-1 b ||^2 through the fragment streams (blocked, diagonal blocks through
+// their inverses) against row-by-row forward substitution, worst of the CF_PROBE_MODES right-hand sides.  An
+// ill-conditioned diagonal block shows up here (cond(L_bb) * eps) before any walker is evaluated.
+static double cf_pack_probe(const cf_host_pack& pk, const double* L, int64_t ld) {
+  double worst = 0.0;
+  std::vector<double> b;
+  for (int mode = 0; mode < CF_PROBE_MODES; ++mode) {
+    cf_probe_rhs(mode, pk.n, b);
+    const double ref = cf_probe_reference(L, pk.n, ld, b);
+    const double got = cf_pack_replay_host(pk, b.data());
+    const double rel = std::fabs(got - ref) / (std::fabs(ref) > 0 ? std::fabs(ref) : 1.0);
+    if (!(rel <= worst)) worst = rel;
+  }
+  return worst;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -226,20 +250,44 @@ struct cf_host_invpack {
   std::vector<int64_t> off;  // [n_rowblocks*4] in fragments
 };
 
-// X = L^-1 (lower triangular, row-major n_pad x n_pad, identity on the padding), column by column.
+// X = L^-1 (lower triangular, row-major n_pad x n_pad, identity on the padding), column by column: column j solves
+// L x = e_j by forward substitution with every product and sum in `long double` (x87 extended: 64-bit significand),
+// four accumulation chains per dot product, and the stored double is the rounding of that extended result -- so an
+// entry of X carries one rounding, not the ~sqrt(n) eps of a double recurrence.  Columns are independent: a few host
+// threads share them (n^3 / 6 = 0.8 G multiply-adds at n = 1701).
 static void cf_invert_lower(const double* L, int64_t n, int64_t ld, int64_t n_pad, std::vector<double>& X) {
   X.assign((size_t)n_pad * n_pad, 0.0);
-  std::vector<double> col((size_t)n_pad);
-  for (int64_t j = 0; j < n_pad; ++j) {
-    if (j >= n) { X[(size_t)j * n_pad + j] = 1.0; continue; }
-    col[j] = 1.0 / L[j * ld + j];
-    for (int64_t i = j + 1; i < n; ++i) {
-      const double* row = L + i * ld;
-      double acc = 0.0;
-      for (int64_t k = j; k < i; ++k) acc += row[k] * col[k];
-      col[i] = -acc / row[i];
+  for (int64_t j = n; j < n_pad; ++j) X[(size_t)j * n_pad + j] = 1.0;
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = nt == 0 ? 1 : (nt > 16 ? 16 : nt);
+  if (n < 256) nt = 1;
+  auto work = [&](unsigned t) {
+    std::vector<long double> col((size_t)n);
+    // interleaved columns: column j costs (n - j)^2 / 2, so neighbours cost the same
+    for (int64_t j = t; j < n; j += nt) {
+      col[j] = 1.0L / (long double)L[j * ld + j];
+      for (int64_t i = j + 1; i < n; ++i) {
+        const double* row = L + i * ld;
+        long double a0 = 0.0L, a1 = 0.0L, a2 = 0.0L, a3 = 0.0L;
+        int64_t k = j;
+        for (; k + 3 < i; k += 4) {
+          a0 += (long double)row[k] * col[k];
+          a1 += (long double)row[k + 1] * col[k + 1];
+          a2 += (long double)row[k + 2] * col[k + 2];
+          a3 += (long double)row[k + 3] * col[k + 3];
+        }
+        for (; k < i; ++k) a0 += (long double)row[k] * col[k];
+        col[i] = -((a0 + a1) + (a2 + a3)) / (long double)row[i];
+      }
+      for (int64_t i = j; i < n; ++i) X[(size_t)i * n_pad + j] = (double)col[i];
     }
-    for (int64_t i = j; i < n; ++i) X[(size_t)i * n_pad + j] = col[i];
+  };
+  if (nt == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, t);
+    for (auto& x : th) x.join();
   }
 }
 
@@ -304,30 +352,14 @@ static double cf_invpack_replay_host(const cf_host_invpack& pk, const double* b_
   return chi;
 }
 
-// Probe of the inverse pack: worst relative chi^2 discrepancy against row-by-row substitution over
-// a pseudo-random vector and the all-ones vector (an offset-like residual).
+// Probe of the inverse pack: worst relative chi^2 discrepancy against row-by-row substitution over the
+// CF_PROBE_MODES right-hand sides (cf_probe_rhs).
 static double cf_invpack_probe(const cf_host_invpack& pk, const double* L, int64_t ld) {
-  const int64_t n = pk.n;
   double worst = 0.0;
-  for (int mode = 0; mode < 2; ++mode) {
-    std::vector<double> b((size_t)n), y((size_t)n);
-    uint64_t s = 0x1234567ull;
-    for (int64_t i = 0; i < n; ++i) {
-      s += 0x9E3779B97F4A7C15ull;
-      uint64_t z = s;
-      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-      z ^= z >> 31;
-      b[i] = mode == 0 ? (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0 : 1.0;
-    }
-    double ref = 0.0;
-    for (int64_t i = 0; i < n; ++i) {
-      const double* row = L + i * ld;
-      double acc = 0.0;
-      for (int64_t j = 0; j < i; ++j) acc += row[j] * y[j];
-      y[i] = (b[i] - acc) / row[i];
-      ref += y[i] * y[i];
-    }
+  std::vector<double> b;
+  for (int mode = 0; mode < CF_PROBE_MODES; ++mode) {
+    cf_probe_rhs(mode, pk.n, b);
+    const double ref = cf_probe_reference(L, pk.n, ld, b);
     const double got = cf_invpack_replay_host(pk, b.data());
     const double rel = std::fabs(got - ref) / (std::fabs(ref) > 0 ? std::fabs(ref) : 1.0);
     if (!(rel <= worst)) worst = rel;

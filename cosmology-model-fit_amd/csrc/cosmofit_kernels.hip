@@ -1268,22 +1268,25 @@ tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict_
     if (lane < 16) chi_tile[g][c * 16 + lane] = v;
   }
   lds_barrier();
-  // Hand-off between workgroups on different XCDs (their L2s are not coherent): the partial sums travel as
-  // agent-scope (L2-bypassing) stores, drained before the arrival counter is bumped, and are read back with
-  // agent-scope loads by the workgroup that arrives last for this panel.  That one adds the row blocks in a
-  // fixed order -- the result does not depend on which workgroup it was -- and re-arms the counter.
+  // Hand-off between workgroups on different XCDs (their L2s are not coherent).  Producer: wave 0 stores the
+  // workgroup's shares with agent-scope (write-through, sc1) stores, drains them (inline asm: also a compiler
+  // barrier), and lane 0 bumps the panel's arrival counter with an agent-scope RELEASE add.  Consumer: the workgroup
+  // whose add returned n_rowblocks - 1 came last; behind the workgroup barrier and an agent-scope ACQUIRE fence it
+  // reads every share back with agent-scope loads and adds the row blocks in a fixed order -- the result does not
+  // depend on which workgroup it was -- and re-arms the counter for the next launch.
   if (g == 0) {
     if (lane < 16 * NP)
       __hip_atomic_store(&partial[(int64_t)rb * w_pad + w0 + lane],
                          ((chi_tile[0][lane] + chi_tile[1][lane]) + chi_tile[2][lane]) + chi_tile[3][lane], __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): the stores have left this CU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of every lane of this wave have left the CU
     if (lane == 0)
-      arrived_before = __hip_atomic_fetch_add(&arrivals[px], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      arrived_before = __hip_atomic_fetch_add(&arrivals[px], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
   CF_GSTAMP(3);
   lds_barrier();
   if (arrived_before != (unsigned)pk.n_rowblocks - 1u) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   if (tid == 0) __hip_atomic_store(&arrivals[px], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (tid < 16 * NP && w0 + tid < W) {
     const int64_t w = w0 + tid;

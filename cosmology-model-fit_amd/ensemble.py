@@ -62,9 +62,29 @@ def _mix(x: torch.Tensor) -> torch.Tensor:
     return x ^ _lsr(x, 31)
 
 
+_U64 = 0xFFFFFFFFFFFFFFFF
+MAX_STREAMS = 256  # random streams per (seed, step, half): the KDE move uses 4 + 2 ndim + 1 <= 37
+
+
+def _mix_int(x: int) -> int:
+    """splitmix64 finaliser on a Python int (the same bijection of 64-bit words as `_mix`)."""
+    x &= _U64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _U64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _U64
+    return x ^ (x >> 31)
+
+
 def stream_key(seed: int, step: int, half: int, stream: int = 0) -> int:
-    """Unsigned 64-bit key of random stream `stream` for (seed, step, half); stream s has key(stream 0) + s."""
-    return ((seed * 1000003 + step) * 8 + half * 4 + stream + 0x5851F42D4C957F2D) & 0xFFFFFFFFFFFFFFFF
+    """Unsigned 64-bit key of random stream `stream` for (seed, step, half); stream s has key(stream 0) + s.
+
+    seed and step each pass through their own hash round, so the 512 consecutive keys of one (seed, step) -- 256
+    streams for each half -- sit at a pseudo-random 64-bit offset: the streams of different steps, halves or seeds
+    never share a key (an arithmetic key such as (seed * K + step) * 8 + half * 4 + stream makes the KDE move's noise
+    streams of step t coincide with the partner / accept streams of step t + 1)."""
+    if not (0 <= stream < MAX_STREAMS) or half not in (0, 1):
+        raise ValueError(f"stream must be in 0..{MAX_STREAMS - 1} and half in (0, 1)")
+    base = _mix_int(_mix_int(seed * 0x9E3779B97F4A7C15 + 0x5851F42D4C957F2D) ^ (step & _U64))
+    return (base + (half << 8) + stream) & _U64
 
 
 def uniform01(seed: int, step: int, half: int, walker_ids: torch.Tensor, stream: int) -> torch.Tensor:
@@ -196,7 +216,7 @@ class ShardedEnsemble:
         return q, self._kde_logpdf(xa, comp, chol_inv_t, log_norm) - self._kde_logpdf(q, comp, chol_inv_t, log_norm)
 
     def _pick_move(self) -> str:
-        u = float(uniform01(self.seed, self.step_count, 0, torch.tensor([-1], dtype=torch.int64), 7)[0])
+        u = float(uniform01(self.seed, self.step_count, 0, torch.tensor([-1], dtype=torch.int64), MAX_STREAMS - 1)[0])
         acc = 0.0
         for name, w in self.moves:
             acc += w

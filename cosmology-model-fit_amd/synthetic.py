@@ -40,3 +40,49 @@ def walkers(bounds, W, seed=0):
     lo, hi = b[:, 0], b[:, 1]
     eps = 1e-9 * (hi - lo)
     return rng.uniform(lo + eps, hi - eps, size=(W, len(lo)))
+
+
+def hard_cov(z, sigma, seed=0):
+    """A seeded covariance with the structure of the Pantheon+ STAT+SYS matrix that the reference snapshot lacks
+    (.MISSING_LARGE_BLOBS), for a z-sorted sample with statistical errors `sigma`:
+
+      * duplicated supernovae: ~18 % of the entries are 2-4 observations of one SN by different surveys, adjacent in
+        z, correlated with rho in [0.99, 0.99995];
+      * one fully coherent 0.05 mag systematic (a calibration offset shared by every SN);
+      * seven survey blocks (contiguous in z with ragged edges) with their own 0.015-0.04 mag zero-point offsets;
+      * four smooth-in-z systematics (0.01-0.03 mag, polynomial in log z);
+      * 0.004 mag of low-rank noise so that no two rows are proportional.
+
+    cond(C) is ~1e7 (tests/test_hard_cov.py prints it): the conditioning-sensitive case for chi^2 = ||L^-1 Delta||^2."""
+    rng = np.random.default_rng(1000 + seed)
+    z = np.asarray(z, dtype=np.float64)
+    sigma = np.asarray(sigma, dtype=np.float64)
+    n = z.size
+    C = np.diag(sigma**2)
+    # duplicated SNe: groups of adjacent entries sharing the intrinsic scatter
+    i = 0
+    while i < n - 4:
+        if rng.uniform() < 0.07:
+            k = int(rng.integers(2, 5))
+            rho = 1.0 - 10 ** rng.uniform(-4.3, -2.0)
+            for a in range(i, i + k):
+                for b in range(i, i + k):
+                    if a != b:
+                        C[a, b] = rho * sigma[a] * sigma[b]
+            i += k
+        else:
+            i += 1
+    C += 0.05**2  # coherent systematic
+    edges = np.sort(rng.choice(np.arange(50, n - 50), size=6, replace=False))
+    survey = np.searchsorted(edges, np.arange(n) + rng.integers(-20, 21, n))  # ragged survey boundaries
+    for s in range(7):
+        m = (survey == s).astype(np.float64)
+        C += rng.uniform(0.015, 0.04) ** 2 * np.outer(m, m)
+    lz = np.log(z / z.min() + 1e-3)
+    lz = (lz - lz.mean()) / lz.std()
+    for p in range(1, 5):
+        f = lz**p / np.max(np.abs(lz**p))
+        C += rng.uniform(0.01, 0.03) ** 2 * np.outer(f, f)
+    A = 0.004 * rng.standard_normal((n, 20))
+    C += A @ A.T
+    return 0.5 * (C + C.T)

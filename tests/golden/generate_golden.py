@@ -102,7 +102,19 @@ def case_interpolator():
     print("interpolator.npz", {k: v.shape for k, v in out.items()})
 
 
-def _inject_pantheon():
+def _repo_synthetic():
+    """cosmology-model-fit_amd/synthetic.py of THIS repo (seeded data recipes shared with the tests), loaded by path:
+    the package itself is not imported in the generator."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location(
+        "cf_synthetic", os.path.join(os.path.dirname(os.path.dirname(HERE)), "cosmology-model-fit_amd", "synthetic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _inject_pantheon(cov_fn=None):
     import pandas as pd
 
     df = pd.read_csv(os.path.join(REF, "y2022pantheonSHOES/raw-data/distances.txt"), sep=" ")
@@ -111,7 +123,7 @@ def _inject_pantheon():
     zh = df["zHEL"].to_numpy(np.float64)[sel]
     mb = df["m_b_corr"].to_numpy(np.float64)[sel]
     sig = df["m_b_corr_err_DIAG"].to_numpy(np.float64)[sel]
-    cov = synthetic_cov(sig)
+    cov = synthetic_cov(sig) if cov_fn is None else cov_fn(z, sig)
     pkg = types.ModuleType("y2022pantheonSHOES")
     pkg.__path__ = []
     mod = types.ModuleType("y2022pantheonSHOES.data")
@@ -148,6 +160,46 @@ def case_sn_pantheon():
         out[f"cum_sub_{k}"] = cum[::250]
     np.savez_compressed(os.path.join(HERE, "sn_pantheon.npz"), **out)
     print("sn_pantheon.npz chi2[:4] =", chi2[:4], "logp[-4:] =", logp[-4:])
+
+
+def case_sn_pantheon_hardcov():
+    """sn/pantheon.py on the real Pantheon+ redshift / magnitude columns with the HARD seeded covariance
+    (synthetic.hard_cov: duplicated SNe with rho up to 0.99995, a coherent systematic, survey offsets, smooth-in-z
+    modes; cond(C) ~ 3e6): the conditioning-sensitive case of chi^2 = ||L^-1 Delta||^2."""
+    syn = _repo_synthetic()
+    _enter_reference()
+    z, zh, mb, sig = _inject_pantheon(lambda z_, s_: syn.hard_cov(z_, s_, seed=0))
+    import sn.pantheon as m
+
+    rng = np.random.default_rng(21)
+    thetas = theta_batch(m.bounds, 24, rng)
+    # walkers near the best fit too: there Delta is small and smooth, the cancellation-prone right-hand side
+    near = np.array([-19.35, 70.4, 0.33, 0.0]) + rng.standard_normal((8, 4)) * np.array([0.01, 0.5, 0.01, 0.3])
+    thetas = np.vstack([thetas, near])
+    chi2 = np.array([m.chi_squared(t) for t in thetas])
+    logp = np.array([m.log_probability(t) for t in thetas])
+    w = np.linalg.eigvalsh(m.cov_matrix)
+    out = dict(z_cmb=z, z_hel=zh, obs=mb, sigma=sig, bounds=m.bounds, thetas=thetas, chi2=chi2, logp=logp,
+               z_max=np.float64(m.z_grid[-1]), cond_cov=np.float64(w[-1] / w[0]), cov_seed=np.int64(0),
+               cov_checksum=np.float64(np.sum(m.cov_matrix * np.arange(1, z.size + 1)[:, None])))
+    DM = m.DM_z(thetas[0], m.z_cmb)
+    out["delta_0"] = m.mb_vals - thetas[0][0] - m.mu_corr(thetas[0], DM) - m.mu_theory(DM)
+    # second data vector, CONSISTENT with the covariance (magnitudes drawn from the model + L N(0,1)): chi^2 ~ N near the
+    # truth, so a relative bar of 1e-10 is not diluted by the huge duplicate-pair terms of the real magnitudes
+    import importlib
+
+    truth = np.array([-19.35, 70.4, 0.315, 0.0])
+    DMt = m.DM_z(truth, m.z_cmb)
+    mb2 = truth[0] + m.mu_theory(DMt) + np.linalg.cholesky(m.cov_matrix) @ np.random.default_rng(22).standard_normal(z.size)
+    cov = m.cov_matrix
+    sys.modules["y2022pantheonSHOES.data"].get_data = lambda: ("Pantheon+ z, model magnitudes", z, zh, mb2, cov)
+    m = importlib.reload(m)
+    out["obs_consistent"] = mb2
+    out["chi2_consistent"] = np.array([m.chi_squared(t) for t in thetas])
+    out["logp_consistent"] = np.array([m.log_probability(t) for t in thetas])
+    np.savez_compressed(os.path.join(HERE, "sn_pantheon_hardcov.npz"), **out)
+    print("sn_pantheon_hardcov.npz cond(C) = %.3e" % out["cond_cov"], "chi2[:3] =", chi2[:3], "consistent data, near the truth:",
+          out["chi2_consistent"][-3:])
 
 
 def _cmb_consts(cmb):
@@ -432,7 +484,7 @@ def case_sn_pantheon_dipole():
     sel = df["zHD"].to_numpy(np.float64) > 0.01
     col = lambda name, dt=np.float64: df[name].to_numpy(dtype=dt)[sel]
     z, zh, mb, sig = col("zHD"), col("zHEL"), col("m_b_corr"), col("m_b_corr_err_DIAG")
-    cov = synthetic_cov(sig)
+    cov = synthetic_cov(sig) if cov_fn is None else cov_fn(z, sig)
     pkg = types.ModuleType("y2022pantheonSHOES"); pkg.__path__ = []
     mod = types.ModuleType("y2022pantheonSHOES.data")
     mod.get_data_with_position = lambda: ("Pantheon+ (synthetic cov)", z, zh, mb, col("RA"), col("DEC"), col("IDSURVEY", np.int32), cov)
@@ -460,7 +512,7 @@ def case_sn_pantheon_and_sh0es():
     rng_sel = np.where(((zall >= 0.0) & (df["IS_CALIBRATOR"] == 1)) | (zall > 0.01))[0]  # data_shoes.py:30-31
     col = lambda name: df[name].to_numpy(np.float64)[rng_sel]
     z, zh, mb, ceph, sig = col("zHD"), col("zHEL"), col("m_b_corr"), col("CEPH_DIST"), col("m_b_corr_err_DIAG")
-    cov = synthetic_cov(sig)
+    cov = synthetic_cov(sig) if cov_fn is None else cov_fn(z, sig)
     pkg = types.ModuleType("y2022pantheonSHOES"); pkg.__path__ = []
     mod = types.ModuleType("y2022pantheonSHOES.data_shoes")
     mod.get_data = lambda z_cut_ceph=0.0: ("Pantheon+ and SH0ES (synthetic cov)", z, zh, mb, ceph, cov)
@@ -518,6 +570,7 @@ def case_bao_desi_union3_cc_theta_star():
 CASES = {
     "interpolator": case_interpolator,
     "sn_pantheon": case_sn_pantheon,
+    "sn_pantheon_hardcov": case_sn_pantheon_hardcov,
     "bao_desi": case_bao_desi,
     "bao_desi_cmb": case_bao_desi_cmb,
     "bao_desi_fs_lya_cmb": case_bao_desi_fs_lya_cmb,

@@ -130,3 +130,29 @@ def test_kde_density_matches_scipy():
     got = ens._kde_logpdf(pts, comp, torch.linalg.inv(chol).T.contiguous(), log_norm)
     ref = gaussian_kde(comp.numpy().T, bw_method="silverman").logpdf(pts.numpy().T)
     np.testing.assert_allclose(got.numpy(), ref, rtol=1e-10)
+
+
+def test_stream_keys_never_collide_across_steps_halves_and_streams():
+    """with an arithmetic key the KDE move's noise streams of step t were the partner / accept streams of
+    step t + 1.  Every (step, half, stream) a run at ndim = 16 touches must have its own key, also across seeds."""
+    ens = load_pkg().ensemble
+    streams = list(range(0, 4 + 2 * 16 + 2)) + [ens.MAX_STREAMS - 1]
+    keys = {}
+    for seed in (41, 42, 43):
+        for step in list(range(0, 6)) + [1000003, 1000004]:
+            for half in (0, 1):
+                for s in streams:
+                    k = ens.stream_key(seed, step, half, s)
+                    assert k not in keys, f"key collision: {(seed, step, half, s)} vs {keys[k]}"
+                    keys[k] = (seed, step, half, s)
+    ids = torch.arange(0, 4096, dtype=torch.int64)
+    # the two collisions the advisor ran
+    assert not torch.equal(ens.uniform01(42, 5, 0, ids, 10), ens.uniform01(42, 6, 0, ids, 2))
+    assert not torch.equal(ens.uniform01(42, 5, 0, ids, 8), ens.uniform01(42, 6, 0, ids, 0))
+    assert not torch.equal(ens.uniform01(42, 5, 1, ids, 8), ens.uniform01(42, 6, 1, ids, 0))
+    assert not torch.equal(ens.uniform01(42, 1000003, 0, ids, 0), ens.uniform01(43, 0, 0, ids, 0))
+    # per-walker numbers of two (step, stream) pairs are uncorrelated
+    a, b = ens.uniform01(42, 5, 0, ids, 10), ens.uniform01(42, 6, 0, ids, 2)
+    assert abs(float(((a - 0.5) * (b - 0.5)).mean())) < 5e-3
+    with pytest.raises(ValueError):
+        ens.stream_key(1, 0, 0, ens.MAX_STREAMS)
