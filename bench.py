@@ -2,18 +2,24 @@
 """
 bench.py — walker-logL evals/s on Pantheon+-shaped full-covariance chi^2 (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--walkers-per-gpu 4096] [--n-sn 1701]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--walkers-per-gpu n] [--scaling weak|strong] [--n-sn 1701]
 
-N > 1 is launched by the driver as
+`python bench.py --gpus N` with N > 1 starts the N ranks itself (torch.distributed.run, one process per GPU, RCCL) from
+a parent that never touches a GPU; the driver's own launch
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
-one process per GPU (RCCL).  A "step" is one pass of the hot path over the ensemble: every rank
-evaluates log P for the walkers it owns (weak scaling: --walkers-per-gpu each) with theta already
-resident in HBM; for N > 1 the step first all-gathers the walker positions (the exchange an
-ensemble move needs to pick partners from the complementary set).  Rank 0 prints ONE JSON line.
+is recognised by RANK / WORLD_SIZE in the environment and runs the rank directly.
 
-Workload at N=1 = BASELINE.json configs[1]: Pantheon+ 1701-SN full-cov flat-LambdaCDM, 4096 walkers.
-Data are synthetic (the real covariance is not in the reference snapshot): see
-cosmology-model-fit_amd/synthetic.py.  All arithmetic float64.
+A "step" is one pass of the hot path over the ensemble: every rank evaluates log P for the walkers it owns with theta
+already resident in HBM; for N > 1 the step first all-gathers the walker positions (the exchange an ensemble move needs
+to pick partners from the complementary set).  Rank 0 prints ONE JSON line.
+
+Workloads (BASELINE.json configs):
+  N = 1          configs[1]: Pantheon+ 1701-SN full-cov flat-LambdaCDM, 4096 walkers.
+  N = 2, 4       the same, 4096 walkers per GPU (weak scaling).
+  N = 8          configs[3]: 65536 walkers sharded over 8 GPUs = 8192 per GPU (override with --walkers-per-gpu).
+  --scaling strong: 65536 walkers in total at every N (65536 / N per GPU).
+Data are synthetic (the real covariance is not in the reference snapshot): see cosmology-model-fit_amd/synthetic.py.
+All arithmetic float64.
 """
 import argparse
 import importlib
@@ -44,7 +50,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--walkers-per-gpu", type=int, default=4096)
+    ap.add_argument("--walkers-per-gpu", type=int, default=None,
+                    help="default: 4096 (BASELINE configs[1]); 8192 at N = 8 (configs[3]: 65536 walkers over 8 GPUs)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: fixed walkers per GPU; strong: 65536 walkers in total (--walkers-total) at every N")
+    ap.add_argument("--walkers-total", type=int, default=65536, help="ensemble size of --scaling strong")
+    ap.add_argument("--fde", default="lcdm", choices=["lcdm", "cpl"],
+                    help="desi_cmb_des5y only: dark energy as shipped (Lambda) or the script's commented w0waCDM line "
+                         "(bao/desi_cmb_des5y.py:28-31), BASELINE configs[2] as worded")
     ap.add_argument("--n-sn", type=int, default=1701)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-seconds of work of the cpu_baseline sample (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -57,40 +70,52 @@ def main():
                          "would batch it); both on the committed fixture data")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N`: this parent starts one child per GPU and never initialises a GPU itself
+        import socket
+        import subprocess
+
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
+
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no HIP device visible); there is no CPU path to time instead")
-    # one GPU per rank; the modulo only matters for a rehearsal of several ranks on a 1-GPU box
-    local_rank = local_rank % torch.cuda.device_count()
+    pkg = importlib.import_module("cosmology-model-fit_amd")
+    if not os.path.exists(pkg._lib.LIB_PATH) and local_rank == 0:
+        pkg.build()  # normally built by __graft_entry__.build(); the Makefile moves the finished file into place atomically
+    n_visible = torch.cuda.device_count()
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # "gloo": rehearsal only (ranks sharing one GPU)
+    if world > n_visible and backend == "nccl":
+        sys.exit(f"bench.py: {world} ranks but {n_visible} GPU(s) visible; RCCL needs one GPU per rank "
+                 "(BENCH_DIST_BACKEND=gloo rehearses several ranks on one GPU)")
+    local_rank = local_rank % n_visible
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # "gloo": rehearsal only (ranks sharing one GPU)
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
-
-    pkg = importlib.import_module("cosmology-model-fit_amd")
-    if not os.path.exists(pkg._lib.LIB_PATH):  # normally built by __graft_entry__.build(); never fall back to anything else
-        if local_rank == 0:
-            pkg.build()
-        for _ in range(600):
-            if os.path.exists(pkg._lib.LIB_PATH):
-                break
-            time.sleep(0.5)
+        dist.barrier()  # rank 0 may have been building the library: nobody loads it before this point
     sn = pkg.sn_pantheon
-    Wl = args.walkers_per_gpu
+    if args.scaling == "strong":
+        if args.walkers_total % (32 * world):
+            sys.exit("--walkers-total must be a multiple of 32 x the number of GPUs")
+        Wl = args.walkers_total // world
+    else:
+        Wl = args.walkers_per_gpu or (8192 if world == 8 else 4096)
     W_total = Wl * world
 
     solve_kw = {} if args.solve == "default" else {"solve": args.solve}
@@ -102,9 +127,12 @@ def main():
         A = 0.01 * rng.standard_normal((g["sigma"].size, 40))
         chol = np.linalg.cholesky(np.diag(g["sigma"] ** 2) + A @ A.T)
         lk = pkg.likelihoods.DesiCmbDes5y(g["z_cmb"], g["z_hel"], g["obs"], None, g["bao_z"], g["bao_val"], g["bao_qty"],
-                                          g["bao_inv_cov"], chol=chol, device=local_rank, **solve_kw)
-        box = np.array([(-0.5, 0.5), (60.0, 75.0), (0.010, 0.030), (0.01, 0.25), (-4.5, 4.5)])  # bao/desi_cmb_des5y.py:156-161
-        args.n_sn, ndim, kind = int(g["z_cmb"].size), 5, pkg.CF_OUT_LOGL
+                                          g["bao_inv_cov"], chol=chol, device=local_rank, fde=args.fde, **solve_kw)
+        box = [(-0.5, 0.5), (60.0, 75.0), (0.010, 0.030), (0.01, 0.25), (-4.5, 4.5)]  # bao/desi_cmb_des5y.py:156-161
+        if args.fde == "cpl":
+            box += [(-3.0, 1.0), (-3.0, 2.0)]  # w0, wa: bao/desi_fs_lya_cmb.py:135-136
+        box = np.array(box)
+        args.n_sn, ndim, kind = int(g["z_cmb"].size), len(box), pkg.CF_OUT_LOGL
         args.no_cpu_baseline = True
     elif args.workload == "desi_des5y_bbn_theta_star":
         g = np.load(os.path.join(ROOT, "tests", "golden", "bao_desi_des5y_bbn_theta_star.npz"))
@@ -167,12 +195,23 @@ def main():
     result = logp.cpu().numpy()
     assert np.all(np.isfinite(result)), "in-box walkers must give a finite log-probability"
 
+    # which physical device each rank ran on (uuid / PCI address), gathered so that rank 0 can show they are distinct
+    props = torch.cuda.get_device_properties(dev)
+    ident = "%s pci %04x:%02x:%02x uuid %s" % (props.name, getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0),
+                                              getattr(props, "pci_device_id", 0), getattr(props, "uuid", "?"))
+    idents = [ident]
+    if world > 1:
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+
     if rank == 0:
         solve_kernel = "tri_gemm_chi2_kernel" if eng.info()["solve_mode"] == pkg.CF_SOLVE_INVERSE_GEMM else "trsm_chi2_kernel"
         resid_ms = float(np.mean([a for a, _ in kms]))
         solve_ms = float(np.mean([b for _, b in kms]))
         solve_flops = flops_per_eval_solve(args.n_sn) * Wl
         achieved = solve_flops / (solve_ms * 1e-3) / 1e12
+        traffic, traffic_source = pmc_traffic(args.workload if args.fde == "lcdm" else f"{args.workload}:{args.fde}", args.n_sn, Wl,
+                                              solve_kernel)
         out = {
             "metric": {"pantheon": "walker-logL evals/s, Pantheon+ 1701-SN full-cov chi2",
                        "desi_cmb_des5y": "walker-logL evals/s, DESI BAO + Planck/ACT CMB + DES-SN joint chi2 (config 3 shape)",
@@ -185,7 +224,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -197,9 +236,17 @@ def main():
                  f"(R, l_A, wb), physical-density E(z), {Wl} walkers per GPU per step") if args.workload == "desi_cmb_des5y" else
                 (f"bao/desi_des5y_bbn_theta_star.py joint log P: {args.n_sn} SNe + 13 BAO (exact D_H) + l_A + BBN prior, "
                  f"physical-density E(z) with thawing dark energy, {Wl} walkers per GPU per step"),
+                "workload_key": args.workload if args.fde == "lcdm" else f"{args.workload}:{args.fde}",
                 "walkers_per_gpu": Wl, "walkers_total": W_total, "n_sn": args.n_sn, "n_grid": 4000, "ndim": ndim,
-                "parallelism": f"walkers sharded over {world} GPU(s)" + (", RCCL all-gather of positions per step" if world > 1 else ""),
+                "parallelism": f"walkers sharded over {world} GPU(s)" + (
+                    "" if world == 1 else
+                    ", RCCL all-gather of positions per step" if backend == "nccl" else
+                    f", {backend} all-gather of positions staged through the host (rehearsal: not RCCL)"),
             },
+            "backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if world > 1 else None,
+            "world_size": world,
+            "device_ids": idents,
+            "distinct_devices": len(set(idents)),
             "roofline": {
                 "kernel": solve_kernel,
                 "bound": "mfma",
@@ -207,7 +254,8 @@ def main():
                 "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                "traffic": pmc_traffic(args.n_sn, Wl, solve_kernel),
+                "traffic": traffic,
+                "traffic_source": traffic_source,
                 "flops_per_launch": solve_flops,
                 "avg_kernel_ms": solve_ms,
                 "measured_mfma_f64_ceiling": FP64_MFMA_MEASURED_TFLOPS,
@@ -220,7 +268,6 @@ def main():
         # kernel / its duration (small by design: the factor is reused by every walker from L2 / Infinity Cache);
         # `trsv_equivalent_gbps` = what a design without reuse would have to stream (8 N (N+1) / 2 bytes per eval),
         # quoted for comparison with the CPU path only -- it exceeds the 8 TB/s HBM peak because of the reuse.
-        traffic = out["roofline"]["traffic"]
         out["roofline"]["hbm_gbps_measured"] = traffic / (solve_ms * 1e-3) / 1e9 if traffic else None
         out["roofline"]["trsv_equivalent_gbps"] = 8.0 * args.n_sn * (args.n_sn + 1) / 2 * out["value"] / 1e9
         if world == 1 and not args.no_cpu_baseline:  # context probes (this and cpu_baseline) stay out of profiled runs
@@ -234,7 +281,11 @@ def main():
             reps = max(3, args.steps // 5)
             for _ in range(reps):
                 host_res = lk.log_probs_vectorized(th_host)
-            out["host_buffer_evals_per_s"] = Wl * reps / (time.perf_counter() - t0)
+            # SURVEY 8(d)'s own wording of the metric: wall-clock, host-visible, H2D of theta and D2H of the results
+            # included -- first-class beside `value` (which is theta-resident, as the bench contract asks)
+            out["value_host_visible"] = Wl * reps / (time.perf_counter() - t0)
+            out["host_visible"] = {"metric": out["metric"] + ", host numpy buffers through cf_eval (H2D + kernels + D2H + sync)",
+                                   "value": out["value_host_visible"], "unit": "evals/s", "calls": reps}
             assert np.array_equal(host_res, result)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, syn, lk, theta_all_host, result, args.cpu_seconds)
@@ -274,16 +325,23 @@ def host_cpu():
     return {"model": model, "logical_cpus": os.cpu_count(), "usable": len(os.sched_getaffinity(0))}
 
 
-def pmc_traffic(n_sn, walkers, kernel):
-    """HBM bytes per launch of the solve kernel from the committed PMC profile of THIS configuration
-    (tools/pmc_profile.sh: separate --pmc passes, gfx950 FETCH_SIZE correction); None when there is none."""
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if prof["config"]["n_sn"] == n_sn and prof["config"]["walkers_per_gpu"] == walkers:
-            return prof["kernels"][kernel]["hbm_bytes_per_launch"]
-    except Exception:
-        pass
-    return None
+def pmc_traffic(workload, n_sn, walkers, kernel):
+    """(HBM bytes per launch of the solve kernel, source file) from the newest committed PMC profile of THIS configuration
+    (profiles/r*_pmc_traffic*.json, written by tools/pmc_profile.sh + tools/pmc_summary.py: separate --pmc passes of this
+    same bench command, gfx950 FETCH_SIZE correction); (None, None) when there is none.  Counters cannot be read from
+    inside the timed run, so the number is replayed from that file and labelled as such (`traffic_source`)."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
+        try:
+            prof = json.load(open(path))
+            cfg = prof["config"]
+            if cfg["n_sn"] == n_sn and cfg["walkers_per_gpu"] == walkers and cfg.get("workload", "pantheon") == workload \
+                    and kernel in prof["kernels"]:
+                return prof["kernels"][kernel]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
 
 
 def cpu_baseline(pkg, syn, lk, theta, gpu_logp, budget_s):

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcosmofit_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-CF_ABI_VERSION = 4
+CF_ABI_VERSION = 5
 CF_P_NSLOTS = 10
 SLOTS = ("offset", "H0", "Om", "obh2", "och2", "w0", "wa", "v", "rd", "fcc")
 
@@ -72,6 +72,8 @@ class cf_desc(C.Structure):
         ("cc_z", C.c_void_p), ("cc_h", C.c_void_p), ("cc_inv_cov", C.c_void_p),
         ("cc_logdet", C.c_double),
         ("solve_mode", C.c_int32), ("_pad4", C.c_int32),
+        ("probe_limit", C.c_double),
+        ("n_devices", C.c_int32), ("_pad5", C.c_int32), ("devices", C.c_void_p),
     ]
 
 
@@ -80,7 +82,8 @@ class cf_info(C.Structure):
         ("n_sn", C.c_int64), ("n_sn_pad", C.c_int64), ("packed_chol_bytes", C.c_int64),
         ("workspace_bytes", C.c_int64), ("max_walkers", C.c_int64), ("nonfinite_count", C.c_int64),
         ("device", C.c_int32), ("cu_count", C.c_int32), ("gcn_arch", C.c_char * 64),
-        ("pack_probe_rel", C.c_double), ("solve_mode", C.c_int32), ("_pad0", C.c_int32),
+        ("pack_probe_rel", C.c_double), ("solve_mode", C.c_int32), ("n_devices", C.c_int32),
+        ("devices", C.c_int32 * 16),
     ]
 
 
@@ -94,6 +97,7 @@ EXPORTS = {
     "cf_destroy": (None, [_VP]),
     "cf_get_info": (C.c_int, [_VP, C.POINTER(cf_info)]),
     "cf_eval": (C.c_int, [_VP, _VP, _I64, _VP, _I32]),
+    "cf_split_rows": (None, [_I64, _I32, _I32, C.POINTER(_I64), C.POINTER(_I64)]),
     "cf_eval_device": (C.c_int, [_VP, _VP, _I64, _VP, _I32, _VP]),
     "cf_eval_parts": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP]),
     "cf_last_kernel_ms": (C.c_int, [_VP, C.POINTER(C.c_float * 2)]),

@@ -9,8 +9,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/cosmofit.h"
@@ -102,17 +105,30 @@ static void default_shape(int& ks, int& tc) {
   }
 }
 #define CF_PROBE_LIMIT 1e-11
+// default sub-batches of a large evaluation (see create_one); 0 = one batch
+#ifndef CF_DEFAULT_CHUNK_FIRST
+#define CF_DEFAULT_CHUNK_FIRST 0
+#define CF_DEFAULT_CHUNK_REST 0
+#endif
 
 static int pack_default(const double* L, int64_t n, int64_t ld, cf_host_pack& hp, double* probe_rel = nullptr) {
   int ks, tc;
   default_shape(ks, tc);
   int rc = cf_pack_cholesky(L, n, ld, hp, ks, tc);
   if (rc == 0 && probe_rel) *probe_rel = cf_pack_probe(hp, L, ld);
-  // TIMING EXPERIMENT ONLY (wrong results): fold every update stream onto the first 64 KiB so that
-  // all factor loads hit L1/L2 -- tells an operand-delivery bound from an MFMA-issue bound.
+#ifdef CF_DEBUG
+  // TIMING EXPERIMENT ONLY (wrong results; debug builds: make EXTRA=-DCF_DEBUG): fold every update stream onto the
+  // first 64 KiB so that all factor loads hit L1/L2 -- tells an operand-delivery bound from an MFMA-issue bound.
   if (rc == 0 && getenv("CF_DEBUG_ALIAS_STREAMS"))
     for (auto& o : hp.upd_off) o = o % 32;
+#endif
   return rc;
+}
+
+static std::string fmt_g(double v) {
+  char buf[32];
+  snprintf(buf, sizeof(buf), "%.3g", v);
+  return buf;
 }
 
 static int fail(int code, const std::string& msg) {
@@ -198,15 +214,38 @@ struct PinnedBuf {
   }
 };
 
+#define CF_MAX_CHUNKS 8  // sub-batches of one evaluation (walker kernel of chunk c + 1 beside the solve of chunk c)
+
+// A host thread that evaluates one replica's slice of a multi-device cf_eval (one per replica beyond the first).
+struct cf_worker {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  bool has_job = false, done = false, quit = false;
+  const double* theta = nullptr;
+  double* out = nullptr;
+  int64_t W = 0;
+  int out_kind = 0, rc = 0;
+  std::string err;
+};
+
 struct cf_handle {
   int device = 0;
   int solve_mode = 0;
   PinnedBuf stage_in, stage_out;
   InversePack ipack;
   DevBuf partial, arrivals;  // inverse-GEMM solve: chi^2 shares per (row block, walker); arrival counters per panel
-  hipStream_t stream = nullptr;
-  // timing ring: 3 events per evaluation (before A, between A and B, after B)
+  hipStream_t stream = nullptr;  // host-buffer evaluations (cf_eval, cf_eval_parts)
+  hipStream_t aux = nullptr;     // second stream of a chunked evaluation
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_walker[2] = {nullptr, nullptr};
+  // the ONE workspace is shared by every evaluation of this handle: an evaluation launched on a different stream
+  // than the previous one first waits for the event recorded at the end of that one
+  hipEvent_t ev_last = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool has_last = false;
+  // timing ring: per evaluation and chunk 3 events (before the walker kernel, between it and the solve, after the solve)
   std::vector<hipEvent_t> ev;
+  std::vector<int> ev_chunks;  // chunks of the evaluation in each ring slot
   int timing_slots = 0;
   int64_t timed_calls = 0;
   cf_dev_desc d{};
@@ -220,6 +259,10 @@ struct cf_handle {
   double pack_probe_rel = 0.0;
   int cu_count = 0;
   char arch[64] = {0};
+  int64_t chunk_first = 0, chunk_rest = 0;  // sub-batch sizes of a chunked evaluation (0: one batch)
+  // replicas on further devices (owned by the primary handle) and their worker threads
+  std::vector<cf_handle*> peers;
+  std::vector<std::unique_ptr<cf_worker>> workers;
   std::mutex mu;
 };
 
@@ -285,9 +328,7 @@ static int ensure_workspace(cf_handle* h, int64_t W) {
   return 0;
 }
 
-extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
-  if (!c || !out) return fail(CF_ERR_INVALID, "cf_create: null argument");
-  *out = nullptr;
+static int validate_desc(const cf_desc* c) {
   if (c->abi_version != CF_ABI_VERSION || c->struct_size != (int32_t)sizeof(cf_desc))
     return fail(CF_ERR_INVALID, "cf_create: descriptor ABI version / size mismatch (got version " +
                                     std::to_string(c->abi_version) + ", size " + std::to_string(c->struct_size) +
@@ -336,14 +377,26 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
       return fail(CF_ERR_INVALID, "cf_create: SN block arrays must not be null");
     if (c->sn_chol_ld < c->n_sn) return fail(CF_ERR_INVALID, "cf_create: sn_chol_ld < n_sn");
   }
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-    return fail(CF_ERR_NO_DEVICE, "cf_create: no HIP device visible (this library has no CPU path)");
-  if (c->device < 0 || c->device >= ndev) return fail(CF_ERR_INVALID, "cf_create: device ordinal out of range");
+  if (c->n_devices < -1 || c->n_devices > 64 || (c->n_devices > 0 && !c->devices))
+    return fail(CF_ERR_INVALID, "cf_create: n_devices must be -1 (all), 0 (cf_desc.device) or 1..64 with a devices array");
+  if (!(c->probe_limit >= 0.0)) return fail(CF_ERR_INVALID, "cf_create: probe_limit must be >= 0 (0 = default)");
+  return 0;
+}
 
+// Host-side preparation shared by the replicas of a multi-device handle: the factor is packed (and, for the
+// inverse-GEMM solve, inverted in extended precision) once, then uploaded to every device.
+struct HostPrep {
+  bool packed = false;
+  int solve_mode = 0;
+  double probe_rel = 0.0;
+  cf_host_invpack ip;
+  cf_host_pack hp;
+};
+
+static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** out) {
   cf_handle* h = new cf_handle();
   auto bail = [&](int code) { cf_destroy(h); return code; };
-  h->device = c->device;
+  h->device = device;
   if (hipSetDevice(h->device) != hipSuccess) return bail(fail(CF_ERR_HIP, "hipSetDevice failed"));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) {
@@ -352,8 +405,23 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
   }
   if (strncmp(h->arch, "gfx950", 6) != 0)
     return bail(fail(CF_ERR_UNSUPPORTED, std::string("cf_create: device is ") + h->arch + ", this library is built for gfx950 only"));
-  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess)
     return bail(fail(CF_ERR_HIP, "hipStreamCreate failed"));
+  for (hipEvent_t* e : {&h->ev_fork, &h->ev_join, &h->ev_walker[0], &h->ev_walker[1], &h->ev_last})
+    if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return bail(fail(CF_ERR_HIP, "hipEventCreate failed"));
+  {
+    // sub-batches of a large evaluation (CF_CHUNKS=<first>,<rest>; 0 = one batch): the distance / residual kernel of
+    // chunk c + 1 (FP64 VALU) runs beside the solve of chunk c (FP64 matrix cores); a walker's result does not depend
+    // on the chunking (tests/test_gpu_parity.py: batch invariance)
+    h->chunk_first = CF_DEFAULT_CHUNK_FIRST;
+    h->chunk_rest = CF_DEFAULT_CHUNK_REST;
+    if (const char* e = getenv("CF_CHUNKS")) {
+      long long a = 0, b = 0;
+      const int n = sscanf(e, "%lld,%lld", &a, &b);
+      if (n >= 1 && a >= 0) { h->chunk_first = a / 32 * 32; h->chunk_rest = (n == 2 && b > 0 ? b : a) / 32 * 32; }
+    }
+  }
 
   cf_dev_desc& d = h->d;
   d.ndim = c->ndim;
@@ -463,35 +531,42 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
       if (!(piv > 0.0) || !std::isfinite(piv))
         return bail(fail(CF_ERR_NOT_POSDEF, "cf_create: the Cholesky factor has a non-positive or non-finite pivot"));
     }
-    h->solve_mode = c->solve_mode;
-    double inv_probe = 0.0;
-    if (c->solve_mode != CF_SOLVE_BLOCKED_TRSM) {
-      cf_host_invpack ip;
-      cf_pack_inverse(c->sn_chol, c->n_sn, c->sn_chol_ld, ip);
-      inv_probe = cf_invpack_probe(ip, c->sn_chol, c->sn_chol_ld);
-      double inv_limit = CF_PROBE_LIMIT;
-      if (const char* e = getenv("CF_DEBUG_INVERSE_PROBE_LIMIT")) inv_limit = atof(e);  // tests: force the fallback
-      if (inv_probe <= inv_limit) {
-        h->solve_mode = CF_SOLVE_INVERSE_GEMM;
-        h->pack_probe_rel = inv_probe;
-        if ((rc = h->ipack.upload(ip))) return bail(rc);
-      } else if (c->solve_mode == CF_SOLVE_INVERSE_GEMM) {
-        return bail(fail(CF_ERR_ILL_CONDITIONED, "cf_create: the explicit inverse of the factor disagrees with row-by-row forward "
-                                                     "substitution by " + std::to_string(inv_probe) + " relative (limit 1e-11); use "
-                                                     "CF_SOLVE_BLOCKED_TRSM or CF_SOLVE_AUTO for this covariance"));
-      } else {
-        h->solve_mode = CF_SOLVE_BLOCKED_TRSM;  // CF_SOLVE_AUTO falls back to forward substitution by blocks
+    if (!prep.packed) {
+      const double limit = c->probe_limit > 0.0 ? c->probe_limit : CF_PROBE_LIMIT;
+      prep.solve_mode = c->solve_mode;
+      if (c->solve_mode != CF_SOLVE_BLOCKED_TRSM) {
+        cf_pack_inverse(c->sn_chol, c->n_sn, c->sn_chol_ld, prep.ip);
+        const double inv_probe = cf_invpack_probe(prep.ip, c->sn_chol, c->sn_chol_ld);
+        if (inv_probe <= limit) {
+          prep.solve_mode = CF_SOLVE_INVERSE_GEMM;
+          prep.probe_rel = inv_probe;
+        } else if (c->solve_mode == CF_SOLVE_INVERSE_GEMM) {
+          return bail(fail(CF_ERR_ILL_CONDITIONED, "cf_create: the explicit inverse of the factor disagrees with row-by-row forward "
+                                                       "substitution by " + fmt_g(inv_probe) + " relative (limit " +
+                                                       fmt_g(limit) + "); use CF_SOLVE_BLOCKED_TRSM or CF_SOLVE_AUTO for "
+                                                       "this covariance"));
+        } else {
+          prep.solve_mode = CF_SOLVE_BLOCKED_TRSM;  // CF_SOLVE_AUTO falls back to forward substitution by blocks
+          prep.ip = cf_host_invpack();
+        }
       }
+      if (prep.solve_mode == CF_SOLVE_BLOCKED_TRSM) {
+        if (pack_default(c->sn_chol, c->n_sn, c->sn_chol_ld, prep.hp, &prep.probe_rel) != 0)
+          return bail(fail(CF_ERR_NOT_POSDEF, "cf_create: the Cholesky factor has a non-positive or non-finite pivot"));
+        // the blocked solve inverts only 256-row diagonal blocks: its limit is the library's, not the caller's
+        if (!(prep.probe_rel <= CF_PROBE_LIMIT))
+          return bail(fail(CF_ERR_ILL_CONDITIONED, "cf_create: the blocked solve disagrees with row-by-row forward substitution by " +
+                                                       fmt_g(prep.probe_rel) + " relative on a probe vector (limit 1e-11): "
+                                                       "the factor's diagonal blocks are too ill-conditioned for 256-row block inverses"));
+      }
+      prep.packed = true;
     }
-    if (h->solve_mode == CF_SOLVE_BLOCKED_TRSM) {
-      cf_host_pack hp;
-      if (pack_default(c->sn_chol, c->n_sn, c->sn_chol_ld, hp, &h->pack_probe_rel) != 0)
-        return bail(fail(CF_ERR_NOT_POSDEF, "cf_create: the Cholesky factor has a non-positive or non-finite pivot"));
-      if (!(h->pack_probe_rel <= CF_PROBE_LIMIT))
-        return bail(fail(CF_ERR_ILL_CONDITIONED, "cf_create: the blocked solve disagrees with row-by-row forward substitution by " +
-                                                     std::to_string(h->pack_probe_rel) + " relative on a probe vector (limit 1e-11): "
-                                                     "the factor's diagonal blocks are too ill-conditioned for 256-row block inverses"));
-      if ((rc = h->pack.upload(hp))) return bail(rc);
+    h->solve_mode = prep.solve_mode;
+    h->pack_probe_rel = prep.probe_rel;
+    if (h->solve_mode == CF_SOLVE_INVERSE_GEMM) {
+      if ((rc = h->ipack.upload(prep.ip))) return bail(rc);
+    } else {
+      if ((rc = h->pack.upload(prep.hp))) return bail(rc);
     }
   }
   if (c->n_bao > 0) {
@@ -571,13 +646,79 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
   return CF_OK;
 }
 
+static int eval_host_single(cf_handle* h, const double* theta, int64_t W, double* out, int out_kind);
+
+// Worker thread of one replica: waits for a slice, evaluates it on its device, reports the status.
+static void worker_main(cf_handle* replica, cf_worker* w) {
+  std::unique_lock<std::mutex> lk(w->m);
+  for (;;) {
+    w->cv.wait(lk, [&] { return w->has_job || w->quit; });
+    if (w->quit) return;
+    w->has_job = false;
+    lk.unlock();
+    const int rc = eval_host_single(replica, w->theta, w->W, w->out, w->out_kind);
+    const std::string err = rc ? g_err : std::string();
+    lk.lock();
+    w->rc = rc;
+    w->err = err;
+    w->done = true;
+    w->cv.notify_all();
+  }
+}
+
+extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
+  if (!c || !out) return fail(CF_ERR_INVALID, "cf_create: null argument");
+  *out = nullptr;
+  int rc = validate_desc(c);
+  if (rc) return rc;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(CF_ERR_NO_DEVICE, "cf_create: no HIP device visible (this library has no CPU path)");
+  std::vector<int> devs;
+  if (c->n_devices == 0) devs.push_back(c->device);
+  else if (c->n_devices < 0) for (int i = 0; i < ndev; ++i) devs.push_back(i);
+  else devs.assign(c->devices, c->devices + c->n_devices);
+  for (int dv : devs)
+    if (dv < 0 || dv >= ndev) return fail(CF_ERR_INVALID, "cf_create: device ordinal out of range");
+  HostPrep prep;
+  cf_handle* primary = nullptr;
+  if ((rc = create_one(c, devs[0], prep, &primary))) return rc;
+  for (size_t k = 1; k < devs.size(); ++k) {
+    cf_handle* r = nullptr;
+    if ((rc = create_one(c, devs[k], prep, &r))) {
+      const std::string keep = g_err;
+      cf_destroy(primary);
+      return fail(rc, keep);
+    }
+    primary->peers.push_back(r);
+    primary->workers.emplace_back(new cf_worker());
+    cf_worker* w = primary->workers.back().get();
+    w->th = std::thread(worker_main, r, w);
+  }
+  (void)hipSetDevice(devs[0]);
+  *out = primary;
+  return CF_OK;
+}
+
 extern "C" void cf_destroy(cf_handle* h) {
   if (!h) return;
+  for (auto& w : h->workers) {
+    {
+      std::lock_guard<std::mutex> lk(w->m);
+      w->quit = true;
+    }
+    w->cv.notify_all();
+    if (w->th.joinable()) w->th.join();
+  }
+  for (cf_handle* r : h->peers) cf_destroy(r);
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();  // evaluations launched on callers' streams may still use the workspace
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_walker[0], h->ev_walker[1], h->ev_last})
+    if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->aux) (void)hipStreamDestroy(h->aux);
   delete h;
 }
 
@@ -595,6 +736,9 @@ extern "C" int cf_get_info(cf_handle* h, cf_info* info) {
   info->device = h->device;
   info->cu_count = h->cu_count;
   info->pack_probe_rel = h->pack_probe_rel;
+  info->n_devices = 1 + (int32_t)h->peers.size();
+  info->devices[0] = h->device;
+  for (size_t k = 0; k < h->peers.size() && k + 1 < 16; ++k) info->devices[k + 1] = h->peers[k]->device;
   snprintf(info->gcn_arch, sizeof(info->gcn_arch), "%s", h->arch);
   unsigned long long nf = 0;
   HIP_TRY(hipSetDevice(h->device));
@@ -609,11 +753,12 @@ extern "C" int cf_enable_timing(cf_handle* h, int slots) {
   if (slots < 0 || slots > 4096) return fail(CF_ERR_INVALID, "cf_enable_timing: slots must be in 0..4096");
   std::lock_guard<std::mutex> lk(h->mu);
   HIP_TRY(hipSetDevice(h->device));
-  while ((int)h->ev.size() < 3 * slots) {
+  while ((int)h->ev.size() < 3 * CF_MAX_CHUNKS * slots) {
     hipEvent_t e;
     HIP_TRY(hipEventCreate(&e));
     h->ev.push_back(e);
   }
+  h->ev_chunks.assign((size_t)slots, 0);
   h->timing_slots = slots;
   h->timed_calls = 0;
   return CF_OK;
@@ -625,10 +770,17 @@ extern "C" int cf_kernel_ms(cf_handle* h, int64_t call, float t[2]) {
   if (!h || !t) return fail(CF_ERR_INVALID, "cf_kernel_ms: null argument");
   if (h->timing_slots == 0 || call < 0 || call >= h->timed_calls || call < h->timed_calls - h->timing_slots)
     return fail(CF_ERR_INVALID, "cf_kernel_ms: that call is not in the timing ring");
-  hipEvent_t* e = &h->ev[3 * (call % h->timing_slots)];
-  HIP_TRY(hipEventSynchronize(e[2]));
-  HIP_TRY(hipEventElapsedTime(&t[0], e[0], e[1]));
-  HIP_TRY(hipEventElapsedTime(&t[1], e[1], e[2]));
+  const int slot = (int)(call % h->timing_slots);
+  t[0] = t[1] = 0.0f;
+  for (int c = 0; c < h->ev_chunks[slot]; ++c) {  // a chunked evaluation: the sum over its sub-batches
+    hipEvent_t* e = &h->ev[3 * (slot * CF_MAX_CHUNKS + c)];
+    float a = 0.0f, b = 0.0f;
+    HIP_TRY(hipEventSynchronize(e[2]));
+    HIP_TRY(hipEventElapsedTime(&a, e[0], e[1]));
+    HIP_TRY(hipEventElapsedTime(&b, e[1], e[2]));
+    t[0] += a;
+    t[1] += b;
+  }
   return CF_OK;
 }
 
@@ -722,44 +874,99 @@ static int launch_tri_gemm(const TriGemmArgs& a, hipStream_t st) {
   return fail(CF_ERR_INVALID, "bad CF_GEMM_SHAPE");
 }
 
-// Launch the path on `st`: per-walker kernel (distance table, residuals, BAO / CMB blocks), then the
-// blocked solve + chi^2 + epilogue (or the bare epilogue for likelihoods without an SN block).
-static int launch_path(cf_handle* h, const double* d_theta, int64_t W, double* d_out, int out_kind, hipStream_t st,
-                       double* dm_out, double* mucorr_out, double* blocks_out, double* bao_out,
-                       double* chi2_sn_out = nullptr) {
+// One sub-batch [off, off + Wc) of an evaluation on stream `st`: per-walker kernel (distance table, residuals; the
+// small-blocks kernel of a joint likelihood), then the solve + chi^2 + epilogue (or the bare epilogue for likelihoods
+// without an SN block).  `off` is a multiple of 32, so every per-walker buffer is addressed by plain offsets and a
+// walker's result does not depend on the chunking.  ev: 3 timing events or null; ev_walker_done: recorded after the
+// per-walker kernels (the next chunk's walker kernel waits for it: chunks enter the chip one after the other).
+static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_t Wc, double* d_out, int out_kind, hipStream_t st,
+                        double* dm_out, double* mucorr_out, double* blocks_out, double* bao_out, double* chi2_sn_out,
+                        hipEvent_t* ev, hipEvent_t ev_walker_done) {
   const cf_dev_desc& d = h->d;
   unsigned long long* nf = h->nonfinite.as<unsigned long long>();
-  hipEvent_t* ev = h->timing_slots ? &h->ev[3 * (h->timed_calls % h->timing_slots)] : nullptr;
+  const double* th = d_theta + off * d.ndim;
+  double* out = d_out + off;
+  double* delta = h->delta.as<double>() ? h->delta.as<double>() + off * d.n_ld : nullptr;
+  d2* bao_nodes = h->bao_nodes.as<d2>() ? h->bao_nodes.as<d2>() + off * d.n_bao * CF_BAO_NODES : nullptr;
   if (ev) HIP_TRY(hipEventRecord(ev[0], st));
   const bool walker_work = d.n_sn > 0 || h->has_small_blocks;
-  double* extra = h->has_small_blocks ? h->chi2_extra.as<double>() : nullptr;
+  double* extra = h->has_small_blocks ? h->chi2_extra.as<double>() + off : nullptr;
   if (walker_work) {
     // skewed {cum, dh} table: one spare 16-byte slot per 2^chunk_shift nodes
     const size_t lds = ((size_t)d.n_grid + (d.n_grid >> d.chunk_shift) + 2) * 16;
-    hipLaunchKernelGGL(pick_walker(d.ez_model, d.fde), dim3((unsigned)W), dim3(512), lds, st, d, d_theta, W,
-                       h->delta.as<double>(), dm_out, mucorr_out, h->bao_nodes.as<d2>());
+    hipLaunchKernelGGL(pick_walker(d.ez_model, d.fde), dim3((unsigned)Wc), dim3(512), lds, st, d, th, Wc, delta, dm_out, mucorr_out,
+                       bao_nodes);
     if (h->has_small_blocks)  // sixteen lanes per walker, sixteen walkers per workgroup
-      hipLaunchKernelGGL(pick_small_blocks(d.ez_model, d.fde), dim3((unsigned)((W + 15) / 16)), dim3(256), 0, st, d, d_theta, W,
-                         h->bao_nodes.as<const d2>(), extra, blocks_out, bao_out);
+      hipLaunchKernelGGL(pick_small_blocks(d.ez_model, d.fde), dim3((unsigned)((Wc + 15) / 16)), dim3(256), 0, st, d, th, Wc,
+                         (const d2*)bao_nodes, extra, blocks_out, bao_out);
   }
+  if (ev_walker_done) HIP_TRY(hipEventRecord(ev_walker_done, st));
   if (ev) HIP_TRY(hipEventRecord(ev[1], st));
   if (d.n_sn > 0 && h->solve_mode == CF_SOLVE_INVERSE_GEMM) {
-    const TriGemmArgs a{&d, &h->ipack.dev, d_theta, W, h->delta.as<const double>(), h->max_walkers, h->partial.as<double>(),
-                        h->arrivals.as<unsigned int>(), extra, d_out, out_kind, nf, chi2_sn_out};
+    const TriGemmArgs a{&d, &h->ipack.dev, th, Wc, delta, h->max_walkers, h->partial.as<double>() + off,
+                        h->arrivals.as<unsigned int>() + off / 16, extra, out, out_kind, nf, chi2_sn_out};
     int rc = launch_tri_gemm(a, st);
     if (rc) return rc;
   } else if (d.n_sn > 0) {
-    int rc = launch_trsm(d, h->pack.dev, d_theta, W, h->delta.as<const double>(), h->ypk.as<d2>(), extra, d_out, out_kind, nf, st,
-                         chi2_sn_out);
+    int rc = launch_trsm(d, h->pack.dev, th, Wc, delta, h->ypk.as<d2>() + (off / 16) * (int64_t)(d.n_pad / 8) * 64, extra, out, out_kind,
+                         nf, st, chi2_sn_out);
     if (rc) return rc;
   } else {
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, d, d_theta, W,
-                       (const double*)extra, d_out, out_kind, nf);
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((Wc + 255) / 256)), dim3(256), 0, st, d, th, Wc, (const double*)extra, out,
+                       out_kind, nf);
+  }
+  if (ev) HIP_TRY(hipEventRecord(ev[2], st));
+  return 0;
+}
+
+// Launch one evaluation of W walkers, ordered on `st`.  Large batches of an SN likelihood run as sub-batches on two
+// streams (h->chunk_first / chunk_rest walkers; chunk c on `st` for even c, on h->aux for odd c), the per-walker kernel
+// of chunk c + 1 beside the solve of chunk c; everything is joined back into `st` before this returns.
+static int launch_path(cf_handle* h, const double* d_theta, int64_t W, double* d_out, int out_kind, hipStream_t st,
+                       double* dm_out, double* mucorr_out, double* blocks_out, double* bao_out,
+                       double* chi2_sn_out = nullptr) {
+  // the workspace is shared: order this evaluation behind the previous one if that ran on another stream
+  if (h->has_last && h->last_stream != st) HIP_TRY(hipStreamWaitEvent(st, h->ev_last, 0));
+  const bool parts = dm_out || mucorr_out || blocks_out || bao_out || chi2_sn_out;
+  int64_t offs[CF_MAX_CHUNKS + 1];
+  int n_chunks = 1;
+  offs[0] = 0;
+  if (!parts && h->d.n_sn > 0 && h->chunk_first > 0 && W > h->chunk_first) {
+    n_chunks = 0;
+    int64_t o = 0, size = h->chunk_first;
+    while (o < W && n_chunks < CF_MAX_CHUNKS - 1) {
+      offs[n_chunks++] = o;
+      o += size;
+      size = h->chunk_rest;
+    }
+    if (o < W) offs[n_chunks++] = o;  // the last chunk takes what is left
+  }
+  offs[n_chunks] = W;
+  const int slot = h->timing_slots ? (int)(h->timed_calls % h->timing_slots) : 0;
+  hipEvent_t* ev = h->timing_slots ? &h->ev[3 * slot * CF_MAX_CHUNKS] : nullptr;
+  if (n_chunks == 1) {
+    int rc = launch_chunk(h, d_theta, 0, W, d_out, out_kind, st, dm_out, mucorr_out, blocks_out, bao_out, chi2_sn_out, ev, nullptr);
+    if (rc) return rc;
+  } else {
+    HIP_TRY(hipEventRecord(h->ev_fork, st));
+    HIP_TRY(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+    for (int c = 0; c < n_chunks; ++c) {
+      hipStream_t sc = (c & 1) ? h->aux : st;
+      if (c > 0) HIP_TRY(hipStreamWaitEvent(sc, h->ev_walker[(c - 1) & 1], 0));  // walker kernels one after the other
+      int rc = launch_chunk(h, d_theta, offs[c], offs[c + 1] - offs[c], d_out, out_kind, sc, nullptr, nullptr, nullptr, nullptr,
+                            nullptr, ev ? ev + 3 * c : nullptr, h->ev_walker[c & 1]);
+      if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(h->ev_join, h->aux));
+    HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
   }
   if (ev) {
-    HIP_TRY(hipEventRecord(ev[2], st));
+    h->ev_chunks[slot] = n_chunks;
     h->timed_calls++;
   }
+  HIP_TRY(hipEventRecord(h->ev_last, st));
+  h->last_stream = st;
+  h->has_last = true;
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -775,6 +982,8 @@ extern "C" int cf_eval_device(cf_handle* h, const double* d_theta, int64_t W, do
                               void* hip_stream) {
   int rc = check_eval_args(h, d_theta, W, d_out, out_kind, "cf_eval_device");
   if (rc) return rc;
+  if (!h->peers.empty())
+    return fail(CF_ERR_INVALID, "cf_eval_device: this handle spans several devices; device-resident evaluation needs one handle per device");
   if (W == 0) return CF_OK;
   std::lock_guard<std::mutex> lk(h->mu);
   HIP_TRY(hipSetDevice(h->device));
@@ -783,10 +992,9 @@ extern "C" int cf_eval_device(cf_handle* h, const double* d_theta, int64_t W, do
   return launch_path(h, d_theta, W, d_out, out_kind, (hipStream_t)hip_stream, nullptr, nullptr, nullptr, nullptr);
 }
 
-extern "C" int cf_eval(cf_handle* h, const double* theta, int64_t W, double* out, int32_t out_kind) {
-  int rc = check_eval_args(h, theta, W, out, out_kind, "cf_eval");
-  if (rc) return rc;
-  if (W == 0) return CF_OK;
+// One replica, host buffers: stage through the handle's pinned block, run on the handle's stream, wait.
+static int eval_host_single(cf_handle* h, const double* theta, int64_t W, double* out, int out_kind) {
+  int rc;
   std::lock_guard<std::mutex> lk(h->mu);
   HIP_TRY(hipSetDevice(h->device));
   if ((rc = ensure_workspace(h, W))) return rc;
@@ -799,6 +1007,53 @@ extern "C" int cf_eval(cf_handle* h, const double* theta, int64_t W, double* out
   HIP_TRY(hipStreamSynchronize(h->stream));
   memcpy(out, h->stage_out.p, (size_t)W * 8);
   return CF_OK;
+}
+
+// Rows of a W-walker batch that replica k of n evaluates: contiguous, whole 32-walker panels, near-equal.
+extern "C" void cf_split_rows(int64_t W, int32_t n, int32_t k, int64_t* begin, int64_t* end) {
+  const int64_t panels = (W + 31) / 32, base = panels / n, extra = panels % n;
+  const int64_t p0 = k * base + (k < extra ? k : extra), p1 = p0 + base + (k < extra ? 1 : 0);
+  *begin = p0 * 32 < W ? p0 * 32 : W;
+  *end = p1 * 32 < W ? p1 * 32 : W;
+}
+
+extern "C" int cf_eval(cf_handle* h, const double* theta, int64_t W, double* out, int32_t out_kind) {
+  int rc = check_eval_args(h, theta, W, out, out_kind, "cf_eval");
+  if (rc) return rc;
+  if (W == 0) return CF_OK;
+  const int n = 1 + (int)h->peers.size();
+  if (n == 1 || W <= 32) return eval_host_single(h, theta, W, out, out_kind);
+  // several devices: replica k > 0 gets its slice through its worker thread, this thread evaluates slice 0
+  const int ndim = h->d.ndim;
+  for (int k = 1; k < n; ++k) {
+    int64_t b, e;
+    cf_split_rows(W, n, k, &b, &e);
+    cf_worker* w = h->workers[k - 1].get();
+    std::lock_guard<std::mutex> lk(w->m);
+    w->theta = theta + b * ndim;
+    w->out = out + b;
+    w->W = e - b;
+    w->out_kind = out_kind;
+    w->done = w->W == 0;
+    w->rc = 0;
+    w->has_job = w->W > 0;
+    if (w->has_job) w->cv.notify_all();
+  }
+  int64_t b0, e0;
+  cf_split_rows(W, n, 0, &b0, &e0);
+  rc = e0 > b0 ? eval_host_single(h, theta + b0 * ndim, e0 - b0, out + b0, out_kind) : 0;
+  std::string err = rc ? g_err : std::string();
+  for (int k = 1; k < n; ++k) {  // always wait for every worker: they write into the caller's buffers
+    cf_worker* w = h->workers[k - 1].get();
+    std::unique_lock<std::mutex> lk(w->m);
+    w->cv.wait(lk, [&] { return w->done; });
+    if (w->rc && !rc) {
+      rc = w->rc;
+      err = w->err;
+    }
+  }
+  (void)hipSetDevice(h->device);
+  return rc ? fail(rc, err) : CF_OK;
 }
 
 extern "C" int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, double* dm_obs, double* mu_corr,

@@ -52,7 +52,7 @@ class LikelihoodEngine:
                  bao: Optional[dict] = None, cmb: Optional[dict] = None, physical: Optional[dict] = None,
                  cc: Optional[dict] = None, solve_mode: int = L.CF_SOLVE_AUTO,
                  bounds=None, gauss: Sequence = (), chi2_gauss: Sequence = (), cpl_wall: bool = False,
-                 device: int = 0, c_km_s: float = C_KM_S):
+                 device: int = 0, devices=None, probe_limit: float = 0.0, c_km_s: float = C_KM_S):
         """
         params: {"H0": Param(1), "Om": Param(2), ...} for the slots of include/cosmofit.h (cf_param_slot).
         sn: dict(z_cmb, z_hel, obs, chol[, step | z_turn, fixed_mu]) — chol is cho_factor(cov, lower=True)[0];
@@ -66,6 +66,10 @@ class LikelihoodEngine:
         physical: dict(or_h2, omnu_h2, o_gamma_h2, nu_m0, nu_rho0, nu_qs_sq[5], nu_ws[5]) — required by
             ez_model=CF_EZ_PHYSICAL (see cmb_data.PLANCK_ACT / EARLY_LCDM).
         gauss / chi2_gauss: sequences of (idx, mean, sigma).
+        devices: None (the single ordinal `device`), "all" (every visible GPU) or a sequence of HIP ordinals: the data and
+            the packed factor are replicated on each, and the host-buffer calls (chi_squared / log_likelihood /
+            log_probability) split their rows over them -- one host process, as emcee / nautilus run, on every GPU.
+        probe_limit: acceptance limit of the create-time accuracy probe of the explicit inverse (0 = default 1e-11).
         solve_mode: CF_SOLVE_AUTO (default: the inverse-GEMM solve when its create-time probe passes, otherwise the
             blocked forward substitution), CF_SOLVE_INVERSE_GEMM or CF_SOLVE_BLOCKED_TRSM; info()["solve_mode"]
             tells which one runs.  See solve_mode_of() for the keyword form the mirrors take.
@@ -77,6 +81,18 @@ class LikelihoodEngine:
         d.ez_model, d.fde, d.n_grid = ez_model, fde, n_grid
         d.z_max, d.c_km_s = float(z_max), float(c_km_s)
         d.solve_mode = int(solve_mode)
+        d.probe_limit = float(probe_limit)
+        dev_arr = None
+        if devices is not None:
+            if isinstance(devices, str):
+                if devices != "all":
+                    raise ValueError('devices must be None, "all" or a sequence of device ordinals')
+                d.n_devices = -1
+            else:
+                dev_arr = np.ascontiguousarray(list(devices), dtype=np.int32)
+                if dev_arr.size < 1:
+                    raise ValueError("devices must name at least one device")
+                d.n_devices, d.devices = dev_arr.size, _ptr(dev_arr)
         unknown = set(params) - set(L.SLOTS)
         if unknown:
             raise ValueError(f"unknown parameter slots {sorted(unknown)}; valid: {L.SLOTS}")

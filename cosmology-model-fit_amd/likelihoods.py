@@ -62,20 +62,20 @@ class DesiBao(_Base):
     """bao/desi.py: theta = (h, Om, w0); bounds bao/desi.py:69-75; r_d = 147.09 Mpc fixed (:10)."""
     bounds = np.array([(0.50, 0.80), (0.1, 0.5), (-1.0, 0.0)])
 
-    def __init__(self, z, val, qty, inv_cov, *, rd=147.09, device=0, bounds=None):
+    def __init__(self, z, val, qty, inv_cov, *, rd=147.09, device=0, devices=None, bounds=None):
         self.bounds = self.bounds if bounds is None else np.asarray(bounds, float)
         self.z_max = float(np.max(z) + 0.1)  # bao/desi.py:19
         self.engine = LikelihoodEngine(
             ndim=3, z_max=self.z_max, n_grid=N_GRID, fde=L.CF_FDE_THAWING,
             params=dict(H0=Param(0, scale=100.0), Om=Param(1), w0=Param(2), rd=Param(fixed=rd)),
-            bao=dict(z=z, val=val, qty=qty, inv_cov=inv_cov), bounds=self.bounds, device=device)
+            bao=dict(z=z, val=val, qty=qty, inv_cov=inv_cov), bounds=self.bounds, device=device, devices=devices)
 
 
 class DesiCmb(_Base):
     """bao/desi_cmb.py: theta = (H0, wb, wc, w0); exact D_H, r_drag fit, (theta*, wb, wm) compression."""
     bounds = np.array([(50.0, 80.0), (0.020, 0.024), (0.05, 0.30), (-1.0, 0.0)])
 
-    def __init__(self, z, val, qty, inv_cov, *, comp=None, device=0, bounds=None):
+    def __init__(self, z, val, qty, inv_cov, *, comp=None, device=0, devices=None, bounds=None):
         comp = cmb_data.EARLY_LCDM if comp is None else comp
         self.bounds = self.bounds if bounds is None else np.asarray(bounds, float)
         self.z_max = float(np.max(z) + 0.1)
@@ -84,13 +84,13 @@ class DesiCmb(_Base):
             params=dict(H0=Param(0), obh2=Param(1), och2=Param(2), w0=Param(3)),
             bao=dict(z=z, val=val, qty=qty, inv_cov=inv_cov, dh_exact=True, rd_fit=comp["rd_fit"]),
             cmb=dict(mode=comp["cmb_mode"], prior=comp["cmb_prior"], inv_cov=comp["cmb_inv_cov"], zstar_fit=comp["zstar_fit"]),
-            physical=_physical(comp), bounds=self.bounds, device=device)
+            physical=_physical(comp), bounds=self.bounds, device=device, devices=devices)
 
 
 class DesiFsLyaCmb(_Base):
     """bao/desi_fs_lya_cmb.py: theta = (H0, wb, wc, w0, wa); CPL; log L = -1e8 when w0 + wa >= 0 (:118-121)."""
 
-    def __init__(self, z, val, qty, inv_cov, *, comp=None, device=0):
+    def __init__(self, z, val, qty, inv_cov, *, comp=None, device=0, devices=None):
         comp = cmb_data.PLANCK_ACT if comp is None else comp
         self.z_max = float(np.max(z) + 0.1)
         self.engine = LikelihoodEngine(
@@ -98,28 +98,42 @@ class DesiFsLyaCmb(_Base):
             params=dict(H0=Param(0), obh2=Param(1), och2=Param(2), w0=Param(3), wa=Param(4)),
             bao=dict(z=z, val=val, qty=qty, inv_cov=inv_cov, rd_fit=comp["rd_fit"]),
             cmb=dict(mode=comp["cmb_mode"], prior=comp["cmb_prior"], inv_cov=comp["cmb_inv_cov"], zstar_fit=comp["zstar_fit"]),
-            physical=_physical(comp), cpl_wall=True, device=device)
+            physical=_physical(comp), cpl_wall=True, device=device, devices=devices)
+
+
+FDE_BY_NAME = {"lcdm": L.CF_FDE_LCDM, "wcdm": L.CF_FDE_WCDM, "thawing": L.CF_FDE_THAWING, "cpl": L.CF_FDE_CPL}
 
 
 class DesiCmbDes5y(_Base):
     """bao/desi_cmb_des5y.py: theta = (dM, H0, wb, wc, v); SN with velocity step at z = 0.10563 (:105), BAO with
     PCHIP D_H and F_AP, Planck+ACT (R, l_A, wb); dark energy = Lambda as shipped (:46).
+    ``fde``: the dark-energy lines the author toggles by commenting (:26-31) -- "lcdm" (as shipped), "wcdm" and "thawing"
+    (theta gains w0), "cpl" (theta gains w0, wa: BASELINE configs[2] as worded, w0waCDM); the dark-energy density then
+    multiplies Ode in Ez exactly as in bao/desi_fs_lya_cmb.py:19-22,40-49; ``cpl_wall`` adds that script's
+    w0 + wa >= 0 -> -1e8 wall (:118-121).
     bao/desi_cmb_pantheon.py is the same likelihood on Pantheon+ with the step at z = 0.15 (:102) and D_H = c / H
     exactly (:62-63): ``DesiCmbDes5y(..., z_turn=0.15, dh_exact=True)`` (alias DesiCmbPantheon)."""
 
     def __init__(self, z_cmb, z_hel, mu_values, cov_sn, bao_z, bao_val, bao_qty, bao_inv_cov, *, chol=None, comp=None,
-                 device=0, solve="auto", latency_mode=None, z_turn=0.10563, dh_exact=False):
+                 device=0, devices=None, solve="auto", latency_mode=None, z_turn=0.10563, dh_exact=False, fde="lcdm",
+                 cpl_wall=False):
         comp = cmb_data.PLANCK_ACT if comp is None else comp
         if chol is None:
             chol = cho_factor(cov_sn, lower=True)[0]  # bao/desi_cmb_des5y.py:17
         self.z_max = float(max(np.max(z_cmb), np.max(bao_z)) + 0.1)  # :20
+        params = dict(offset=Param(0), H0=Param(1), obh2=Param(2), och2=Param(3), v=Param(4))
+        if fde != "lcdm":
+            params["w0"] = Param(5)
+        if fde == "cpl":
+            params["wa"] = Param(6)
+        self.ndim = len(params)
         self.engine = LikelihoodEngine(
-            ndim=5, z_max=self.z_max, n_grid=N_GRID, ez_model=L.CF_EZ_PHYSICAL, fde=L.CF_FDE_LCDM,
-            params=dict(offset=Param(0), H0=Param(1), obh2=Param(2), och2=Param(3), v=Param(4)),
+            ndim=self.ndim, z_max=self.z_max, n_grid=N_GRID, ez_model=L.CF_EZ_PHYSICAL, fde=FDE_BY_NAME[fde],
+            params=params,
             sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=mu_values, chol=chol, z_turn=z_turn),
             bao=dict(z=bao_z, val=bao_val, qty=bao_qty, inv_cov=bao_inv_cov, rd_fit=comp["rd_fit"], dh_exact=dh_exact),
             cmb=dict(mode=comp["cmb_mode"], prior=comp["cmb_prior"], inv_cov=comp["cmb_inv_cov"], zstar_fit=comp["zstar_fit"]),
-            physical=_physical(comp), device=device,
+            physical=_physical(comp), device=device, devices=devices, cpl_wall=cpl_wall,
             solve_mode=solve_mode_of(solve, latency_mode))
 
 
@@ -139,7 +153,7 @@ class DesiCmbDes5yH0Trgb(_Base):
     H0_TRGB = (70.39, 1.80)
 
     def __init__(self, z_cmb, z_hel, mu_values, cov_sn, bao_z, bao_val, bao_qty, bao_inv_cov, sixdf_z, sixdf_val, sixdf_qty,
-                 sixdf_inv_cov, *, chol=None, comp=None, device=0, solve="auto"):
+                 sixdf_inv_cov, *, chol=None, comp=None, device=0, devices=None, solve="auto"):
         from scipy.linalg import block_diag
 
         comp = cmb_data.PLANCK_ACT if comp is None else comp
@@ -156,7 +170,7 @@ class DesiCmbDes5yH0Trgb(_Base):
                      inv_cov=block_diag(np.asarray(bao_inv_cov, float), np.atleast_2d(np.asarray(sixdf_inv_cov, float))),
                      dh_exact=True, rd_fit=comp["rd_fit"]),
             cmb=dict(mode=comp["cmb_mode"], prior=comp["cmb_prior"], inv_cov=comp["cmb_inv_cov"], zstar_fit=comp["zstar_fit"]),
-            physical=_physical(comp), chi2_gauss=[(1, self.H0_TRGB[0], self.H0_TRGB[1])], device=device,
+            physical=_physical(comp), chi2_gauss=[(1, self.H0_TRGB[0], self.H0_TRGB[1])], device=device, devices=devices,
             solve_mode=solve_mode_of(solve))
 
 
@@ -166,7 +180,7 @@ class SnCmb(_Base):
     box prior of sn/pantheon_cmb.py:91-99 when `bounds` is given (the DES script samples with nautilus: log L only)."""
     PANTHEON_BOUNDS = np.array([(-20.0, -19.0), (60.0, 75.0), (0.010, 0.030), (0.010, 0.25), (-2.5, 2.5)])
 
-    def __init__(self, z_cmb, z_hel, obs, cov_sn, *, z_turn, chol=None, comp=None, bounds=None, device=0, solve="auto"):
+    def __init__(self, z_cmb, z_hel, obs, cov_sn, *, z_turn, chol=None, comp=None, bounds=None, device=0, devices=None, solve="auto"):
         comp = cmb_data.PLANCK_ACT if comp is None else comp
         if chol is None:
             chol = cho_factor(cov_sn, lower=True)[0]
@@ -177,7 +191,7 @@ class SnCmb(_Base):
             params=dict(offset=Param(0), H0=Param(1), obh2=Param(2), och2=Param(3), v=Param(4)),
             sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=obs, chol=chol, z_turn=z_turn),
             cmb=dict(mode=comp["cmb_mode"], prior=comp["cmb_prior"], inv_cov=comp["cmb_inv_cov"], zstar_fit=comp["zstar_fit"]),
-            physical=_physical(comp), bounds=self.bounds, device=device, solve_mode=solve_mode_of(solve))
+            physical=_physical(comp), bounds=self.bounds, device=device, devices=devices, solve_mode=solve_mode_of(solve))
 
 
 class DesiDes5yBbnThetaStar(_Base):
@@ -186,7 +200,7 @@ class DesiDes5yBbnThetaStar(_Base):
     bounds = np.array([(-0.5, 0.5), (50.0, 90.0), (0.010, 0.030), (0.05, 0.30), (-1.0, -1 / 3)])
 
     def __init__(self, z_cmb, z_hel, mu_values, cov_sn, bao_z, bao_val, bao_qty, bao_inv_cov, *, chol=None, comp=None,
-                 bbn=cmb_data.BBN_SCHONEBERG, device=0, bounds=None):
+                 bbn=cmb_data.BBN_SCHONEBERG, device=0, devices=None, bounds=None):
         comp = cmb_data.PLANCK_ACT if comp is None else comp
         self.bounds = self.bounds if bounds is None else np.asarray(bounds, float)
         if chol is None:
@@ -200,7 +214,7 @@ class DesiDes5yBbnThetaStar(_Base):
             sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=mu_values, chol=chol),
             bao=dict(z=bao_z, val=bao_val, qty=bao_qty, inv_cov=bao_inv_cov, dh_exact=True, rd_fit=comp["rd_fit"]),
             cmb=dict(mode=2, prior=comp["cmb_prior"], inv_cov=inv, zstar_fit=comp["zstar_fit"]),
-            physical=_physical(comp), bounds=self.bounds, gauss=[(2, bbn[0], bbn[1])], device=device)
+            physical=_physical(comp), bounds=self.bounds, gauss=[(2, bbn[0], bbn[1])], device=device, devices=devices)
 
 
 class SnUnion3(_Base):
@@ -209,14 +223,14 @@ class SnUnion3(_Base):
 
     PRIOR_BOX = np.array([(-1.0, 1.0), (0.1, 0.7), (-9.0, 9.0)])  # the nautilus prior of main() (:77-79)
 
-    def __init__(self, z_cmb, z_hel, mu_vals, cov_matrix, *, H0=70.0, bounds=None, device=0):
+    def __init__(self, z_cmb, z_hel, mu_vals, cov_matrix, *, H0=70.0, bounds=None, device=0, devices=None):
         self.z_max = float(np.max(z_cmb) + 0.1)
         self.bounds = None if bounds is None else np.asarray(bounds, float)
         self.engine = LikelihoodEngine(
             ndim=3, z_max=self.z_max, n_grid=N_GRID, fde=L.CF_FDE_LCDM,
             params=dict(offset=Param(0), H0=Param(fixed=H0), Om=Param(1), v=Param(2)),
             sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=mu_vals, chol=np.linalg.cholesky(cov_matrix), z_turn=0.2),
-            bounds=self.bounds, device=device)
+            bounds=self.bounds, device=device, devices=devices)
 
 
 class CcSn(_Base):
@@ -226,7 +240,7 @@ class CcSn(_Base):
     bounds = np.array([(0.2, 3.0), (-0.5, 0.5), (50.0, 85.0), (0.05, 0.6), (-1.0, -1.0 / 3)])
 
     def __init__(self, z_cmb, z_hel, mu_values, cov_sn, z_cc, H_cc, cov_cc, *, chol=None, fde=L.CF_FDE_WCDM, bounds=None,
-                 device=0, solve="auto"):
+                 device=0, devices=None, solve="auto"):
         if chol is None:
             chol = cho_factor(cov_sn, lower=True)[0]
         self.bounds = self.bounds if bounds is None else np.asarray(bounds, float)
@@ -236,7 +250,7 @@ class CcSn(_Base):
             params=dict(fcc=Param(0), offset=Param(1), H0=Param(2), Om=Param(3), w0=Param(4)),
             sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=mu_values, chol=chol),
             cc=dict(z=z_cc, h=H_cc, inv_cov=np.linalg.inv(cov_cc), logdet=np.linalg.slogdet(cov_cc)[1]),
-            bounds=self.bounds, device=device, solve_mode=solve_mode_of(solve))
+            bounds=self.bounds, device=device, devices=devices, solve_mode=solve_mode_of(solve))
 
 
 class DesiUnion3CcThetaStar(_Base):
@@ -245,7 +259,7 @@ class DesiUnion3CcThetaStar(_Base):
     normalisation with rescaled errors in log L (:129-139).  nautilus vectorized callback: ``log_likelihood``."""
 
     def __init__(self, z_cmb, z_hel, mu_values, cov_sn, bao_z, bao_val, bao_qty, bao_inv_cov, z_cc, H_cc, cov_cc, *,
-                 comp=None, device=0):
+                 comp=None, device=0, devices=None):
         comp = cmb_data.PLANCK_ACT if comp is None else comp
         inv = np.zeros((3, 3))
         inv[1, 1] = 1.0 / comp["cmb_cov"][1, 1]
@@ -257,4 +271,4 @@ class DesiUnion3CcThetaStar(_Base):
             bao=dict(z=bao_z, val=bao_val, qty=bao_qty, inv_cov=bao_inv_cov, dh_exact=True, rd_fit=comp["rd_fit"]),
             cmb=dict(mode=2, prior=comp["cmb_prior"], inv_cov=inv, zstar_fit=comp["zstar_fit"]),
             cc=dict(z=z_cc, h=H_cc, inv_cov=np.linalg.inv(cov_cc), logdet=np.linalg.slogdet(cov_cc)[1]),
-            physical=_physical(comp), device=device)
+            physical=_physical(comp), device=device, devices=devices)

@@ -30,8 +30,9 @@ N_GRID = 4000  # sn/pantheon.py:16
 
 
 class PantheonLikelihood:
-    def __init__(self, z_cmb, z_hel, mb_vals, cov_matrix=None, *, chol=None, device=0, bounds=bounds,
-                 h0_prior=H0_PRIOR, fde=L.CF_FDE_LCDM, step=None, fixed_mu=None, z_turn=Z_TURN, solve="auto", latency_mode=None):
+    def __init__(self, z_cmb, z_hel, mb_vals, cov_matrix=None, *, chol=None, device=0, devices=None, bounds=bounds,
+                 h0_prior=H0_PRIOR, fde=L.CF_FDE_LCDM, step=None, fixed_mu=None, z_turn=Z_TURN, solve="auto", latency_mode=None,
+                 probe_limit=0.0):
         """step: per-SN velocity weights instead of the +-1 Heaviside step (dipole fits, sn/pantheon_dipole.py:60-68:
         cos(angle) * attenuation * survey mask); fixed_mu: Cepheid distance moduli of calibrator hosts, NaN elsewhere
         (sn/pantheon_and_sh0es.py:63-69)."""
@@ -39,6 +40,7 @@ class PantheonLikelihood:
         if chol is None:
             chol = cho_factor(cov_matrix, lower=True)[0]  # sn/pantheon.py:14
         self.bounds = np.asarray(bounds, dtype=np.float64)
+        self.h0_prior = tuple(h0_prior) if h0_prior else None
         self.normalization = -np.sum(np.log(self.bounds[:, 1] - self.bounds[:, 0]))  # sn/pantheon.py:77
         self.z_cmb, self.z_hel, self.mb_vals = z_cmb, np.asarray(z_hel, float), np.asarray(mb_vals, float)
         self.z_max = float(np.max(z_cmb) + 0.1)  # sn/pantheon.py:16
@@ -46,8 +48,8 @@ class PantheonLikelihood:
             ndim=4, z_max=self.z_max, n_grid=N_GRID, fde=fde,
             params=dict(offset=Param(0), H0=Param(1), Om=Param(2), v=Param(3)),
             sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=mb_vals, chol=chol, z_turn=z_turn, step=step, fixed_mu=fixed_mu),
-            bounds=self.bounds, gauss=[h0_prior] if h0_prior else [], device=device,
-            solve_mode=solve_mode_of(solve, latency_mode),
+            bounds=self.bounds, gauss=[h0_prior] if h0_prior else [], device=device, devices=devices,
+            solve_mode=solve_mode_of(solve, latency_mode), probe_limit=probe_limit,
         )
 
     # -- reference names ----------------------------------------------------------------------
@@ -69,7 +71,10 @@ class PantheonLikelihood:
         p = np.asarray(params, dtype=np.float64)
         if not np.all((self.bounds[:, 0] < p) & (p < self.bounds[:, 1])):
             return -np.inf
-        return self.normalization - 0.5 * (p[1] - H0_PRIOR[1]) ** 2 / H0_PRIOR[2] ** 2
+        if self.h0_prior is None:
+            return self.normalization
+        idx, mean, sigma = self.h0_prior
+        return self.normalization - 0.5 * (p[idx] - mean) ** 2 / sigma**2
 
     # -- accessors the post-fit plots use (sn/pantheon.py:152-155) -----------------------------
     def DM_z(self, params):

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 4
+#define CF_ABI_VERSION 5
 
 typedef struct cf_handle cf_handle;
 
@@ -223,6 +223,19 @@ typedef struct cf_desc {
 
   int32_t solve_mode;       /* cf_solve_mode */
   int32_t _pad4;
+  double probe_limit;       /* acceptance limit of the create-time accuracy probe of the packed factor (relative chi^2
+                               discrepancy against row-by-row substitution on three probe vectors); 0 = the default 1e-11.
+                               A smaller value makes CF_SOLVE_AUTO fall back to the blocked solve earlier. */
+
+  /* ---- several GPUs behind one handle (the sampler stays in ONE host process, sn/pantheon.py:119-125) ----
+   * n_devices = 0: the single ordinal `device`.  n_devices > 0: `devices[n_devices]` HIP ordinals; the data and the
+   * packed factor are replicated on each at cf_create, cf_eval splits the rows of theta contiguously over them (one
+   * host thread + one stream per device, disjoint slices of `out`), results are bit-identical to one device.
+   * n_devices = -1: every visible device.  An ordinal may repeat (two replicas on one GPU).  cf_eval_device needs a
+   * single-device handle. */
+  int32_t n_devices;
+  int32_t _pad5;
+  const int32_t* devices;
 } cf_desc;
 
 typedef struct cf_info {
@@ -238,7 +251,8 @@ typedef struct cf_info {
   double pack_probe_rel;   /* |chi2(packed streams) - chi2(row-by-row substitution)| / chi2 on a probe vector,
                               measured on the host at cf_create (refused above 1e-11) */
   int32_t solve_mode;      /* cf_solve_mode in effect (never CF_SOLVE_AUTO) */
-  int32_t _pad0;
+  int32_t n_devices;       /* replicas behind this handle (1 unless cf_desc.n_devices asked for more) */
+  int32_t devices[16];     /* their HIP ordinals (the first 16) */
 } cf_info;
 
 int cf_device_count(void);
@@ -249,8 +263,15 @@ int cf_create(const cf_desc* desc, cf_handle** out);
 void cf_destroy(cf_handle* h);
 int cf_get_info(cf_handle* h, cf_info* info);
 
-/* Host buffers. theta: [W*ndim] C-order float64; out: [W] float64. Synchronous. */
+/* Host buffers. theta: [W*ndim] C-order float64; out: [W] float64. Synchronous.  A handle created over several
+ * devices (cf_desc.n_devices) splits the rows as cf_split_rows says, one host thread and one stream per device; this is
+ * what lets a sampler that lives in one host process (emcee / nautilus with a vectorised callback, sn/pantheon.py:119-125,
+ * bao/desi.py:100-129) use every GPU of the node. */
 int cf_eval(cf_handle* h, const double* theta, int64_t W, double* out, int32_t out_kind);
+
+/* Rows [*begin, *end) of a W-walker batch that replica k of n evaluates: contiguous, whole 32-walker panels, sizes
+ * differing by at most one panel.  Pure host arithmetic (no device needed). */
+void cf_split_rows(int64_t W, int32_t n, int32_t k, int64_t* begin, int64_t* end);
 
 /* Device buffers on the handle's device; asynchronous on `hip_stream` (a hipStream_t; NULL = HIP's
  * default stream, which is what torch.cuda.current_stream().cuda_stream reports as 0), ordered like any

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(pkg):
 def test_desc_layout_matches_c(pkg, tmp_path):
     """sizeof / offsetof of cf_desc and cf_info as gcc sees them == the ctypes mirror."""
     fields = ["ndim", "z_max", "param", "n_sn", "sn_chol_ld", "n_bao", "rd_fit", "cmb_mode", "cmb_inv_cov", "nu_ws",
-              "bounds", "gauss", "chi2_gauss", "sn_fixed_mu", "n_cc", "cc_logdet", "solve_mode"]
+              "bounds", "gauss", "chi2_gauss", "sn_fixed_mu", "n_cc", "cc_logdet", "solve_mode", "probe_limit", "n_devices", "devices"]
     prog = '#include <stdio.h>\n#include <stddef.h>\n#include "cosmofit.h"\nint main(){printf("%zu %zu", sizeof(cf_desc), sizeof(cf_info));' + \
         "".join(f'printf(" %zu", offsetof(cf_desc, {f}));' for f in fields) + "return 0;}"
     src = tmp_path / "sz.c"
@@ -47,6 +47,36 @@ def test_desc_layout_matches_c(pkg, tmp_path):
     assert vals[1] == C.sizeof(L.cf_info)
     for f, off in zip(fields, vals[2:]):
         assert getattr(L.cf_desc, f).offset == off, f
+
+
+def test_split_rows_partitions_a_batch_into_whole_panels(pkg):
+    """cf_eval over n replicas (cf_desc.n_devices): contiguous slices that cover the batch once, cut at 32-walker panels,
+    at most one panel apart in size -- host arithmetic, checked without a GPU."""
+    lib = pkg.lib()
+    for W in (1, 31, 32, 33, 75, 4096, 4097, 65536, 100000):
+        for n in (1, 2, 3, 8):
+            cuts = []
+            for k in range(n):
+                b, e = C.c_int64(), C.c_int64()
+                lib.cf_split_rows(W, n, k, C.byref(b), C.byref(e))
+                cuts.append((b.value, e.value))
+            assert cuts[0][0] == 0 and cuts[-1][1] == W
+            assert all(cuts[k][1] == cuts[k + 1][0] for k in range(n - 1))
+            assert all(b % 32 == 0 or b == W for b, _ in cuts) and all(0 <= b <= e <= W for b, e in cuts)
+            sizes = [e - b for b, e in cuts]
+            assert max(sizes) - min(sizes) <= 32 + 31, (W, n, sizes)
+    b, e = C.c_int64(), C.c_int64()
+    lib.cf_split_rows(65536, 8, 3, C.byref(b), C.byref(e))
+    assert (b.value, e.value) == (3 * 8192, 4 * 8192)  # BASELINE configs[3]: 8192 walkers per GPU
+
+
+def test_engine_rejects_a_bad_device_list(pkg):
+    with pytest.raises(ValueError):
+        pkg.LikelihoodEngine(ndim=2, z_max=1.0, params=dict(H0=pkg.Param(0), Om=pkg.Param(1)), devices="some")
+    with pytest.raises(ValueError):
+        pkg.LikelihoodEngine(ndim=2, z_max=1.0, params=dict(H0=pkg.Param(0), Om=pkg.Param(1)), devices=[])
+    with pytest.raises(pkg.CosmofitError, match="CF_ERR_INVALID"):
+        pkg.LikelihoodEngine(ndim=2, z_max=1.0, params=dict(H0=pkg.Param(0), Om=pkg.Param(1)), probe_limit=-1.0)
 
 
 def test_no_gpu_is_a_loud_error_not_a_fallback(pkg):

@@ -171,6 +171,36 @@ def test_config2_batch_invariance(config2):
     assert lk.chi_squared(theta[:0]).shape == (0,)
 
 
+@pytest.mark.parametrize("W", [8192, 65536])
+def test_configs3_shape_per_rank_and_whole_ensemble(config2, W):
+    """BASELINE configs[3]: 65536 walkers over 8 GPUs = 8192 per rank.  Both shapes on ONE GPU (the per-rank batch, and the
+    whole ensemble as a strong-scaling N = 1 run would see it): the oracle on a 512-walker subset, bit-equality with the
+    same walkers evaluated in 4096-walker batches (batch invariance), the device-resident entry point bit-equal to the
+    host one, and the size-independent property chi2(theta) >= 0 with no non-finite result."""
+    import torch
+
+    lk, ref, theta4096 = config2
+    gpu_pkg = __import__("conftest").load_pkg()
+    theta = gpu_pkg.synthetic.walkers(gpu_pkg.sn_pantheon.bounds, W, seed=0)
+    assert np.array_equal(theta[:0], theta4096[:0]) and theta.shape == (W, 4)
+    got = lk.log_probs_vectorized(theta)
+    assert got.shape == (W,) and np.all(np.isfinite(got))
+    pick = np.sort(np.random.default_rng(W).choice(W, 512, replace=False))
+    pick[0], pick[-1] = 0, W - 1
+    want = ref.logp(theta[pick])
+    rel = np.abs(got[pick] - want) / np.abs(want)
+    assert rel.max() < RTOL, f"max rel diff {rel.max():.3e}"
+    for a in (0, W // 2, W - 4096):  # the same walkers in a 4096 batch: not one bit may differ
+        np.testing.assert_array_equal(lk.log_probs_vectorized(theta[a:a + 4096]), got[a:a + 4096])
+    th = torch.from_numpy(theta).cuda()
+    out = torch.empty(W, dtype=torch.float64, device="cuda")
+    lk.engine.eval_device(th.data_ptr(), W, out.data_ptr(), gpu_pkg.CF_OUT_LOGP, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), got)
+    chi2 = lk.chi_squared(theta)
+    assert np.all(chi2 >= 0) and lk.engine.info()["nonfinite_count"] == 0
+
+
 def test_config2_offset_parameter_property(config2):
     """chi^2 is an exact quadratic in the magnitude offset M: chi2(M) = a + b M + c M^2 with c = 1^T C^-1 1."""
     lk, _, theta = config2
@@ -354,16 +384,75 @@ def test_batched_laplace_evidence_gpu_vs_oracle(gpu):
     lk.engine.close()
 
 
-def test_auto_mode_falls_back_to_the_blocked_solve(gpu, config2, monkeypatch):
-    """CF_SOLVE_AUTO with a failing inverse probe (forced through the debug knob) must run the blocked solve."""
+def test_auto_mode_falls_back_to_the_blocked_solve(gpu, config2):
+    """CF_SOLVE_AUTO with a failing inverse probe (forced through cf_desc.probe_limit) must run the blocked solve."""
     _, ref, theta = config2
     syn = gpu.synthetic.pantheon_like(n_sn=1701, seed=0)
-    monkeypatch.setenv("CF_DEBUG_INVERSE_PROBE_LIMIT", "0")
-    lk = gpu.sn_pantheon.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"])
+    lk = gpu.sn_pantheon.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"], probe_limit=1e-300)
     assert lk.engine.info()["solve_mode"] == gpu.CF_SOLVE_BLOCKED_TRSM
     np.testing.assert_allclose(lk.log_probs_vectorized(theta[:200]), ref.logp(theta[:200]), rtol=RTOL)
     with pytest.raises(gpu.CosmofitError, match="CF_ERR_ILL_CONDITIONED"):
-        gpu.sn_pantheon.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"], solve="inverse")
+        gpu.sn_pantheon.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"], solve="inverse", probe_limit=1e-300)
+    lk.engine.close()
+
+
+@pytest.mark.parametrize("solve", ["auto", "blocked"])
+def test_replicas_and_chunks_do_not_change_a_walkers_result(gpu, solve, monkeypatch):
+    """one handle over several devices splits the rows of theta over its replicas (one host thread + one
+    stream each).  On a one-GPU box the ordinals repeat -- two / three replicas on the same device exercise the same
+    split, threads and streams; where more GPUs are visible, "all" spreads over them.  Results are bit-identical to the
+    single-device handle, and so are those of a chunked evaluation (CF_CHUNKS: walker kernel of chunk c + 1 beside the
+    solve of chunk c)."""
+    syn = gpu.synthetic.pantheon_like(n_sn=531, seed=4)
+    mk = lambda **kw: gpu.sn_pantheon.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"], solve=solve, **kw)
+    theta = gpu.synthetic.walkers(gpu.sn_pantheon.bounds, 3000, seed=5)
+    theta[17, 2] = 0.9  # one walker outside the box
+    one = mk()
+    want = one.log_probs_vectorized(theta)
+    for devs in ([0, 0], [0, 0, 0], "all"):
+        lk = mk(devices=devs)
+        info = lk.engine.info()
+        assert info["n_devices"] == (gpu.lib().cf_device_count() if devs == "all" else len(devs))
+        for W in (3000, 1, 31, 33, 64, 1000):
+            assert np.array_equal(lk.log_probs_vectorized(theta[:W]), want[:W]), (devs, W)
+        assert np.array_equal(lk.chi_squared(theta), one.chi_squared(theta))
+        if info["n_devices"] > 1:
+            import torch
+            t = torch.zeros((64, 4), dtype=torch.float64, device="cuda")
+            with pytest.raises(gpu.CosmofitError, match="several devices"):
+                lk.engine.eval_device(t.data_ptr(), 64, t.data_ptr(), gpu.CF_OUT_LOGP, 0)
+        lk.engine.close()
+    for chunks in ("512", "256,1024", "1024,512"):
+        monkeypatch.setenv("CF_CHUNKS", chunks)
+        lk = mk()
+        for W in (3000, 513, 2048):
+            assert np.array_equal(lk.log_probs_vectorized(theta[:W]), want[:W]), (chunks, W)
+        lk.engine.close()
+    monkeypatch.delenv("CF_CHUNKS")
+    one.engine.close()
+
+
+def test_evaluations_on_different_streams_are_ordered(gpu):
+    """cf_eval (the handle's own stream) right after an asynchronous cf_eval_device on the caller's stream
+    shares the one workspace; the library orders them with an event."""
+    import torch
+
+    syn = gpu.synthetic.pantheon_like(n_sn=700, seed=6)
+    lk = gpu.sn_pantheon.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"])
+    th_a = gpu.synthetic.walkers(gpu.sn_pantheon.bounds, 2048, seed=7)
+    th_b = gpu.synthetic.walkers(gpu.sn_pantheon.bounds, 2048, seed=8)
+    want_a, want_b = lk.log_probs_vectorized(th_a), lk.log_probs_vectorized(th_b)
+    ta = torch.from_numpy(th_a).cuda()
+    side = torch.cuda.Stream()
+    for _ in range(10):
+        out_a = torch.empty(2048, dtype=torch.float64, device="cuda")
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                lk.engine.eval_device(ta.data_ptr(), 2048, out_a.data_ptr(), gpu.CF_OUT_LOGP, side.cuda_stream)
+        got_b = lk.log_probs_vectorized(th_b)  # host path, on the handle's stream, while `side` is still busy
+        side.synchronize()
+        assert np.array_equal(got_b, want_b)
+        assert np.array_equal(out_a.cpu().numpy(), want_a)
     lk.engine.close()
 
 

@@ -21,20 +21,28 @@ open(os.path.join(out, "pmc_summary.txt"), "w").write(txt + "\n")
 # HBM-side traffic per launch, corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE (KB) counts
 # 128-B read requests at 64 B -> double it; WRITE_SIZE (KB) is exact for 16-B-per-lane streaming stores.
 import json
+cfg, run = {}, {}
+try:
+    run = json.load(open(os.path.join(out, "pass1.json")))
+    cfg = run["config"]
+except Exception:
+    pass
+steps_total = (run.get("steps", 0) + run.get("warmup", 0)) or None
 traffic = {}
 for k, cs in acc.items():
     if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
         name = "trsm_chi2_kernel" if "trsm" in k else ("tri_gemm_chi2_kernel" if "tri_gemm" in k else ("walker_kernel" if "walker" in k else None))
         if name:
-            f = cs["FETCH_SIZE"][2:] or cs["FETCH_SIZE"]
-            w = cs["WRITE_SIZE"][2:] or cs["WRITE_SIZE"]
+            # a chunked evaluation dispatches the kernel several times per step: bytes per step = per-dispatch mean x dispatches
+            per_step = max(1, round(len(cs["FETCH_SIZE"]) / steps_total)) if steps_total else 1
+            f = cs["FETCH_SIZE"][2 * per_step:] or cs["FETCH_SIZE"]
+            w = cs["WRITE_SIZE"][2 * per_step:] or cs["WRITE_SIZE"]
             fk, wk = sum(f) / len(f), sum(w) / len(w)
-            traffic[name] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_bytes_per_launch": (2 * fk + wk) * 1024}
-cfg = {}
-try:
-    cfg = json.load(open(os.path.join(out, "pass1.json")))["config"]
-except Exception:
-    pass
-json.dump({"config": {k: cfg.get(k) for k in ("n_sn", "walkers_per_gpu", "n_grid")}, "kernels": traffic,
-           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE) KB (gfx950 correction)"},
+            traffic[name] = {"FETCH_SIZE_KB_per_dispatch": fk, "WRITE_SIZE_KB_per_dispatch": wk, "dispatches_per_step": per_step,
+                             "hbm_bytes_per_launch": (2 * fk + wk) * 1024 * per_step}
+json.dump({"config": {"n_sn": cfg.get("n_sn"), "walkers_per_gpu": cfg.get("walkers_per_gpu"), "n_grid": cfg.get("n_grid"),
+                      "workload": cfg.get("workload_key", "pantheon")},
+           "kernels": traffic,
+           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of `python bench.py --steps 5 --warmup 2`; "
+                     "bytes per step of W walkers = (2*FETCH_SIZE + WRITE_SIZE) KB per dispatch (gfx950 correction) x dispatches per step"},
           open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
