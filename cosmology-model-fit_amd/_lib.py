@@ -11,12 +11,13 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcosmofit_hip.so")
+# COSMOFIT_LIB: another build of the same sources (tools/build_variant.sh: tuning / debug variants for A/B timing)
+LIB_PATH = os.environ.get("COSMOFIT_LIB") or os.path.join(_HERE, "libcosmofit_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 CF_ABI_VERSION = 5
-CF_P_NSLOTS = 10
-SLOTS = ("offset", "H0", "Om", "obh2", "och2", "w0", "wa", "v", "rd", "fcc")
+CF_P_NSLOTS = 15
+SLOTS = ("offset", "H0", "Om", "obh2", "och2", "w0", "wa", "v", "rd", "fcc", "lin", "v2", "v3", "s8", "fs8err")
 
 # enums of include/cosmofit.h
 CF_EZ_LATE_FLAT, CF_EZ_PHYSICAL = 0, 1
@@ -74,6 +75,7 @@ class cf_desc(C.Structure):
         ("solve_mode", C.c_int32), ("_pad4", C.c_int32),
         ("probe_limit", C.c_double),
         ("n_devices", C.c_int32), ("_pad5", C.c_int32), ("devices", C.c_void_p),
+        ("om_mode", C.c_int32), ("_pad6", C.c_int32), ("sn_lin_coef", C.c_void_p), ("sn_dir", C.c_void_p),
     ]
 
 

@@ -251,7 +251,7 @@ struct cf_handle {
   cf_dev_desc d{};
   PackedFactor pack;
   DevBuf z_cmb, z_hel, obs, sn_step, sn_rec, log10_tab;
-  DevBuf bao_z, bao_val, bao_inv_cov, bao_qty, gl_x, gl_w, fixed_mu, cc_z, cc_h, cc_inv_cov, nu_grid;
+  DevBuf bao_z, bao_val, bao_inv_cov, bao_qty, gl_x, gl_w, fixed_mu, cc_z, cc_h, cc_inv_cov, nu_grid, sn_lin, sn_dir;
   DevBuf theta, out, delta, ypk, chi2_extra, nonfinite;
   DevBuf bao_nodes, bao_base;  // [max_walkers][n_bao][CF_BAO_NODES] table nodes for small_blocks_kernel; first node per datum
   bool has_small_blocks = false;  // BAO and / or CMB block present
@@ -377,6 +377,7 @@ static int validate_desc(const cf_desc* c) {
       return fail(CF_ERR_INVALID, "cf_create: SN block arrays must not be null");
     if (c->sn_chol_ld < c->n_sn) return fail(CF_ERR_INVALID, "cf_create: sn_chol_ld < n_sn");
   }
+  if (c->om_mode != 0 && c->om_mode != 1) return fail(CF_ERR_INVALID, "cf_create: om_mode must be 0 or 1");
   if (c->n_devices < -1 || c->n_devices > 64 || (c->n_devices > 0 && !c->devices))
     return fail(CF_ERR_INVALID, "cf_create: n_devices must be -1 (all), 0 (cf_desc.device) or 1..64 with a devices array");
   if (!(c->probe_limit >= 0.0)) return fail(CF_ERR_INVALID, "cf_create: probe_limit must be >= 0 (0 = default)");
@@ -443,8 +444,12 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
   d.n_sn = (int32_t)c->n_sn;
   d.n_pad = (int32_t)((c->n_sn + 15) / 16 * 16);
   d.n_ld = (int32_t)((c->n_sn + 63) / 64 * 64);
-  // a velocity step exists if its slot is a parameter or a non-zero constant
+  // a velocity step exists if its slot is a parameter or a non-zero constant (with directions: any of the three)
   d.has_vstep = c->param[CF_P_V].idx >= 0 || c->param[CF_P_V].fixed != 0.0;
+  if (c->sn_dir)
+    for (int s : {CF_P_V2, CF_P_V3}) d.has_vstep = d.has_vstep || c->param[s].idx >= 0 || c->param[s].fixed != 0.0;
+  d.om_mode = c->om_mode;
+  d.lin_in_rec = c->sn_lin_coef && !d.has_vstep;
   d.or_h2 = c->or_h2;
   d.omnu_h2 = c->omnu_h2;
   d.o_gamma_h2 = c->o_gamma_h2;
@@ -517,7 +522,8 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
       // one record per SN for the production loop; 512 spare records so that its look-ahead needs no bounds check
       std::vector<cf_d4> rec((size_t)d.n_ld + 512, cf_d4{1.0, 1.0, 1.0, 0.0});
       for (int64_t i = 0; i < c->n_sn; ++i)
-        rec[i] = cf_d4{d.has_vstep ? 1.0 + c->sn_z_cmb[i] : c->sn_z_cmb[i], step[i], 1.0 + c->sn_z_hel[i], c->sn_obs[i]};
+        rec[i] = cf_d4{d.has_vstep ? 1.0 + c->sn_z_cmb[i] : c->sn_z_cmb[i], d.lin_in_rec ? c->sn_lin_coef[i] : step[i],
+                       1.0 + c->sn_z_hel[i], c->sn_obs[i]};
       if (h->sn_rec.ensure(rec.size() * sizeof(cf_d4))) return bail(CF_ERR_HIP);
       if (hipMemcpy(h->sn_rec.p, rec.data(), rec.size() * sizeof(cf_d4), hipMemcpyHostToDevice) != hipSuccess)
         return bail(fail(CF_ERR_HIP, "hipMemcpy(sn_rec) failed"));
@@ -632,6 +638,16 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
     int rc;
     if ((rc = upload_vec(h->fixed_mu, c->sn_fixed_mu, c->n_sn))) return bail(rc);
     d.sn_fixed_mu = h->fixed_mu.as<const double>();
+  }
+  if (c->n_sn > 0 && c->sn_lin_coef) {
+    int rc;
+    if ((rc = upload_vec(h->sn_lin, c->sn_lin_coef, c->n_sn))) return bail(rc);
+    d.sn_lin = h->sn_lin.as<const double>();
+  }
+  if (c->n_sn > 0 && c->sn_dir) {
+    int rc;
+    if ((rc = upload_vec(h->sn_dir, c->sn_dir, 3 * c->n_sn))) return bail(rc);
+    d.sn_dir = h->sn_dir.as<const double>();
   }
   if (c->cmb_mode != CF_CMB_NONE) {
     int rc;

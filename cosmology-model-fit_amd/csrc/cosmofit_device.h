@@ -11,7 +11,7 @@
 #define CF_MAX_BAO 64
 #define CF_MAX_GL 256
 #define CF_MAX_CC 64
-#define CF_N_SLOTS 10
+#define CF_N_SLOTS 15
 
 // One block row of the blocked solve = 16 MFMA tiles of 16 rows.
 #define CF_BLOCK_TILES 16
@@ -36,6 +36,11 @@
 #define CF_P_V_D 7
 #define CF_P_RD_D 8
 #define CF_P_FCC_D 9
+#define CF_P_LIN_D 10
+#define CF_P_V2_D 11
+#define CF_P_V3_D 12
+#define CF_P_S8_D 13
+#define CF_P_FS8ERR_D 14
 
 #define CF_OUT_CHI2_D 0
 #define CF_OUT_LOGL_D 1
@@ -72,6 +77,9 @@ struct cf_dev_desc {
   int32_t has_vstep;  // 0: the likelihood has no peculiar-velocity step (z_cosmo = z_cmb)
   int32_t step_pm1;   // 1: every sn_step entry is +1 or -1
   const double* sn_fixed_mu;  // [n_sn] or null; non-NaN entries replace mu_theory (SH0ES calibrators)
+  const double* sn_lin;       // [n_sn] or null: offset_i = offset + theta_LIN * sn_lin[i] (bulk-flow magnitude term)
+  const double* sn_dir;       // [n_sn * 3] or null: unit vectors of a direction-dependent peculiar velocity
+  int32_t om_mode, lin_in_rec;  // om_mode 1: slot OM holds omega_m = Omega_m h^2; lin_in_rec: sn_rec[i].y carries sn_lin[i]
   // cosmic chronometers
   int32_t n_cc, pad3;
   const double* cc_z;

@@ -46,6 +46,10 @@ __device__ __forceinline__ WalkerCosmo make_cosmo(const cf_dev_desc& d, const do
   WalkerCosmo wc;
   wc.H0 = slot_get(d, CF_P_H0_D, th);
   wc.Om = slot_get(d, CF_P_OM_D, th);
+  if (d.om_mode) {  // the sampler's parameter is omega_m = Omega_m h^2    bao/desi_omh2.py:18-20
+    const double h = wc.H0 / 100;
+    wc.Om = wc.Om / (h * h);
+  }
   wc.w0 = slot_get(d, CF_P_W0_D, th);
   wc.wa = slot_get(d, CF_P_WA_D, th);
   wc.c = d.c;
@@ -552,9 +556,11 @@ __device__ double r_drag_fit(const double* f, double wb, double wm) {
 // two values per walker and z_cosmo = -1 + (1+z) * (1/(1+z_pec)) needs no per-SN division
 // (<= 1 ulp of 1+z_cosmo away from the quotient form).
 // ------------------------------------------------------------------------------------------------
-template <bool PM1>
+// LIN: the record's second field carries the coefficient of the linear magnitude term instead of a step weight (only
+// likelihoods without a velocity step): offset_i = offset + lin * coef_i    bao/desi_cmb_pantheon_H0trgb.py:102-106
+template <bool PM1, bool LIN = false>
 __device__ __forceinline__ void sn_fast_loop(const cf_dev_desc& d, const DistTable& T, const d2* __restrict__ log_tab,
-                                             double* __restrict__ out, double off, double v100, int tid) {
+                                             double* __restrict__ out, double off, double v100, int tid, double lin = 0.0) {
   const int n_sn = d.n_sn;
   double r_pos = 1.0, r_neg = 1.0;
   if (PM1 && d.has_vstep) {
@@ -568,7 +574,7 @@ __device__ __forceinline__ void sn_fast_loop(const cf_dev_desc& d, const DistTab
   auto one_sn = [&](const d4& r, int i) {
     const double za = r[0], st = r[1], zhp1 = r[2], ob = r[3];
     double z_cosmo = za;
-    if (d.has_vstep) {
+    if (!LIN && d.has_vstep) {
       if (PM1) {
         z_cosmo = -1.0 + za * (st > 0.0 ? r_pos : r_neg);
       } else {  // general weights (dipole fits): sn/pantheon.py:43-48 as written
@@ -576,7 +582,8 @@ __device__ __forceinline__ void sn_fast_loop(const cf_dev_desc& d, const DistTab
         z_cosmo = -1.0 + za / (1.0 + z_pec);
       }
     }
-    out[i] = ob - off - (25.0 + 5 * log10_tab(zhp1 * hermite_fast(T, z_cosmo), log_tab));
+    const double off_i = LIN ? off + lin * st : off;
+    out[i] = ob - off_i - (25.0 + 5 * log10_tab(zhp1 * hermite_fast(T, z_cosmo), log_tab));
   };
   // two records in flight, ping-pong (no register copies); the record array carries 512 spare entries past n_ld
   d4 ra = rec[0], rb;
@@ -653,41 +660,48 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
     double* out = delta + w * d.n_ld;
     const double off = slot_get(d, CF_P_OFFSET_D, th);
     const double v100 = 100 * slot_get(d, CF_P_V_D, th);
+    const double lin = d.sn_lin ? slot_get(d, CF_P_LIN_D, th) : 0.0;
     const bool parts = dm_out != nullptr || mucorr_out != nullptr;
-    if (!parts && !d.sn_fixed_mu) {
-      if (d.step_pm1) sn_fast_loop<true>(d, T, log_tab, out, off, v100, tid);
+    if (!parts && !d.sn_fixed_mu && !d.sn_dir && (!d.sn_lin || d.lin_in_rec)) {
+      if (d.lin_in_rec) sn_fast_loop<false, true>(d, T, log_tab, out, off, v100, tid, lin);
+      else if (d.step_pm1) sn_fast_loop<true>(d, T, log_tab, out, off, v100, tid);
       else sn_fast_loop<false>(d, T, log_tab, out, off, v100, tid);
-    } else
-    for (int i = tid; i < d.n_ld; i += CF_TPB_A) {
-      double res = 0.0;
-      if (i < d.n_sn) {
-        const double zc = d.z_cmb[i];
-        double z_cosmo = zc;
-        if (d.has_vstep) {  // sn/pantheon.py:43-49
-          const double v_km_s = v100 * d.sn_step[i];
-          const double z_pec = v_km_s / d.c;
-          z_cosmo = -1.0 + (1.0 + zc) / (1.0 + z_pec);
+    } else {
+      // direction-dependent velocity: v_los = n . (V, V2, V3), weight = sn_step    sn/pantheon_dipole_xyz.py:54-57
+      const double vx = slot_get(d, CF_P_V_D, th), vy = slot_get(d, CF_P_V2_D, th), vz = slot_get(d, CF_P_V3_D, th);
+      for (int i = tid; i < d.n_ld; i += CF_TPB_A) {
+        double res = 0.0;
+        if (i < d.n_sn) {
+          const double zc = d.z_cmb[i];
+          const double off_i = d.sn_lin ? off + lin * d.sn_lin[i] : off;
+          double z_cosmo = zc;
+          if (d.has_vstep) {  // sn/pantheon.py:43-49
+            const double v_km_s = d.sn_dir ? 100 * (d.sn_dir[3 * i] * vx + d.sn_dir[3 * i + 1] * vy + d.sn_dir[3 * i + 2] * vz) * d.sn_step[i]
+                                           : v100 * d.sn_step[i];
+            const double z_pec = v_km_s / d.c;
+            z_cosmo = -1.0 + (1.0 + zc) / (1.0 + z_pec);
+          }
+          const double DMc = hermite_tab(T, z_cosmo);
+          const double fixed = d.sn_fixed_mu ? d.sn_fixed_mu[i] : __longlong_as_double(0x7ff8000000000000ll);
+          if (fixed == fixed) {  // calibrator: its distance modulus is data, only mu_corr is theory (sn/pantheon_and_sh0es.py:65-67)
+            const double DM = hermite_tab(T, zc);
+            const double mu_corr = d.has_vstep ? 5.0 * log10_pos(DMc / DM) : 0.0;
+            res = d.obs[i] - off_i - mu_corr - fixed;
+            if (dm_out) dm_out[w * d.n_sn + i] = DM;
+            if (mucorr_out) mucorr_out[w * d.n_sn + i] = mu_corr;
+          } else if (!parts) {
+            res = d.obs[i] - off_i - (25.0 + 5 * log10_pos((1.0 + d.z_hel[i]) * DMc));
+          } else {
+            const double DM = hermite_tab(T, zc);
+            const double mu_corr = d.has_vstep ? 5.0 * log10(DMc / DM) : 0.0;
+            const double mu_th = 25.0 + 5 * log10((1.0 + d.z_hel[i]) * DM);  // sn/pantheon.py:52-54
+            res = d.obs[i] - off_i - mu_corr - mu_th;                        // sn/pantheon.py:59-60
+            if (dm_out) dm_out[w * d.n_sn + i] = DM;
+            if (mucorr_out) mucorr_out[w * d.n_sn + i] = mu_corr;
+          }
         }
-        const double DMc = hermite_tab(T, z_cosmo);
-        const double fixed = d.sn_fixed_mu ? d.sn_fixed_mu[i] : __longlong_as_double(0x7ff8000000000000ll);
-        if (fixed == fixed) {  // calibrator: its distance modulus is data, only mu_corr is theory (sn/pantheon_and_sh0es.py:65-67)
-          const double DM = hermite_tab(T, zc);
-          const double mu_corr = d.has_vstep ? 5.0 * log10_pos(DMc / DM) : 0.0;
-          res = d.obs[i] - off - mu_corr - fixed;
-          if (dm_out) dm_out[w * d.n_sn + i] = DM;
-          if (mucorr_out) mucorr_out[w * d.n_sn + i] = mu_corr;
-        } else if (!parts) {
-          res = d.obs[i] - off - (25.0 + 5 * log10_pos((1.0 + d.z_hel[i]) * DMc));
-        } else {
-          const double DM = hermite_tab(T, zc);
-          const double mu_corr = d.has_vstep ? 5.0 * log10(DMc / DM) : 0.0;
-          const double mu_th = 25.0 + 5 * log10((1.0 + d.z_hel[i]) * DM);  // sn/pantheon.py:52-54
-          res = d.obs[i] - off - mu_corr - mu_th;                          // sn/pantheon.py:59-60
-          if (dm_out) dm_out[w * d.n_sn + i] = DM;
-          if (mucorr_out) mucorr_out[w * d.n_sn + i] = mu_corr;
-        }
+        out[i] = res;  // rows >= n_sn are zero padding for the 16-row MFMA tiles
       }
-      out[i] = res;  // rows >= n_sn are zero padding for the 16-row MFMA tiles
     }
   }
   CF_WSTAMP(5);
@@ -1195,6 +1209,17 @@ tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict_
   // B fragments: 16 bytes per lane from the walker's residual row; panel c is 16 rows (8 n_ld d2) further on
   const d2* Bq = reinterpret_cast<const d2*>(delta) + ((w0 + col) * (int64_t)n_ld + 8 * (int64_t)g * nq + 2 * kq) / 2;
   const int64_t bstride = 8 * (int64_t)n_ld;
+#ifdef CF_DEBUG_ALIAS_A  // TIMING EXPERIMENT (wrong results): every factor load hits the same 16 KiB
+#define CF_A_ADV 0
+  A = pk.frags + (g * 16) * 64 + lane;
+#else
+#define CF_A_ADV 1
+#endif
+#ifdef CF_DEBUG_ALIAS_B  // TIMING EXPERIMENT (wrong results): every residual load hits the first K-steps of the panel
+#define CF_B_ADV 0
+#else
+#define CF_B_ADV 1
+#endif
   d4 acc[NP][4];
 #pragma unroll
   for (int c = 0; c < NP; ++c)
@@ -1226,8 +1251,8 @@ tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict_
     load_stage(p);  // unconditional (a guard costs hipcc its exact vmcnt bookkeeping); only row block 0 has nq < PF
     __builtin_amdgcn_sched_barrier(0);  // stage 0 must be the oldest load
   }
-  A += PF * 4 * 64;
-  Bq += PF * 4;
+  A += CF_A_ADV * PF * 4 * 64;
+  Bq += CF_B_ADV * PF * 4;
   const int n_groups = nq / PF, rem = nq - n_groups * PF;
   CF_GSTAMP(1);
   for (int grp = 0; grp + 1 < n_groups; ++grp) {  // branch-free body: a guard around the MFMAs makes hipcc drain vmcnt(0) per stage
@@ -1238,8 +1263,8 @@ tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict_
       load_stage(p);
       __builtin_amdgcn_sched_barrier(0);
     }
-    A += PF * 4 * 64;
-    Bq += PF * 4;
+    A += CF_A_ADV * PF * 4 * 64;
+    Bq += CF_B_ADV * PF * 4;
   }
   if (n_groups > 0) {  // last full group: only the nq % PF pairs of the tail are still to be fetched
 #pragma unroll
@@ -1268,20 +1293,30 @@ tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict_
     if (lane < 16) chi_tile[g][c * 16 + lane] = v;
   }
   lds_barrier();
-  // Hand-off between workgroups on different XCDs (their L2s are not coherent).  Producer: wave 0 stores the
-  // workgroup's shares with agent-scope (write-through, sc1) stores, drains them (inline asm: also a compiler
-  // barrier), and lane 0 bumps the panel's arrival counter with an agent-scope RELEASE add.  Consumer: the workgroup
-  // whose add returned n_rowblocks - 1 came last; behind the workgroup barrier and an agent-scope ACQUIRE fence it
-  // reads every share back with agent-scope loads and adds the row blocks in a fixed order -- the result does not
-  // depend on which workgroup it was -- and re-arms the counter for the next launch.
+  // Hand-off between workgroups on different XCDs (their L2s are not coherent), in the form MI355X_MICROARCH.md lists as
+  // valid for gfx950 (Workgroup dispatch, XCD placement & inter-workgroup visibility: "Valid forms", first table row):
+  // producer -- wave 0 stores the workgroup's shares with agent-scope (sc1, write-through) stores, drains them with
+  // s_waitcnt vmcnt(0) (inline asm with a memory clobber: the compiler may not move the stores or the add across it),
+  // then ONE lane bumps the panel's arrival counter with an agent-scope atomic add.  Consumer -- the workgroup whose
+  // add returned n_rowblocks - 1 came last: behind the workgroup barrier its lanes issue an agent-scope ACQUIRE fence
+  // and read every share back with agent-scope (sc1) loads, add the row blocks in a fixed order (the result does not
+  // depend on which workgroup it was) and re-arm the counter for the next launch.
+  // The add is RELAXED unless CF_HANDOFF_RELEASE is defined: an agent-scope release lowers to buffer_wbl2 (write back
+  // this XCD's L2) + vmcnt(0) in EVERY workgroup; with write-through stores there is nothing for it to write back, and
+  // 3456 of them per launch were measured to cost 15 % of the kernel (profiles/r02_handoff_ab.txt).
+#ifdef CF_HANDOFF_RELEASE
+#define CF_ARRIVE_ORDER __ATOMIC_RELEASE
+#else
+#define CF_ARRIVE_ORDER __ATOMIC_RELAXED
+#endif
   if (g == 0) {
     if (lane < 16 * NP)
       __hip_atomic_store(&partial[(int64_t)rb * w_pad + w0 + lane],
                          ((chi_tile[0][lane] + chi_tile[1][lane]) + chi_tile[2][lane]) + chi_tile[3][lane], __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of every lane of this wave have left the CU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of every lane of this wave have reached memory
     if (lane == 0)
-      arrived_before = __hip_atomic_fetch_add(&arrivals[px], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      arrived_before = __hip_atomic_fetch_add(&arrivals[px], 1u, CF_ARRIVE_ORDER, __HIP_MEMORY_SCOPE_AGENT);
   }
   CF_GSTAMP(3);
   lds_barrier();

@@ -52,12 +52,15 @@ class LikelihoodEngine:
                  bao: Optional[dict] = None, cmb: Optional[dict] = None, physical: Optional[dict] = None,
                  cc: Optional[dict] = None, solve_mode: int = L.CF_SOLVE_AUTO,
                  bounds=None, gauss: Sequence = (), chi2_gauss: Sequence = (), cpl_wall: bool = False,
-                 device: int = 0, devices=None, probe_limit: float = 0.0, c_km_s: float = C_KM_S):
+                 device: int = 0, devices=None, probe_limit: float = 0.0, om_mode: int = 0, c_km_s: float = C_KM_S):
         """
         params: {"H0": Param(1), "Om": Param(2), ...} for the slots of include/cosmofit.h (cf_param_slot).
-        sn: dict(z_cmb, z_hel, obs, chol[, step | z_turn, fixed_mu]) — chol is cho_factor(cov, lower=True)[0];
-            the strict upper triangle is never read; fixed_mu[i] (NaN = none) replaces mu_theory for SN i
-            (SH0ES Cepheid hosts, sn/pantheon_and_sh0es.py:63-69).
+        sn: dict(z_cmb, z_hel, obs, chol[, step | z_turn, fixed_mu, lin_coef, dirs]) — chol is
+            cho_factor(cov, lower=True)[0]; the strict upper triangle is never read; fixed_mu[i] (NaN = none) replaces
+            mu_theory for SN i (SH0ES Cepheid hosts, sn/pantheon_and_sh0es.py:63-69); lin_coef[i] multiplies the "lin"
+            slot and is added to the offset (bulk-flow magnitude term, bao/desi_cmb_pantheon_H0trgb.py:102-106); dirs
+            [N, 3] unit vectors make the peculiar velocity n . (v, v2, v3) x step (sn/pantheon_dipole_xyz.py:50-60).
+        om_mode: 1 = the "Om" slot holds omega_m = Omega_m h^2 (bao/desi_omh2.py:18-20).
         cc: dict(z, h, inv_cov, logdet) — cosmic chronometers with the rescale parameter slot "fcc"
             (bao/desi_union3_cc_theta_star.py:129-139).
         bao: dict(z, val, qty (0 DV/rd, 1 DM/rd, 2 DH/rd, 3 F_AP), inv_cov[, dh_exact=False, rd_fit=None]);
@@ -82,6 +85,7 @@ class LikelihoodEngine:
         d.z_max, d.c_km_s = float(z_max), float(c_km_s)
         d.solve_mode = int(solve_mode)
         d.probe_limit = float(probe_limit)
+        d.om_mode = int(om_mode)
         dev_arr = None
         if devices is not None:
             if isinstance(devices, str):
@@ -117,6 +121,18 @@ class LikelihoodEngine:
                     raise ValueError("sn['fixed_mu'] must have one entry per SN (NaN where unused)")
                 keep.append(fm)
                 d.sn_fixed_mu = _ptr(fm)
+            if sn.get("lin_coef") is not None:
+                lc = _f64(sn["lin_coef"])
+                if lc.size != z_cmb.size:
+                    raise ValueError("sn['lin_coef'] must have one entry per SN")
+                keep.append(lc)
+                d.sn_lin_coef = _ptr(lc)
+            if sn.get("dirs") is not None:
+                dirs = _f64(sn["dirs"])
+                if dirs.shape != (z_cmb.size, 3):
+                    raise ValueError("sn['dirs'] must be (N, 3)")
+                keep.append(dirs)
+                d.sn_dir = _ptr(dirs)
         self.n_bao = 0
         if physical is not None:
             d.or_h2, d.omnu_h2, d.o_gamma_h2 = physical["or_h2"], physical["omnu_h2"], physical["o_gamma_h2"]

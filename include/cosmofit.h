@@ -80,7 +80,13 @@ enum cf_param_slot {
   CF_P_V = 7,      /* peculiar-velocity step amplitude in units of 100 km/s (mu_corr) */
   CF_P_RD = 8,     /* sound horizon in Mpc when fixed or free (BAO block) */
   CF_P_FCC = 9,    /* error-rescale factor of the cosmic-chronometer block (default: fixed 1) */
-  CF_P_NSLOTS = 10
+  CF_P_LIN = 10,   /* amplitude of the per-SN linear magnitude term sn_lin_coef[i] (bulk-flow correction of M,
+                      bao/desi_cmb_pantheon_H0trgb.py:102-106) */
+  CF_P_V2 = 11,    /* second and third velocity components (x 100 km/s) of a direction-dependent peculiar velocity: */
+  CF_P_V3 = 12,    /*   v_los,i = n_i . (V, V2, V3)                     sn/pantheon_dipole_xyz.py:50-60 */
+  CF_P_S8 = 13,    /* sigma_8(z = 0) of the growth-rate block          fs8/fs8.py:84-98 */
+  CF_P_FS8ERR = 14,/* error-rescale factor f_err of the growth-rate block (default: fixed 1)  fs8/fs8.py:116-125 */
+  CF_P_NSLOTS = 15
 };
 
 typedef struct cf_param {
@@ -236,6 +242,17 @@ typedef struct cf_desc {
   int32_t n_devices;
   int32_t _pad5;
   const int32_t* devices;
+
+  /* ---- parameterisation variants of the scripts ("Physics variants") ---- */
+  int32_t om_mode;          /* 0: Omega_m = slot CF_P_OM; 1: slot CF_P_OM is omega_m = Omega_m h^2 and
+                               Omega_m = omega_m / (H0/100)^2          bao/desi_omh2.py:18-20 */
+  int32_t _pad6;
+  const double* sn_lin_coef;/* [n_sn] or NULL: the SN offset becomes offset + theta_LIN * sn_lin_coef[i]; with
+                               sn_lin_coef[i] = 100 (5/ln 10) / (c z_cmb,i) this is the linearised bulk-flow magnitude
+                               term                                    bao/desi_cmb_pantheon_H0trgb.py:102-106 */
+  const double* sn_dir;     /* [n_sn*3] or NULL: unit vectors n_i; then the peculiar velocity of SN i is
+                               100 * (n_i . (V, V2, V3)) * sn_step[i] km/s (sn_step = attenuation x survey mask)
+                                                                       sn/pantheon_dipole_xyz.py:50-60 */
 } cf_desc;
 
 typedef struct cf_info {

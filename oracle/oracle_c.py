@@ -83,6 +83,10 @@ class COracle:
     """Built from an ``oracle_np.Likelihood`` so both oracles share one description of a case."""
 
     def __init__(self, lk):
+        if getattr(lk, "lin_coef", None) is not None or getattr(lk, "dirs", None) is not None or getattr(lk, "om_mode", 0):
+            raise NotImplementedError("the C oracle restates the BASELINE configs; the parameterisation variants "
+                                      "(linear magnitude term, direction-dependent velocity, omega_m slot) are checked "
+                                      "against oracle_np and the golden fixtures")
         self.lk = lk
         self._keep = dict(
             z_cmb=_f64(lk.z_cmb), z_hel=_f64(lk.z_hel), obs=_f64(lk.obs), step=_f64(lk.step),

@@ -155,6 +155,10 @@ class Likelihood:
     v: Slot = field(default_factory=Slot)
     rd: Slot = field(default_factory=Slot)
     fcc: Slot = field(default_factory=lambda: Slot(fixed=1.0))
+    lin: Slot = field(default_factory=Slot)  # amplitude of the per-SN linear magnitude term (bulk-flow correction)
+    v2: Slot = field(default_factory=Slot)   # second / third velocity component of a direction-dependent peculiar velocity
+    v3: Slot = field(default_factory=Slot)
+    om_mode: int = 0  # 1: slot Om holds omega_m = Omega_m h^2 (bao/desi_omh2.py:18-20)
     # SN block
     z_cmb: Optional[np.ndarray] = None
     z_hel: Optional[np.ndarray] = None
@@ -164,6 +168,8 @@ class Likelihood:
     chol: Optional[np.ndarray] = None
     has_vstep: bool = True  # False: no peculiar-velocity step at all (z_cosmo = z_cmb, mu_corr = 0)
     fixed_mu: Optional[np.ndarray] = None  # per SN: NaN -> mu_theory, else this distance modulus (SH0ES calibrators)
+    lin_coef: Optional[np.ndarray] = None  # per SN: offset_i = offset + lin * lin_coef[i] (bao/desi_cmb_pantheon_H0trgb.py:102-106)
+    dirs: Optional[np.ndarray] = None  # [N, 3] unit vectors: v_los = n . (v, v2, v3), weight = step (sn/pantheon_dipole_xyz.py:50-60)
     # cosmic-chronometer block: H(z) data with explicit inverse covariance and error-rescale parameter f_cc
     cc_z: Optional[np.ndarray] = None
     cc_h: Optional[np.ndarray] = None
@@ -243,6 +249,9 @@ def H_z(lk: Likelihood, z, theta):
     cubed = zp1 * zp1 * zp1
     if lk.ez_model == EZ_LATE_FLAT:
         Om = lk.Om.get(theta)
+        if lk.om_mode:  # bao/desi_omh2.py:18-20: h, Omh2 = params[1] / 100, params[2]; Om = Omh2 / h**2
+            h = H0 / 100
+            Om = Om / (h * h)
         if lk.fde == FDE_LCDM:
             return H0 * np.sqrt(Om * cubed + (1.0 - Om))
         return H0 * np.sqrt(Om * cubed + (1.0 - Om) * f_de(lk, z, theta))
@@ -356,7 +365,11 @@ def sn_parts(lk: Likelihood, theta, tables=None):
     cum_dm, dh_grid = tables if tables is not None else dm_grid(lk, theta)
     DM = interp_hermite(lk.z_cmb, lk.z_grid, cum_dm, dh_grid)
     if lk.has_vstep:
-        v_km_s = 100 * lk.v.get(theta) * lk.step
+        if lk.dirs is not None:  # sn/pantheon_dipole_xyz.py:54-57; step = attenuation * survey_mask
+            v_los = lk.dirs[:, 0] * lk.v.get(theta) + lk.dirs[:, 1] * lk.v2.get(theta) + lk.dirs[:, 2] * lk.v3.get(theta)
+            v_km_s = 100 * v_los * lk.step
+        else:
+            v_km_s = 100 * lk.v.get(theta) * lk.step
         z_pec = v_km_s / lk.c
         z_cosmo = -1.0 + (1.0 + lk.z_cmb) / (1.0 + z_pec)
         mu_corr = 5.0 * np.log10(interp_hermite(z_cosmo, lk.z_grid, cum_dm, dh_grid) / DM)
@@ -365,7 +378,10 @@ def sn_parts(lk: Likelihood, theta, tables=None):
     mu_theory = 25.0 + 5 * np.log10((1.0 + lk.z_hel) * DM)
     if lk.fixed_mu is not None:  # sn/pantheon_and_sh0es.py:65
         mu_theory = np.where(np.isnan(lk.fixed_mu), mu_theory, lk.fixed_mu)
-    delta = lk.obs - lk.offset.get(theta) - mu_corr - mu_theory
+    offset = lk.offset.get(theta)
+    if lk.lin_coef is not None:  # M = params[0] + v_flow_corr, bao/desi_cmb_pantheon_H0trgb.py:104-105
+        offset = offset + lk.lin.get(theta) * lk.lin_coef
+    delta = lk.obs - offset - mu_corr - mu_theory
     return DM, mu_corr, mu_theory, delta
 
 

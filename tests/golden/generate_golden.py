@@ -484,7 +484,7 @@ def case_sn_pantheon_dipole():
     sel = df["zHD"].to_numpy(np.float64) > 0.01
     col = lambda name, dt=np.float64: df[name].to_numpy(dtype=dt)[sel]
     z, zh, mb, sig = col("zHD"), col("zHEL"), col("m_b_corr"), col("m_b_corr_err_DIAG")
-    cov = synthetic_cov(sig) if cov_fn is None else cov_fn(z, sig)
+    cov = synthetic_cov(sig)
     pkg = types.ModuleType("y2022pantheonSHOES"); pkg.__path__ = []
     mod = types.ModuleType("y2022pantheonSHOES.data")
     mod.get_data_with_position = lambda: ("Pantheon+ (synthetic cov)", z, zh, mb, col("RA"), col("DEC"), col("IDSURVEY", np.int32), cov)
@@ -512,7 +512,7 @@ def case_sn_pantheon_and_sh0es():
     rng_sel = np.where(((zall >= 0.0) & (df["IS_CALIBRATOR"] == 1)) | (zall > 0.01))[0]  # data_shoes.py:30-31
     col = lambda name: df[name].to_numpy(np.float64)[rng_sel]
     z, zh, mb, ceph, sig = col("zHD"), col("zHEL"), col("m_b_corr"), col("CEPH_DIST"), col("m_b_corr_err_DIAG")
-    cov = synthetic_cov(sig) if cov_fn is None else cov_fn(z, sig)
+    cov = synthetic_cov(sig)
     pkg = types.ModuleType("y2022pantheonSHOES"); pkg.__path__ = []
     mod = types.ModuleType("y2022pantheonSHOES.data_shoes")
     mod.get_data = lambda z_cut_ceph=0.0: ("Pantheon+ and SH0ES (synthetic cov)", z, zh, mb, ceph, cov)
@@ -567,6 +567,130 @@ def case_bao_desi_union3_cc_theta_star():
     print("bao_desi_union3_cc_theta_star.npz chi2[-1] =", out["chi2"][-1], "logl[-1] =", out["logl"][-1])
 
 
+def case_bao_desi_omh2():
+    """bao/desi_omh2.py: BAO only, theta = (rd, H0, omega_m, w0): free r_d, Omega_m = omega_m / h^2 (:18-20), thawing
+    dark energy, D_H = c / H exactly.  All data real (no missing blob)."""
+    _enter_reference()
+    import bao.desi_omh2 as m
+
+    rng = np.random.default_rng(31)
+    box = [(120.0, 160.0), (50.0, 85.0), (0.138, 0.148), (-1.0, -1 / 3)]  # nautilus prior of main() (:86-89; omega_m ~ N(0.1430, 0.0011))
+    thetas = np.vstack([_uniform(box, 18, rng), [[147.1, 67.5, 0.1430, -0.8]]])
+    out = _bao_inputs(m.bao_data, m.bao_cov_matrix, m.quantities, m.inv_cov_mat)
+    out.update(thetas=thetas, z_max=np.float64(m.z_grid[-1]), c=np.float64(m.c),
+               chi2=np.array([m.chi_squared(t) for t in thetas]), logl=np.array([m.log_likelihood(t) for t in thetas]),
+               theory=np.array([m.bao_theory(m.bao_data["z"], m.quantities, t) for t in thetas[:4]]))
+    np.savez_compressed(os.path.join(HERE, "bao_desi_omh2.npz"), **out)
+    print("bao_desi_omh2.npz chi2[-3:] =", out["chi2"][-3:])
+
+
+def case_bao_desi_des5y_rd():
+    """bao/desi_des5y_rd.py: DES-Dovekie SNe (step at z = 0.10563) + DESI DR2 BAO with PCHIP D_H, theta = (dM, rd, H0, Om, v):
+    r_d is a free parameter (Planck prior applied by nautilus, not by the likelihood), flat LCDM."""
+    _enter_reference()
+    z, zh, mu, sig = _inject_dovekie()
+    import bao.desi_des5y_rd as m
+
+    rng = np.random.default_rng(32)
+    box = [(-0.4, 0.4), (146.0, 148.2), (50.0, 85.0), (0.1, 0.6), (-4.5, 4.5)]  # main() (:113-117; rd ~ N(147.09, 0.26))
+    thetas = np.vstack([_uniform(box, 14, rng), [[0.0, 147.09, 68.0, 0.31, 0.0]]])
+    out = _bao_inputs(m.bao, m.bao_cov_matrix, m.bao_qty, m.inv_cov_bao)
+    out.update(z_cmb=z, z_hel=zh, obs=mu, sigma=sig, thetas=thetas, z_max=np.float64(m.z_grid[-1]),
+               chi2=np.array([m.chi_squared(t) for t in thetas]), logl=np.array([m.log_likelihood(t) for t in thetas]),
+               theory=np.array([m.bao_theory(m.bao["z"], m.bao_qty, t, m.DM_grid(t)) for t in thetas[:4]]))
+    np.savez_compressed(os.path.join(HERE, "bao_desi_des5y_rd.npz"), **out)
+    print("bao_desi_des5y_rd.npz chi2[-3:] =", out["chi2"][-3:])
+
+
+def case_bao_desi_cmb_pantheon_h0trgb():
+    """bao/desi_cmb_pantheon_H0trgb.py: Pantheon+ with the linearised bulk-flow magnitude term M_i = M + 100 v (5 / ln 10) /
+    (c z_i) (:102-106, no velocity step), DESI DR2 BAO (exact D_H, r_drag fit), Planck+ACT CMB, TRGB H0 chi^2 term."""
+    _enter_reference()
+    z, zh, mb, sig = _inject_pantheon()
+    import bao.desi_cmb_pantheon_H0trgb as m
+
+    cmb = m.cmb
+    rng = np.random.default_rng(33)
+    box = [(-20.0, -19.0), (60.0, 75.0), (0.019, 0.025), (0.01, 0.25), (-1.2, 3.2)]  # main() (:153-157)
+    thetas = np.vstack([_uniform(box, 14, rng), [[-19.35, 68.5, 0.0224, 0.118, 0.0], [-19.4, 70.0, 0.0225, 0.119, 1.5]]])
+    out = _bao_inputs(m.bao_data, m.bao_cov_matrix, m.quantities, m.inv_cov_bao)
+    out.update(_cmb_consts(cmb))
+    out.update(z_cmb=z, z_hel=zh, obs=mb, sigma=sig, thetas=thetas, z_max=np.float64(m.z_grid[-1]),
+               chi2=np.array([m.chi_squared(t) for t in thetas]), logl=np.array([m.log_likelihood(t) for t in thetas]),
+               mag_0=m.apparent_mag(thetas[0]), mag_last=m.apparent_mag(thetas[-1]))
+    np.savez_compressed(os.path.join(HERE, "bao_desi_cmb_pantheon_H0trgb.npz"), **out)
+    print("bao_desi_cmb_pantheon_H0trgb.npz chi2[-3:] =", out["chi2"][-3:])
+
+
+def case_sn_pantheon_dipole_xyz():
+    """sn/pantheon_dipole_xyz.py: bulk-flow velocity vector (vx, vy, vz): v_los = n . v, tanh attenuation, survey mask
+    (:50-60); theta = (M, H0, Om, vx, vy, vz), log L only (nautilus)."""
+    _enter_reference()
+    import pandas as pd
+
+    df = pd.read_csv(os.path.join(REF, "y2022pantheonSHOES/raw-data/distances.txt"), sep=" ")
+    sel = df["zHD"].to_numpy(np.float64) > 0.01
+    col = lambda name, dt=np.float64: df[name].to_numpy(dtype=dt)[sel]
+    z, zh, mb, sig = col("zHD"), col("zHEL"), col("m_b_corr"), col("m_b_corr_err_DIAG")
+    cov = synthetic_cov(sig)
+    pkg = types.ModuleType("y2022pantheonSHOES"); pkg.__path__ = []
+    mod = types.ModuleType("y2022pantheonSHOES.data")
+    mod.get_data_with_position = lambda: ("Pantheon+ (synthetic cov)", z, zh, mb, col("RA"), col("DEC"), col("IDSURVEY", np.int32), cov)
+    sys.modules["y2022pantheonSHOES"] = pkg
+    sys.modules["y2022pantheonSHOES.data"] = mod
+    import sn.pantheon_dipole_xyz as m
+
+    rng = np.random.default_rng(34)
+    box = [(-20.0, -19.0), (62.0, 78.0), (0.1, 0.7), (-4.0, 1.0), (-4.0, 1.0), (-4.0, 2.0)]  # main() (:78-85)
+    thetas = np.vstack([_uniform(box, 15, rng), [[-19.35, 70.4, 0.33, 0.0, 0.0, 0.0]]])
+    att = 0.5 * (1.0 - np.tanh((m.z_cmb - 0.10) / 0.02))
+    DM0 = m.DM_z(thetas[0], m.z_cmb)
+    out = dict(z_cmb=z, z_hel=zh, obs=mb, sigma=sig, dirs=np.stack([m.nx, m.ny, m.nz], axis=1), weights=att * m.survey_mask,
+               thetas=thetas, z_max=np.float64(m.z_grid[-1]), chi2=np.array([m.chi_squared(t) for t in thetas]),
+               logl=np.array([m.log_likelihood(t) for t in thetas]), mucorr_0=m.mu_corr(thetas[0], DM0))
+    np.savez_compressed(os.path.join(HERE, "sn_pantheon_dipole_xyz.npz"), **out)
+    print("sn_pantheon_dipole_xyz.npz chi2[:3] =", out["chi2"][:3], "nonzero weights:", int(np.count_nonzero(out["weights"])))
+
+
+def case_bao_desi_cmb_des5y_cpl():
+    """BASELINE configs[2] AS WORDED (w0waCDM): bao/desi_cmb_des5y.py with the dark-energy line the author keeps commented
+    (:26-31, the CPL form) made active.  The module's own functions are used for everything; only its ``H_z`` attribute
+    is replaced (and re-registered with ``cmb.set_HZ``) by the same expansion rate with the script's own Ode multiplied
+    by the CPL density ratio -- exactly what un-commenting line 31 and threading (w0, wa) through Ez does, as
+    bao/desi_fs_lya_cmb.py:19-49 does for its own Ez.  theta = (dM, H0, wb, wc, v, w0, wa)."""
+    _enter_reference()
+    z, zh, mu, sig = _inject_dovekie()
+    import bao.desi_cmb_des5y as m
+
+    cmb = m.cmb
+
+    def H_z_cpl(zz, params):
+        H0, Obh2, Och2, w0, wa = params[1], params[2], params[3], params[5], params[6]
+        h = H0 / 100
+        Onu = m.Omnuh2 / h**2
+        Or = m.Orh2 / h**2
+        Obc = (Obh2 + Och2) / h**2
+        Ode = 1.0 - Obc - Or - Onu
+        zp1 = 1.0 + zz
+        f_de = zp1 ** (3 * (1 + w0 + wa)) * np.exp(-3 * wa * zz / zp1)  # the commented line, :31
+        return H0 * np.sqrt(Or * zp1**4 + Obc * zp1**3 + Ode * f_de + Onu * cmb.Omnu_z(zz))
+
+    m.H_z = H_z_cpl
+    cmb.set_HZ(H_z_cpl)
+    rng = np.random.default_rng(35)
+    box = [(-0.5, 0.5), (60.0, 75.0), (0.010, 0.030), (0.01, 0.25), (-4.5, 4.5), (-3.0, 1.0), (-3.0, 2.0)]
+    thetas = _uniform(box, 40, rng)
+    thetas = thetas[thetas[:, 5] + thetas[:, 6] < -0.05][:16]  # matter domination at early times (w0 + wa < 0)
+    thetas = np.vstack([thetas, [[0.0, 67.5, 0.0224, 0.119, 0.0, -1.0, 0.0], [0.03, 66.0, 0.0224, 0.119, -1.2, -0.75, -0.8]]])
+    parts = np.array([[m.chi2_sn(t, m.DM_grid(t)), m.chi2_bao(t, m.DM_grid(t)), m.chi2_cmb(t)] for t in thetas])
+    out = dict(thetas=thetas, z_max=np.float64(m.z_grid[-1]), chi2=np.array([m.chi_squared(t) for t in thetas]),
+               logl=np.array([m.log_likelihood(t) for t in thetas]), chi2_parts=parts,
+               theory=np.array([m.bao_theory(m.bao["z"], m.bao_qty, t, m.DM_grid(t)) for t in thetas[:4]]),
+               cmb_dist=np.array([cmb.cmb_distances(t[2], t[3], t) for t in thetas[:4]]))
+    np.savez_compressed(os.path.join(HERE, "bao_desi_cmb_des5y_cpl.npz"), **out)
+    print("bao_desi_cmb_des5y_cpl.npz chi2[-2:] =", out["chi2"][-2:], "(LCDM row must equal the as-shipped fixture's)")
+
+
 CASES = {
     "interpolator": case_interpolator,
     "sn_pantheon": case_sn_pantheon,
@@ -586,6 +710,11 @@ CASES = {
     "sn_pantheon_and_sh0es": case_sn_pantheon_and_sh0es,
     "ohd_cc_des5y": case_ohd_cc_des5y,
     "bao_desi_union3_cc_theta_star": case_bao_desi_union3_cc_theta_star,
+    "bao_desi_omh2": case_bao_desi_omh2,
+    "bao_desi_des5y_rd": case_bao_desi_des5y_rd,
+    "bao_desi_cmb_pantheon_H0trgb": case_bao_desi_cmb_pantheon_h0trgb,
+    "sn_pantheon_dipole_xyz": case_sn_pantheon_dipole_xyz,
+    "bao_desi_cmb_des5y_cpl": case_bao_desi_cmb_des5y_cpl,
 }
 
 if __name__ == "__main__":
