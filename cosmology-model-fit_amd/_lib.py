@@ -102,6 +102,7 @@ EXPORTS = {
     "cf_split_rows": (None, [_I64, _I32, _I32, C.POINTER(_I64), C.POINTER(_I64)]),
     "cf_eval_device": (C.c_int, [_VP, _VP, _I64, _VP, _I32, _VP]),
     "cf_eval_parts": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP]),
+    "cf_eval_table": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
     "cf_last_kernel_ms": (C.c_int, [_VP, C.POINTER(C.c_float * 2)]),
     "cf_enable_timing": (C.c_int, [_VP, C.c_int]),
     "cf_timed_calls": (C.c_int64, [_VP]),

@@ -29,18 +29,18 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define CF_BAO_NODES 6  // table nodes copied out per BAO datum (cosmofit_kernels.hip)
 template <int MODEL, int FDE>
 __global__ void walker_kernel(cf_dev_desc d, const double* theta, int64_t W, double* delta, double* dm_out, double* mucorr_out,
-                              d2* bao_nodes);
+                              d2* bao_nodes, d2* table_out);
 template <int MODEL, int FDE>
 __global__ void small_blocks_kernel(cf_dev_desc d, const double* theta, int64_t W, const d2* bao_nodes, double* chi2_extra,
                                     double* blocks_out, double* bao_out);
 #define CF_DECLARE_WALKER(M, F)                                                                                            \
-  extern template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*); \
+  extern template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*, d2*); \
   extern template __global__ void small_blocks_kernel<M, F>(cf_dev_desc, const double*, int64_t, const d2*, double*,       \
                                                             double*, double*);
 CF_DECLARE_WALKER(0, 0) CF_DECLARE_WALKER(0, 1) CF_DECLARE_WALKER(0, 2) CF_DECLARE_WALKER(0, 3)
 CF_DECLARE_WALKER(1, 0) CF_DECLARE_WALKER(1, 1) CF_DECLARE_WALKER(1, 2) CF_DECLARE_WALKER(1, 3)
 
-typedef void (*walker_fn)(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*);
+typedef void (*walker_fn)(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*, d2*);
 static walker_fn pick_walker(int model, int fde) {
   static const walker_fn table[2][4] = {
       {walker_kernel<0, 0>, walker_kernel<0, 1>, walker_kernel<0, 2>, walker_kernel<0, 3>},
@@ -911,7 +911,7 @@ static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_
     // skewed {cum, dh} table: one spare 16-byte slot per 2^chunk_shift nodes
     const size_t lds = ((size_t)d.n_grid + (d.n_grid >> d.chunk_shift) + 2) * 16;
     hipLaunchKernelGGL(pick_walker(d.ez_model, d.fde), dim3((unsigned)Wc), dim3(512), lds, st, d, th, Wc, delta, dm_out, mucorr_out,
-                       bao_nodes);
+                       bao_nodes, (d2*)nullptr);
     if (h->has_small_blocks)  // sixteen lanes per walker, sixteen walkers per workgroup
       hipLaunchKernelGGL(pick_small_blocks(d.ez_model, d.fde), dim3((unsigned)((Wc + 15) / 16)), dim3(256), 0, st, d, th, Wc,
                          (const d2*)bao_nodes, extra, blocks_out, bao_out);
@@ -1117,6 +1117,38 @@ extern "C" int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, doubl
       chi2_blocks[7 * w + 5] = b6[6 * w + 4];
       chi2_blocks[7 * w + 6] = b6[6 * w + 5];
     }
+  }
+  return CF_OK;
+}
+
+// The distance table of W walkers: cum_dm[W*G] and dh[W*G] on the reference's grid linspace(0, z_max, G)  -- what
+// DM_z(params, z) of the scripts interpolates (sn/pantheon.py:34-40).  Only the table build of walker_kernel runs.
+extern "C" int cf_eval_table(cf_handle* h, const double* theta, int64_t W, double* cum_dm, double* dh) {
+  if (!h || !theta || !cum_dm || !dh) return fail(CF_ERR_INVALID, "cf_eval_table: null argument");
+  if (W <= 0 || W > 4096) return fail(CF_ERR_INVALID, "cf_eval_table: W must be in 1..4096");
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIP_TRY(hipSetDevice(h->device));
+  int rc;
+  if ((rc = ensure_workspace(h, W))) return rc;
+  if (h->has_last && h->last_stream != h->stream) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_last, 0));
+  cf_dev_desc d = h->d;  // a copy without the SN / BAO consumers of the table: only the build runs
+  const int G = d.n_grid;
+  d.n_sn = 0;
+  d.n_bao = 0;
+  d.n_ld = 0;
+  DevBuf tab;
+  if (tab.ensure((size_t)W * G * sizeof(d2))) return CF_ERR_HIP;
+  HIP_TRY(hipMemcpyAsync(h->theta.p, theta, (size_t)W * d.ndim * 8, hipMemcpyHostToDevice, h->stream));
+  const size_t lds = ((size_t)G + (G >> d.chunk_shift) + 2) * 16;
+  hipLaunchKernelGGL(pick_walker(d.ez_model, d.fde), dim3((unsigned)W), dim3(512), lds, h->stream, d, h->theta.as<const double>(), W,
+                     (double*)nullptr, (double*)nullptr, (double*)nullptr, (d2*)nullptr, tab.as<d2>());
+  HIP_TRY(hipGetLastError());
+  std::vector<cf_d2> host((size_t)W * G);
+  HIP_TRY(hipMemcpyAsync(host.data(), tab.p, host.size() * sizeof(cf_d2), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (size_t i = 0; i < host.size(); ++i) {
+    cum_dm[i] = host[i].x;
+    dh[i] = host[i].y;
   }
   return CF_OK;
 }

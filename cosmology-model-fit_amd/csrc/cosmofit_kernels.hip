@@ -615,7 +615,7 @@ __device__ __forceinline__ void sn_fast_loop(const cf_dev_desc& d, const DistTab
 template <int MODEL, int FDE>
 __global__ void __launch_bounds__(CF_TPB_A, 4)
 walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double* __restrict__ delta,
-              double* __restrict__ dm_out, double* __restrict__ mucorr_out, d2* __restrict__ bao_nodes) {
+              double* __restrict__ dm_out, double* __restrict__ mucorr_out, d2* __restrict__ bao_nodes, d2* __restrict__ table_out) {
   extern __shared__ __align__(16) d2 lds_tab[];
   __shared__ __align__(16) d4 wave_pub[CF_TPB_A / 64];  // per-wave {interval sum, first dh, last dh} of the table build
   __shared__ __align__(16) d2 log_tab[64];  // log10_tab's reduction table; the table build's barriers order the fill
@@ -646,8 +646,10 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
   T.z_max = d.z_max;
 
   CF_WSTAMP(1);
-  if (d.n_sn > 0 || d.n_bao > 0) build_distance_table<MODEL, FDE>(d, wc, lds_tab, wave_pub, nu_pre);
+  if (d.n_sn > 0 || d.n_bao > 0 || table_out) build_distance_table<MODEL, FDE>(d, wc, lds_tab, wave_pub, nu_pre);
   CF_WSTAMP(4);
+  if (table_out)  // accessor path (cf_eval_table): the walker's whole {cum_dm, dh} table, node order
+    for (int g = tid; g < d.n_grid; g += CF_TPB_A) table_out[w * d.n_grid + g] = T.at(g);
   // the table nodes around each BAO redshift go to small_blocks_kernel (the BAO block is evaluated there, one wave
   // per walker); copied by the last threads of the workgroup, whose waves have the lightest share of the SN loop
   if (tid >= CF_TPB_A - CF_BAO_NODES * d.n_bao) {
@@ -875,7 +877,7 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
 }
 
 #define CF_INSTANTIATE_WALKER(M, F)                                                                              \
-  template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*); \
+  template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*, d2*); \
   template __global__ void small_blocks_kernel<M, F>(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, \
                                                      double*);
 CF_INSTANTIATE_WALKER(0, 0) CF_INSTANTIATE_WALKER(0, 1) CF_INSTANTIATE_WALKER(0, 2) CF_INSTANTIATE_WALKER(0, 3)

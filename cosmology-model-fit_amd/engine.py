@@ -178,6 +178,7 @@ class LikelihoodEngine:
         d.n_chi2_gauss, d.chi2_gauss = len(chi2_gauss), C.cast(cg, C.c_void_p)
         d.cpl_wall = int(cpl_wall)
         self.ndim = ndim
+        self.n_grid, self.z_max = int(n_grid), float(z_max)
         self.n_sn = int(d.n_sn)
         self._h = C.c_void_p()
         L.check(lib.cf_create(C.byref(d), C.byref(self._h)))
@@ -258,6 +259,23 @@ class LikelihoodEngine:
         L.check(L.lib().cf_eval_parts(self._h, _ptr(th), W, _ptr(dm), _ptr(mc), _ptr(dl), _ptr(blocks), _ptr(bt)))
         return dict(dm=dm, mu_corr=mc, delta=dl, chi2_blocks=blocks[:, :3], cmb_vector=blocks[:, 3:6], chi2_cc=blocks[:, 6],
                     bao_theory=bt)
+
+    def distance_table(self, theta):
+        """(z_grid [G], cum_dm [W, G], dh_grid [W, G]) of one theta or a small batch: the grid of the scripts
+        (``np.linspace(0, z_max, 4000)``) and the two arrays their ``DM_z`` interpolates (sn/pantheon.py:34-40)."""
+        th = np.atleast_2d(_f64(theta))
+        W, G = th.shape[0], self.n_grid
+        cum, dh = np.empty((W, G)), np.empty((W, G))
+        L.check(L.lib().cf_eval_table(self._h, _ptr(th), W, _ptr(cum), _ptr(dh)))
+        return np.linspace(0, self.z_max, num=G), cum, dh
+
+    def DM_z(self, theta, z):
+        """Comoving distance at arbitrary redshifts: the reference's ``DM_z(params, z)`` (sn/pantheon.py:34-40) -- the
+        walker's table from the GPU, then the stand-alone GPU Hermite operator (interpolator.py:117-119)."""
+        from .interpolator import interp_hermite
+
+        z_grid, cum, dh = self.distance_table(np.asarray(theta, dtype=np.float64).reshape(1, -1))
+        return interp_hermite(np.atleast_1d(_f64(z)), z_grid, cum[0], dh[0])
 
     def enable_timing(self, slots=1):
         """Keep HIP-event timings of the last `slots` evaluations (0 = off)."""

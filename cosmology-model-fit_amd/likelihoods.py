@@ -18,7 +18,7 @@ from scipy.linalg import cho_factor
 
 from . import _lib as L
 from . import cmb_data
-from .engine import LikelihoodEngine, Param, solve_mode_of
+from .engine import C_KM_S, LikelihoodEngine, Param, solve_mode_of
 
 N_GRID = 4000
 QTY_MAP = {"DV_over_rs": 0, "DM_over_rs": 1, "DH_over_rs": 2, "F_AP": 3}  # bao/desi_cmb_des5y.py:69-78
@@ -272,3 +272,89 @@ class DesiUnion3CcThetaStar(_Base):
             cmb=dict(mode=2, prior=comp["cmb_prior"], inv_cov=inv, zstar_fit=comp["zstar_fit"]),
             cc=dict(z=z_cc, h=H_cc, inv_cov=np.linalg.inv(cov_cc), logdet=np.linalg.slogdet(cov_cc)[1]),
             physical=_physical(comp), device=device, devices=devices)
+
+
+class DesiOmh2(_Base):
+    """bao/desi_omh2.py: theta = (rd, H0, omega_m, w0).  BAO only; r_d free; the matter density is sampled as
+    omega_m = Omega_m h^2 (:18-20, Planck prior on it applied by nautilus); thawing dark energy; D_H = c / H exactly.
+    bao/desi_union3_omh2.py / desi_des5y_omh2.py add an SN block: ``DesiSnRd(..., omh2=True)``."""
+
+    def __init__(self, z, val, qty, inv_cov, *, device=0, devices=None, bounds=None):
+        self.bounds = None if bounds is None else np.asarray(bounds, float)
+        self.z_max = float(np.max(z) + 0.1)  # :13
+        self.engine = LikelihoodEngine(
+            ndim=4, z_max=self.z_max, n_grid=N_GRID, fde=L.CF_FDE_THAWING, om_mode=1,
+            params=dict(rd=Param(0), H0=Param(1), Om=Param(2), w0=Param(3)),
+            bao=dict(z=z, val=val, qty=qty, inv_cov=inv_cov, dh_exact=True), bounds=self.bounds, device=device, devices=devices)
+
+
+class DesiSnRd(_Base):
+    """bao/desi_des5y_rd.py: theta = (dM, rd, H0, Om, v).  SN (velocity step at z = 0.10563, :86) + DESI BAO with PCHIP D_H
+    and a FREE sound horizon r_d (its Gaussian prior lives in the sampler, :114); flat LCDM.
+    ``omh2=True``: theta[3] is omega_m = Omega_m h^2 (bao/desi_des5y_omh2.py:31-32); ``z_turn`` 0.15 / 0.2 and the matching
+    data give bao/desi_pantheon_rd.py and bao/desi_union3_rd.py."""
+
+    def __init__(self, z_cmb, z_hel, mu_values, cov_sn, bao_z, bao_val, bao_qty, bao_inv_cov, *, chol=None, z_turn=0.10563,
+                 omh2=False, dh_exact=False, fde="lcdm", device=0, devices=None, solve="auto", bounds=None):
+        if chol is None:
+            chol = cho_factor(cov_sn, lower=True)[0]  # :12
+        self.bounds = None if bounds is None else np.asarray(bounds, float)
+        self.z_max = float(max(np.max(z_cmb), np.max(bao_z)) + 0.1)  # :17
+        params = dict(offset=Param(0), rd=Param(1), H0=Param(2), Om=Param(3), v=Param(4))
+        if fde != "lcdm":
+            params["w0"] = Param(5)
+        self.engine = LikelihoodEngine(
+            ndim=len(params), z_max=self.z_max, n_grid=N_GRID, fde=FDE_BY_NAME[fde], om_mode=int(omh2), params=params,
+            sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=mu_values, chol=chol, z_turn=z_turn),
+            bao=dict(z=bao_z, val=bao_val, qty=bao_qty, inv_cov=bao_inv_cov, dh_exact=dh_exact),
+            bounds=self.bounds, device=device, devices=devices, solve_mode=solve_mode_of(solve))
+
+
+class DesiCmbPantheonH0Trgb(_Base):
+    """bao/desi_cmb_pantheon_H0trgb.py: theta = (M, H0, wb, wc, v_flow).  Pantheon+ magnitudes with the linearised bulk-flow
+    term M_i = M + 100 v_flow (5 / ln 10) / (c z_i) instead of a velocity step (:102-106), DESI BAO (exact D_H, r_drag
+    fit), Planck+ACT (R, l_A, wb) and the TRGB term ((H0 - 70.39) / 1.80)^2 in chi^2 (:123)."""
+    H0_TRGB = (70.39, 1.80)
+
+    def __init__(self, z_cmb, z_hel, mb_values, cov_sn, bao_z, bao_val, bao_qty, bao_inv_cov, *, chol=None, comp=None,
+                 device=0, devices=None, solve="auto"):
+        comp = cmb_data.PLANCK_ACT if comp is None else comp
+        if chol is None:
+            chol = cho_factor(cov_sn, lower=True)[0]  # :16
+        z_cmb = np.asarray(z_cmb, dtype=np.float64)
+        self.z_max = float(max(np.max(z_cmb), np.max(bao_z)) + 0.1)  # :19
+        lin_coef = 100 * (5 / np.log(10)) / (C_KM_S * z_cmb)  # :104
+        self.engine = LikelihoodEngine(
+            ndim=5, z_max=self.z_max, n_grid=N_GRID, ez_model=L.CF_EZ_PHYSICAL, fde=L.CF_FDE_LCDM,
+            params=dict(offset=Param(0), H0=Param(1), obh2=Param(2), och2=Param(3), lin=Param(4)),
+            sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=mb_values, chol=chol, lin_coef=lin_coef),
+            bao=dict(z=bao_z, val=bao_val, qty=bao_qty, inv_cov=bao_inv_cov, dh_exact=True, rd_fit=comp["rd_fit"]),
+            cmb=dict(mode=comp["cmb_mode"], prior=comp["cmb_prior"], inv_cov=comp["cmb_inv_cov"], zstar_fit=comp["zstar_fit"]),
+            physical=_physical(comp), chi2_gauss=[(1, self.H0_TRGB[0], self.H0_TRGB[1])], device=device, devices=devices,
+            solve_mode=solve_mode_of(solve))
+
+
+class PantheonDipoleXyz(_Base):
+    """sn/pantheon_dipole_xyz.py: theta = (M, H0, Om, vx, vy, vz).  Bulk-flow velocity VECTOR in equatorial cartesian
+    coordinates: v_los,i = n_i . v with n_i from (RA, DEC) (:13-17), times the tanh attenuation and the survey mask
+    (:50-57).  ``dirs`` [N, 3] = (nx, ny, nz), ``weights`` [N] = attenuation * survey_mask (see ``dipole_geometry``)."""
+
+    def __init__(self, z_cmb, z_hel, mb_vals, cov_matrix, dirs, weights, *, chol=None, device=0, devices=None, solve="auto",
+                 bounds=None):
+        if chol is None:
+            chol = cho_factor(cov_matrix, lower=True)[0]  # :9
+        self.bounds = None if bounds is None else np.asarray(bounds, float)
+        self.z_max = float(np.max(z_cmb) + 0.1)  # :22
+        self.engine = LikelihoodEngine(
+            ndim=6, z_max=self.z_max, n_grid=N_GRID, fde=L.CF_FDE_LCDM,
+            params=dict(offset=Param(0), H0=Param(1), Om=Param(2), v=Param(3), v2=Param(4), v3=Param(5)),
+            sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=mb_vals, chol=chol, step=weights, dirs=dirs),
+            bounds=self.bounds, device=device, devices=devices, solve_mode=solve_mode_of(solve))
+
+    @staticmethod
+    def dipole_geometry(z_cmb, ra_deg, dec_deg, survey_id, target_ids=(1, 5, 15, 50, 51, 56, 63, 150), z_c=0.10, dz=0.02):
+        """(dirs, weights) from sky positions as sn/pantheon_dipole_xyz.py:12-20,51-53 builds them (host side, once)."""
+        ra, dec = np.deg2rad(ra_deg), np.deg2rad(dec_deg)
+        dirs = np.stack([np.cos(dec) * np.cos(ra), np.cos(dec) * np.sin(ra), np.sin(dec)], axis=1)
+        att = 0.5 * (1.0 - np.tanh((np.asarray(z_cmb) - z_c) / dz))
+        return dirs, att * np.isin(survey_id, list(target_ids)).astype(int)

@@ -13,7 +13,7 @@ import numpy as np
 from scipy.linalg import cho_factor
 
 from . import _lib as L
-from .engine import LikelihoodEngine, Param, solve_mode_of
+from .engine import C_KM_S, LikelihoodEngine, Param, solve_mode_of
 
 # sn/pantheon.py:68-75
 bounds = np.array(
@@ -44,6 +44,8 @@ class PantheonLikelihood:
         self.normalization = -np.sum(np.log(self.bounds[:, 1] - self.bounds[:, 0]))  # sn/pantheon.py:77
         self.z_cmb, self.z_hel, self.mb_vals = z_cmb, np.asarray(z_hel, float), np.asarray(mb_vals, float)
         self.z_max = float(np.max(z_cmb) + 0.1)  # sn/pantheon.py:16
+        self.step = None if step is None else np.asarray(step, dtype=np.float64)
+        self.z_turn = z_turn
         self.engine = LikelihoodEngine(
             ndim=4, z_max=self.z_max, n_grid=N_GRID, fde=fde,
             params=dict(offset=Param(0), H0=Param(1), Om=Param(2), v=Param(3)),
@@ -76,13 +78,28 @@ class PantheonLikelihood:
         idx, mean, sigma = self.h0_prior
         return self.normalization - 0.5 * (p[idx] - mean) ** 2 / sigma**2
 
-    # -- accessors the post-fit plots use (sn/pantheon.py:152-155) -----------------------------
-    def DM_z(self, params):
-        return self.engine.parts(params)["dm"][0]
+    # -- accessors the post-fit plots use, with the reference's own signatures (sn/pantheon.py:34-54,152-155) --------
+    def DM_z(self, params, z=None):
+        """``DM_z(params, z)``: comoving distance at redshifts z (default: the sample's z_cmb), sn/pantheon.py:34-40."""
+        if z is None:
+            return self.engine.parts(params)["dm"][0]
+        return self.engine.DM_z(params, z)
 
-    def mu_corr(self, params):
-        return self.engine.parts(params)["mu_corr"][0]
+    def mu_theory(self, DM):
+        """``mu_theory(DM)``: 25 + 5 log10((1 + z_hel) DM), sn/pantheon.py:52-54.  (A parameter vector instead of a
+        distance array is accepted too: then DM = DM_z(params, z_cmb).)"""
+        DM = np.asarray(DM, dtype=np.float64)
+        if DM.shape != self.z_hel.shape:
+            DM = self.DM_z(DM)
+        return 25.0 + 5 * np.log10((1.0 + self.z_hel) * DM)
 
-    def mu_theory(self, params):
-        dm = self.engine.parts(params)["dm"][0]
-        return 25.0 + 5 * np.log10((1.0 + self.z_hel) * dm)
+    def mu_corr(self, params, DM_obs=None):
+        """``mu_corr(params, DM_obs)``: 5 log10(DM_z(params, z_cosmo) / DM_obs) with the velocity step, sn/pantheon.py:43-49.
+        Without DM_obs the kernel's own accessor path returns it for DM_obs = DM_z(params, z_cmb)."""
+        if DM_obs is None:
+            return self.engine.parts(params)["mu_corr"][0]
+        p = np.asarray(params, dtype=np.float64)
+        step = self.step if self.step is not None else np.where(self.z_cmb <= self.z_turn, 1.0, -1.0)
+        v_km_s = 100 * p[3] * step
+        z_cosmo = -1.0 + (1.0 + self.z_cmb) / (1.0 + v_km_s / C_KM_S)
+        return 5.0 * np.log10(self.engine.DM_z(p, z_cosmo) / np.asarray(DM_obs, dtype=np.float64))

@@ -15,6 +15,7 @@
  *                        emcee pool.map dispatch          sn/pantheon.py:119-125)
  *   cf_eval_parts        DM_z / mu_theory / mu_corr accessors used by the post-fit plots
  *                                                        sn/pantheon.py:34-54,152-155
+ *   cf_eval_table        the (cum_dm, dh_grid) pair inside DM_z / DM_grid  sn/pantheon.py:35-39, bao/desi_cmb_des5y.py:60-66
  *   cf_interp_hermite    interp_hermite                   interpolator.py:117-119
  *   cf_interp_pchip      interp_pchip                     interpolator.py:111-114
  *   cf_solve_triangular  solve_triangular (returns y.y)   solve_triangular.py:5-14
@@ -308,6 +309,12 @@ int cf_eval_device(cf_handle* h, const double* d_theta, int64_t W, double* d_out
  *   bao_theory[W*n_bao]                  bao/desi_cmb_des5y.py:82-100 */
 int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, double* dm_obs, double* mu_corr,
                   double* delta, double* chi2_blocks, double* bao_theory);
+
+/* The distance table of W <= 4096 walkers on the reference's grid z_grid = linspace(0, z_max, G): cum_dm[W*G] (the
+ * cumulative trapezoid of c/H) and dh[W*G] (c/H at the nodes), host buffers -- the pair that DM_z(params, z) of the
+ * scripts hands to interp_hermite (sn/pantheon.py:34-40, bao/desi_cmb_des5y.py:60-66), for the post-fit plots that
+ * evaluate distances at arbitrary redshifts (sn/pantheon.py:152-155). */
+int cf_eval_table(cf_handle* h, const double* theta, int64_t W, double* cum_dm, double* dh);
 
 /* Per-kernel timing with HIP events recorded on the stream the kernels are launched on.
  * cf_enable_timing(h, slots): keep events for the last `slots` evaluation calls (0 = off, the
