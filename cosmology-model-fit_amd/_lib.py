@@ -76,6 +76,9 @@ class cf_desc(C.Structure):
         ("probe_limit", C.c_double),
         ("n_devices", C.c_int32), ("_pad5", C.c_int32), ("devices", C.c_void_p),
         ("om_mode", C.c_int32), ("_pad6", C.c_int32), ("sn_lin_coef", C.c_void_p), ("sn_dir", C.c_void_p),
+        ("n_fs8", C.c_int32), ("fs8_steps", C.c_int32),
+        ("fs8_z", C.c_void_p), ("fs8_val", C.c_void_p), ("fs8_inv_cov", C.c_void_p), ("fs8_fid", C.c_void_p),
+        ("fs8_a_init", C.c_double),
     ]
 
 
@@ -101,7 +104,7 @@ EXPORTS = {
     "cf_eval": (C.c_int, [_VP, _VP, _I64, _VP, _I32]),
     "cf_split_rows": (None, [_I64, _I32, _I32, C.POINTER(_I64), C.POINTER(_I64)]),
     "cf_eval_device": (C.c_int, [_VP, _VP, _I64, _VP, _I32, _VP]),
-    "cf_eval_parts": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP]),
+    "cf_eval_parts": (C.c_int, [_VP, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP]),
     "cf_eval_table": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
     "cf_last_kernel_ms": (C.c_int, [_VP, C.POINTER(C.c_float * 2)]),
     "cf_enable_timing": (C.c_int, [_VP, C.c_int]),

@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <utility>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -33,10 +35,15 @@ __global__ void walker_kernel(cf_dev_desc d, const double* theta, int64_t W, dou
 template <int MODEL, int FDE>
 __global__ void small_blocks_kernel(cf_dev_desc d, const double* theta, int64_t W, const d2* bao_nodes, double* chi2_extra,
                                     double* blocks_out, double* bao_out);
+template <int MODEL, int FDE>
+__global__ void growth_kernel(cf_dev_desc d, const double* theta, int64_t W, const d2* aux_nodes, double* scratch, double* chi2_extra,
+                              int accumulate, double* blocks_out, double* theory_out);
 #define CF_DECLARE_WALKER(M, F)                                                                                            \
   extern template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*, d2*); \
   extern template __global__ void small_blocks_kernel<M, F>(cf_dev_desc, const double*, int64_t, const d2*, double*,       \
-                                                            double*, double*);
+                                                            double*, double*);                                            \
+  extern template __global__ void growth_kernel<M, F>(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, int, \
+                                                      double*, double*);
 CF_DECLARE_WALKER(0, 0) CF_DECLARE_WALKER(0, 1) CF_DECLARE_WALKER(0, 2) CF_DECLARE_WALKER(0, 3)
 CF_DECLARE_WALKER(1, 0) CF_DECLARE_WALKER(1, 1) CF_DECLARE_WALKER(1, 2) CF_DECLARE_WALKER(1, 3)
 
@@ -52,6 +59,12 @@ static small_blocks_fn pick_small_blocks(int model, int fde) {
   static const small_blocks_fn table[2][4] = {
       {small_blocks_kernel<0, 0>, small_blocks_kernel<0, 1>, small_blocks_kernel<0, 2>, small_blocks_kernel<0, 3>},
       {small_blocks_kernel<1, 0>, small_blocks_kernel<1, 1>, small_blocks_kernel<1, 2>, small_blocks_kernel<1, 3>}};
+  return table[model][fde];
+}
+typedef void (*growth_fn)(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, int, double*, double*);
+static growth_fn pick_growth(int model, int fde) {
+  static const growth_fn table[2][4] = {{growth_kernel<0, 0>, growth_kernel<0, 1>, growth_kernel<0, 2>, growth_kernel<0, 3>},
+                                        {growth_kernel<1, 0>, growth_kernel<1, 1>, growth_kernel<1, 2>, growth_kernel<1, 3>}};
   return table[model][fde];
 }
 template <int KS, int TC>
@@ -253,8 +266,10 @@ struct cf_handle {
   DevBuf z_cmb, z_hel, obs, sn_step, sn_rec, log10_tab;
   DevBuf bao_z, bao_val, bao_inv_cov, bao_qty, gl_x, gl_w, fixed_mu, cc_z, cc_h, cc_inv_cov, nu_grid, sn_lin, sn_dir;
   DevBuf theta, out, delta, ypk, chi2_extra, nonfinite;
+  DevBuf fs8_z, fs8_val, fs8_inv_cov, fs8_fid, fs8_step_of, fs8_order, fs8_scratch;
   DevBuf bao_nodes, bao_base;  // [max_walkers][n_bao][CF_BAO_NODES] table nodes for small_blocks_kernel; first node per datum
   bool has_small_blocks = false;  // BAO and / or CMB block present
+  bool has_growth = false;        // growth-rate block present
   int64_t max_walkers = 0;
   double pack_probe_rel = 0.0;
   int cu_count = 0;
@@ -307,7 +322,8 @@ static int ensure_workspace(cf_handle* h, int64_t W) {
   if (h->stage_in.ensure((size_t)w_pad * (h->d.ndim > 0 ? h->d.ndim : 1) * 8)) return CF_ERR_HIP;
   if (h->stage_out.ensure((size_t)w_pad * 8)) return CF_ERR_HIP;
   if (h->chi2_extra.ensure((size_t)w_pad * 8)) return CF_ERR_HIP;
-  if (h->d.n_bao > 0 && h->bao_nodes.ensure((size_t)w_pad * h->d.n_bao * CF_BAO_NODES * sizeof(d2))) return CF_ERR_HIP;
+  if (h->d.n_aux > 0 && h->bao_nodes.ensure((size_t)w_pad * h->d.n_aux * CF_BAO_NODES * sizeof(d2))) return CF_ERR_HIP;
+  if (h->d.n_fs8 > 0 && h->fs8_scratch.ensure((size_t)w_pad * h->d.n_fs8 * 8)) return CF_ERR_HIP;
   if (h->d.n_sn > 0 && h->solve_mode == CF_SOLVE_INVERSE_GEMM) {
     if (h->partial.ensure((size_t)w_pad * h->ipack.dev.n_rowblocks * 8)) return CF_ERR_HIP;
     if (h->arrivals.ensure((size_t)(w_pad / 16) * 4)) return CF_ERR_HIP;
@@ -376,6 +392,16 @@ static int validate_desc(const cf_desc* c) {
     if (!c->sn_z_cmb || !c->sn_z_hel || !c->sn_obs || !c->sn_chol)
       return fail(CF_ERR_INVALID, "cf_create: SN block arrays must not be null");
     if (c->sn_chol_ld < c->n_sn) return fail(CF_ERR_INVALID, "cf_create: sn_chol_ld < n_sn");
+  }
+  if (c->n_fs8 < 0 || c->n_fs8 > CF_MAX_FS8) return fail(CF_ERR_INVALID, "cf_create: n_fs8 must be in 0..64");
+  if (c->n_fs8 > 0) {
+    if (!c->fs8_z || !c->fs8_val || !c->fs8_inv_cov || !c->fs8_fid) return fail(CF_ERR_INVALID, "cf_create: growth-rate arrays must not be null");
+    if (!(c->fs8_a_init > 0.0 && c->fs8_a_init < 1.0)) return fail(CF_ERR_INVALID, "cf_create: fs8_a_init must be in (0, 1)");
+    if (c->fs8_steps < 0 || c->fs8_steps > 65536) return fail(CF_ERR_INVALID, "cf_create: fs8_steps must be in 0..65536");
+    if (c->n_grid < CF_BAO_NODES) return fail(CF_ERR_INVALID, "cf_create: a growth-rate block needs n_grid >= 6");
+    for (int k = 0; k < c->n_fs8; ++k)
+      if (!(1.0 / (1.0 + c->fs8_z[k]) >= c->fs8_a_init) || c->fs8_z[k] < 0.0)
+        return fail(CF_ERR_INVALID, "cf_create: growth-rate data must lie in a_init <= a <= 1");
   }
   if (c->om_mode != 0 && c->om_mode != 1) return fail(CF_ERR_INVALID, "cf_create: om_mode must be 0 or 1");
   if (c->n_devices < -1 || c->n_devices > 64 || (c->n_devices > 0 && !c->devices))
@@ -473,6 +499,11 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
   d.n_cc = c->n_cc;
   d.cc_logdet = c->cc_logdet;
   h->has_small_blocks = c->n_bao > 0 || c->cmb_mode != CF_CMB_NONE || c->n_cc > 0;
+  h->has_growth = c->n_fs8 > 0;
+  d.n_fs8 = c->n_fs8;
+  d.fs8_steps = c->fs8_steps > 0 ? c->fs8_steps : 512;
+  d.fs8_a_init = c->fs8_a_init;
+  d.n_aux = c->n_bao + c->n_fs8;
   d.cpl_wall = c->cpl_wall;
   d.has_bounds = c->bounds != nullptr;
   d.log_norm = 0.0;
@@ -587,27 +618,59 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
     d.bao_val = h->bao_val.as<const double>();
     d.bao_inv_cov = h->bao_inv_cov.as<const double>();
     d.bao_qty = h->bao_qty.as<const int32_t>();
-    {
-      // interval of each BAO redshift on the grid, by the arithmetic of hermite_tab (cosmofit_kernels.hip); the copy
-      // of CF_BAO_NODES nodes starts two nodes below it, so that the kernel's own interval search, the Hermite pair
-      // and the two 3-point PCHIP stencils all stay inside the copy
-      std::vector<int32_t> base((size_t)c->n_bao);
-      const int G = d.n_grid;
-      for (int k = 0; k < c->n_bao; ++k) {
-        const double xi = c->bao_z[k];
-        int i = (int)(xi * d.inv_step);
-        i = i > G - 2 ? G - 2 : (i < 0 ? 0 : i);
-        if (i > 0 && (double)i * d.step >= xi) --i;
-        if (i < G - 2 && (double)(i + 1) * d.step < xi) ++i;
-        int b = i - 2;
-        b = b < 0 ? 0 : (b > G - CF_BAO_NODES ? G - CF_BAO_NODES : b);
-        base[k] = b;
-      }
-      if (h->bao_base.ensure(base.size() * 4)) return bail(CF_ERR_HIP);
-      if (hipMemcpy(h->bao_base.p, base.data(), base.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
-        return bail(fail(CF_ERR_HIP, "hipMemcpy(bao_base) failed"));
-      d.bao_base = h->bao_base.as<const int32_t>();
+  }
+  if (d.n_aux > 0) {
+    // interval of each BAO / growth-rate redshift on the grid, by the arithmetic of hermite_tab (cosmofit_kernels.hip); the
+    // copy of CF_BAO_NODES nodes starts two nodes below it, so that the kernel's own interval search, the Hermite pair
+    // and the two 3-point PCHIP stencils all stay inside the copy
+    std::vector<int32_t> base((size_t)d.n_aux);
+    const int G = d.n_grid;
+    for (int k = 0; k < d.n_aux; ++k) {
+      const double xi = k < c->n_bao ? c->bao_z[k] : c->fs8_z[k - c->n_bao];
+      int i = (int)(xi * d.inv_step);
+      i = i > G - 2 ? G - 2 : (i < 0 ? 0 : i);
+      if (i > 0 && (double)i * d.step >= xi) --i;
+      if (i < G - 2 && (double)(i + 1) * d.step < xi) ++i;
+      int b = i - 2;
+      b = b < 0 ? 0 : (b > G - CF_BAO_NODES ? G - CF_BAO_NODES : b);
+      base[k] = b;
     }
+    if (h->bao_base.ensure(base.size() * 4)) return bail(CF_ERR_HIP);
+    if (hipMemcpy(h->bao_base.p, base.data(), base.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+      return bail(fail(CF_ERR_HIP, "hipMemcpy(bao_base) failed"));
+    d.bao_base = h->bao_base.as<const int32_t>();
+  }
+  if (c->n_fs8 > 0) {
+    int rc;
+    const int n = c->n_fs8;
+    if ((rc = upload_vec(h->fs8_z, c->fs8_z, n))) return bail(rc);
+    if ((rc = upload_vec(h->fs8_val, c->fs8_val, n))) return bail(rc);
+    if ((rc = upload_vec(h->fs8_inv_cov, c->fs8_inv_cov, (int64_t)n * n))) return bail(rc);
+    if ((rc = upload_vec(h->fs8_fid, c->fs8_fid, n))) return bail(rc);
+    d.fs8_z = h->fs8_z.as<const double>();
+    d.fs8_val = h->fs8_val.as<const double>();
+    d.fs8_inv_cov = h->fs8_inv_cov.as<const double>();
+    d.fs8_fid = h->fs8_fid.as<const double>();
+    // RK4 step that contains ln a_k, and the data in step order (ascending a)
+    const double x0 = std::log(c->fs8_a_init), hstep = -x0 / d.fs8_steps;
+    std::vector<int32_t> step_of((size_t)n), order((size_t)n);
+    std::vector<std::pair<int32_t, int32_t>> so;
+    for (int k = 0; k < n; ++k) {
+      int i = (int)((std::log(1.0 / (1.0 + c->fs8_z[k])) - x0) / hstep);
+      i = i < 0 ? 0 : (i > d.fs8_steps - 1 ? d.fs8_steps - 1 : i);
+      so.emplace_back(i, k);
+    }
+    std::sort(so.begin(), so.end());
+    for (int k = 0; k < n; ++k) {
+      step_of[k] = so[k].first;
+      order[k] = so[k].second;
+    }
+    if (h->fs8_step_of.ensure((size_t)n * 4) || h->fs8_order.ensure((size_t)n * 4)) return bail(CF_ERR_HIP);
+    if (hipMemcpy(h->fs8_step_of.p, step_of.data(), (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->fs8_order.p, order.data(), (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess)
+      return bail(fail(CF_ERR_HIP, "hipMemcpy(fs8 order) failed"));
+    d.fs8_step_of = h->fs8_step_of.as<const int32_t>();
+    d.fs8_order = h->fs8_order.as<const int32_t>();
   }
   if (c->ez_model == CF_EZ_PHYSICAL) {
     // massive-neutrino density at the grid nodes, cmb/data_planck_act_compression.py:53-66 -- independent of theta
@@ -897,16 +960,16 @@ static int launch_tri_gemm(const TriGemmArgs& a, hipStream_t st) {
 // per-walker kernels (the next chunk's walker kernel waits for it: chunks enter the chip one after the other).
 static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_t Wc, double* d_out, int out_kind, hipStream_t st,
                         double* dm_out, double* mucorr_out, double* blocks_out, double* bao_out, double* chi2_sn_out,
-                        hipEvent_t* ev, hipEvent_t ev_walker_done) {
+                        hipEvent_t* ev, hipEvent_t ev_walker_done, double* fs8_block_out = nullptr, double* fs8_theory_out = nullptr) {
   const cf_dev_desc& d = h->d;
   unsigned long long* nf = h->nonfinite.as<unsigned long long>();
   const double* th = d_theta + off * d.ndim;
   double* out = d_out + off;
   double* delta = h->delta.as<double>() ? h->delta.as<double>() + off * d.n_ld : nullptr;
-  d2* bao_nodes = h->bao_nodes.as<d2>() ? h->bao_nodes.as<d2>() + off * d.n_bao * CF_BAO_NODES : nullptr;
+  d2* bao_nodes = h->bao_nodes.as<d2>() ? h->bao_nodes.as<d2>() + off * d.n_aux * CF_BAO_NODES : nullptr;
   if (ev) HIP_TRY(hipEventRecord(ev[0], st));
-  const bool walker_work = d.n_sn > 0 || h->has_small_blocks;
-  double* extra = h->has_small_blocks ? h->chi2_extra.as<double>() + off : nullptr;
+  const bool walker_work = d.n_sn > 0 || h->has_small_blocks || h->has_growth;
+  double* extra = (h->has_small_blocks || h->has_growth) ? h->chi2_extra.as<double>() + off : nullptr;
   if (walker_work) {
     // skewed {cum, dh} table: one spare 16-byte slot per 2^chunk_shift nodes
     const size_t lds = ((size_t)d.n_grid + (d.n_grid >> d.chunk_shift) + 2) * 16;
@@ -915,6 +978,10 @@ static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_
     if (h->has_small_blocks)  // sixteen lanes per walker, sixteen walkers per workgroup
       hipLaunchKernelGGL(pick_small_blocks(d.ez_model, d.fde), dim3((unsigned)((Wc + 15) / 16)), dim3(256), 0, st, d, th, Wc,
                          (const d2*)bao_nodes, extra, blocks_out, bao_out);
+    if (h->has_growth)  // one lane per walker: the growth ODE and the f sigma_8 quadratic form, added to chi2_extra
+      hipLaunchKernelGGL(pick_growth(d.ez_model, d.fde), dim3((unsigned)((Wc + 63) / 64)), dim3(64), 0, st, d, th, Wc,
+                         (const d2*)bao_nodes, h->fs8_scratch.as<double>() + off * d.n_fs8, extra, h->has_small_blocks ? 1 : 0,
+                         fs8_block_out, fs8_theory_out);
   }
   if (ev_walker_done) HIP_TRY(hipEventRecord(ev_walker_done, st));
   if (ev) HIP_TRY(hipEventRecord(ev[1], st));
@@ -940,7 +1007,7 @@ static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_
 // of chunk c + 1 beside the solve of chunk c; everything is joined back into `st` before this returns.
 static int launch_path(cf_handle* h, const double* d_theta, int64_t W, double* d_out, int out_kind, hipStream_t st,
                        double* dm_out, double* mucorr_out, double* blocks_out, double* bao_out,
-                       double* chi2_sn_out = nullptr) {
+                       double* chi2_sn_out = nullptr, double* fs8_block_out = nullptr, double* fs8_theory_out = nullptr) {
   // the workspace is shared: order this evaluation behind the previous one if that ran on another stream
   if (h->has_last && h->last_stream != st) HIP_TRY(hipStreamWaitEvent(st, h->ev_last, 0));
   const bool parts = dm_out || mucorr_out || blocks_out || bao_out || chi2_sn_out;
@@ -961,7 +1028,8 @@ static int launch_path(cf_handle* h, const double* d_theta, int64_t W, double* d
   const int slot = h->timing_slots ? (int)(h->timed_calls % h->timing_slots) : 0;
   hipEvent_t* ev = h->timing_slots ? &h->ev[3 * slot * CF_MAX_CHUNKS] : nullptr;
   if (n_chunks == 1) {
-    int rc = launch_chunk(h, d_theta, 0, W, d_out, out_kind, st, dm_out, mucorr_out, blocks_out, bao_out, chi2_sn_out, ev, nullptr);
+    int rc = launch_chunk(h, d_theta, 0, W, d_out, out_kind, st, dm_out, mucorr_out, blocks_out, bao_out, chi2_sn_out, ev, nullptr,
+                          fs8_block_out, fs8_theory_out);
     if (rc) return rc;
   } else {
     HIP_TRY(hipEventRecord(h->ev_fork, st));
@@ -1073,28 +1141,32 @@ extern "C" int cf_eval(cf_handle* h, const double* theta, int64_t W, double* out
 }
 
 extern "C" int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, double* dm_obs, double* mu_corr,
-                             double* delta, double* chi2_blocks, double* bao_theory) {
+                             double* delta, double* chi2_blocks, double* bao_theory, double* fs8_theory) {
   if (!h || !theta) return fail(CF_ERR_INVALID, "cf_eval_parts: null argument");
   if (W <= 0 || W > (1 << 20)) return fail(CF_ERR_INVALID, "cf_eval_parts: W out of range");
   if (bao_theory && h->d.n_bao == 0) return fail(CF_ERR_INVALID, "cf_eval_parts: this likelihood has no BAO block");
+  if (fs8_theory && h->d.n_fs8 == 0) return fail(CF_ERR_INVALID, "cf_eval_parts: this likelihood has no growth-rate block");
   if ((dm_obs || mu_corr || delta) && h->d.n_sn == 0) return fail(CF_ERR_INVALID, "cf_eval_parts: this likelihood has no SN block");
   std::lock_guard<std::mutex> lk(h->mu);
   HIP_TRY(hipSetDevice(h->device));
   int rc;
   if ((rc = ensure_workspace(h, W))) return rc;
-  const int64_t n = h->d.n_sn, n_ld = h->d.n_ld, nb = h->d.n_bao;
-  DevBuf dm, mc, blk, bt, snb;
-  if (snb.ensure((size_t)W * 8)) return CF_ERR_HIP;
+  const int64_t n = h->d.n_sn, n_ld = h->d.n_ld, nb = h->d.n_bao, nf = h->d.n_fs8;
+  DevBuf dm, mc, blk, bt, snb, fsb, ft;
+  if (snb.ensure((size_t)W * 8) || fsb.ensure((size_t)W * 8)) return CF_ERR_HIP;
   HIP_TRY(hipMemsetAsync(snb.p, 0, (size_t)W * 8, h->stream));
+  HIP_TRY(hipMemsetAsync(fsb.p, 0, (size_t)W * 8, h->stream));
   // the SN accessor path (reference-order mu_corr / mu_theory) is selected by a non-null dm / mu_corr buffer
   if (n > 0 && dm.ensure((size_t)W * n * 8)) return CF_ERR_HIP;
   if (n > 0 && mu_corr && mc.ensure((size_t)W * n * 8)) return CF_ERR_HIP;
   if (blk.ensure((size_t)W * 6 * 8)) return CF_ERR_HIP;
   HIP_TRY(hipMemsetAsync(blk.p, 0, (size_t)W * 6 * 8, h->stream));
   if (nb > 0 && bt.ensure((size_t)W * nb * 8)) return CF_ERR_HIP;
+  if (nf > 0 && ft.ensure((size_t)W * nf * 8)) return CF_ERR_HIP;
   HIP_TRY(hipMemcpyAsync(h->theta.p, theta, (size_t)W * h->d.ndim * 8, hipMemcpyHostToDevice, h->stream));
   if ((rc = launch_path(h, h->theta.as<const double>(), W, h->out.as<double>(), CF_OUT_CHI2, h->stream,
-                        dm.as<double>(), mc.as<double>(), blk.as<double>(), bt.as<double>(), snb.as<double>())))
+                        dm.as<double>(), mc.as<double>(), blk.as<double>(), bt.as<double>(), snb.as<double>(), fsb.as<double>(),
+                        ft.as<double>())))
     return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (dm_obs) HIP_TRY(hipMemcpy(dm_obs, dm.p, (size_t)W * n * 8, hipMemcpyDeviceToHost));
@@ -1103,19 +1175,22 @@ extern "C" int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, doubl
     HIP_TRY(hipMemcpy2D(delta, (size_t)n * 8, h->delta.p, (size_t)n_ld * 8, (size_t)n * 8, (size_t)W,
                         hipMemcpyDeviceToHost));
   if (bao_theory) HIP_TRY(hipMemcpy(bao_theory, bt.p, (size_t)W * nb * 8, hipMemcpyDeviceToHost));
+  if (fs8_theory) HIP_TRY(hipMemcpy(fs8_theory, ft.p, (size_t)W * nf * 8, hipMemcpyDeviceToHost));
   if (chi2_blocks) {
-    std::vector<double> sn((size_t)W), b6((size_t)W * 6);
+    std::vector<double> sn((size_t)W), b6((size_t)W * 6), fs((size_t)W);
     HIP_TRY(hipMemcpy(sn.data(), snb.p, (size_t)W * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(b6.data(), blk.p, (size_t)W * 6 * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(fs.data(), fsb.p, (size_t)W * 8, hipMemcpyDeviceToHost));
     for (int64_t w = 0; w < W; ++w) {
-      // sn (written by the solve kernel before the other blocks are added), bao, cmb, the CMB distance vector, cc
-      chi2_blocks[7 * w + 0] = sn[w];
-      chi2_blocks[7 * w + 1] = b6[6 * w + 0];
-      chi2_blocks[7 * w + 2] = b6[6 * w + 1];
-      chi2_blocks[7 * w + 3] = b6[6 * w + 2];
-      chi2_blocks[7 * w + 4] = b6[6 * w + 3];
-      chi2_blocks[7 * w + 5] = b6[6 * w + 4];
-      chi2_blocks[7 * w + 6] = b6[6 * w + 5];
+      // sn (written by the solve kernel before the other blocks are added), bao, cmb, the CMB distance vector, cc, fs8
+      chi2_blocks[8 * w + 0] = sn[w];
+      chi2_blocks[8 * w + 1] = b6[6 * w + 0];
+      chi2_blocks[8 * w + 2] = b6[6 * w + 1];
+      chi2_blocks[8 * w + 3] = b6[6 * w + 2];
+      chi2_blocks[8 * w + 4] = b6[6 * w + 3];
+      chi2_blocks[8 * w + 5] = b6[6 * w + 4];
+      chi2_blocks[8 * w + 6] = b6[6 * w + 5];
+      chi2_blocks[8 * w + 7] = fs[w];
     }
   }
   return CF_OK;

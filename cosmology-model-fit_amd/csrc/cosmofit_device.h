@@ -11,6 +11,7 @@
 #define CF_MAX_BAO 64
 #define CF_MAX_GL 256
 #define CF_MAX_CC 64
+#define CF_MAX_FS8 64
 #define CF_N_SLOTS 15
 
 // One block row of the blocked solve = 16 MFMA tiles of 16 rows.
@@ -86,6 +87,17 @@ struct cf_dev_desc {
   const double* cc_h;
   const double* cc_inv_cov;
   double cc_logdet;
+  // growth-rate block (fs8/fs8.py:64-120): f sigma_8 data, explicit inverse covariance, fiducial H(z) D_M(z) of the
+  // Alcock-Paczynski correction; the growth ODE is integrated in ln a by RK4 from a_init to 1 in fs8_steps steps
+  int32_t n_fs8, fs8_steps;
+  const double* fs8_z;
+  const double* fs8_val;
+  const double* fs8_inv_cov;
+  const double* fs8_fid;
+  const int32_t* fs8_step_of;  // [n_fs8] RK4 step that contains ln a_k, data sorted by step (ascending a)
+  const int32_t* fs8_order;    // [n_fs8] datum index of the k-th entry in that order
+  double fs8_a_init;
+  int32_t n_aux, pad_aux;       // table-node copies for small_blocks / growth kernels: n_bao BAO data then n_fs8 growth data
   // radiation + massive neutrinos (CF_EZ_PHYSICAL)   cmb/data_planck_act_compression.py:29-66
   double or_h2, omnu_h2, o_gamma_h2, nu_m0, nu_rho0;
   double nu_qs_sq[5], nu_ws[5];

@@ -646,15 +646,15 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
   T.z_max = d.z_max;
 
   CF_WSTAMP(1);
-  if (d.n_sn > 0 || d.n_bao > 0 || table_out) build_distance_table<MODEL, FDE>(d, wc, lds_tab, wave_pub, nu_pre);
+  if (d.n_sn > 0 || d.n_aux > 0 || table_out) build_distance_table<MODEL, FDE>(d, wc, lds_tab, wave_pub, nu_pre);
   CF_WSTAMP(4);
   if (table_out)  // accessor path (cf_eval_table): the walker's whole {cum_dm, dh} table, node order
     for (int g = tid; g < d.n_grid; g += CF_TPB_A) table_out[w * d.n_grid + g] = T.at(g);
   // the table nodes around each BAO redshift go to small_blocks_kernel (the BAO block is evaluated there, one wave
   // per walker); copied by the last threads of the workgroup, whose waves have the lightest share of the SN loop
-  if (tid >= CF_TPB_A - CF_BAO_NODES * d.n_bao) {
-    const int e = CF_TPB_A - 1 - tid, k = e / CF_BAO_NODES, o = e % CF_BAO_NODES;
-    bao_nodes[(w * d.n_bao + k) * CF_BAO_NODES + o] = T.at(d.bao_base[k] + o);
+  for (int e = CF_TPB_A - 1 - tid; e < CF_BAO_NODES * d.n_aux; e += CF_TPB_A) {
+    const int k = e / CF_BAO_NODES, o = e % CF_BAO_NODES;
+    bao_nodes[(w * d.n_aux + k) * CF_BAO_NODES + o] = T.at(d.bao_base[k] + o);
   }
 
   // ---- SN residual vector ----
@@ -844,7 +844,7 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
   if (d.n_bao > 0) {
     for (int k = sl; k < d.n_bao; k += CF_SB_LANES) {
       NodeView T;
-      T.p = bao_nodes + (w * d.n_bao + k) * CF_BAO_NODES;
+      T.p = bao_nodes + (w * d.n_aux + k) * CF_BAO_NODES;
       T.base = d.bao_base[k];
       T.G = d.n_grid;
       T.step = d.step;
@@ -876,10 +876,135 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Growth-rate block f sigma_8(z): fs8/fs8.py:26-120, bao/desi_cmb_union3_fs8.py:27-207.  ONE LANE per walker.
+//   delta'' = -(3/a + E_a/E) delta' + (3/2) Om delta / (a^5 E^2),   E_a/E = -(dE^2/dz) / (2 a^2 E^2),
+//   from a_init with delta = a_init, delta' = 1 to a = 1 (fs8/fs8.py:64-90).  The reference hands this to scipy's adaptive
+//   RK45 (rtol 1e-6, atol 1e-8) and reads delta' at the data points by PCHIP from a 1000 / 2500-point log grid; here
+//   classical RK4 in x = ln a with a fixed step (y1 = delta, y2 = delta'; dy/dx = a dy/da), and delta'(a_k) by cubic Hermite
+//   inside the step that contains ln a_k (the slope dy2/dx is the first stage of the next step): error ~1e-9, far below
+//   the reference's own ~1e-6 (tests/test_fs8.py states the resulting parity bar).
+//   theory_k = (sigma8 / delta(1)) a_k delta'(a_k)                                        fs8/fs8.py:84-98
+//   q_k = H(z_k) D_M(z_k) / (H D_M)_fid,k ;  Delta = val - theory / q ;  chi2 = f_err^2 Delta^T inv_cov Delta    :111-120
+// ------------------------------------------------------------------------------------------------
+template <int FDE>
+__device__ __forceinline__ double dfde_dz(const WalkerCosmo& wc, double z, double zp1, double cubed, double f) {
+  if (FDE == CF_FDE_LCDM_D) return 0.0;
+  if (FDE == CF_FDE_WCDM_D) return f * 3 * (1.0 + wc.w0) / zp1;
+  if (FDE == CF_FDE_THAWING_D) {  // fs8/fs8.py:26-41: Ode_z * 3 (1 + w_de(z)) / (1 + z)
+    const double w = -1.0 + 2 * (1.0 + wc.w0) / ((1.0 + wc.w0) + (1.0 - wc.w0) * cubed);
+    return f * 3 * (1.0 + w) / zp1;
+  }
+  return f * 3 * (1.0 + wc.w0 + wc.wa * z / zp1) / zp1;  // CPL: w(z) = w0 + wa z / (1 + z)
+}
+
+// massive-neutrino equation of state, cmb/data_planck_act_compression.py:70-83
+__device__ __forceinline__ double w_nu_z(const cf_dev_desc& d, double zp1) {
+  const double r = d.nu_m0 / zp1, mz_sq = r * r;
+  double num = 0.0, den = 0.0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const double f = sqrt(d.nu_qs_sq[i] + mz_sq);
+    num += d.nu_ws[i] / f;
+    den += d.nu_ws[i] * f;
+  }
+  return (1.0 / 3) - (1.0 / 3) * mz_sq * num / den;
+}
+
+// {E^2, dE^2/dz} at z                       fs8/fs8.py:44-56, bao/desi_cmb_union3_fs8.py:46-66,127-140
+template <int MODEL, int FDE>
+__device__ __forceinline__ void e2_and_slope(const cf_dev_desc& d, const WalkerCosmo& wc, double z, double& e2, double& de2) {
+  const double zp1 = 1.0 + z, sq = zp1 * zp1, cubed = sq * zp1;
+  const double f = (FDE == CF_FDE_LCDM_D) ? 1.0 : f_de<FDE>(wc, z, zp1, cubed);
+  const double df = dfde_dz<FDE>(wc, z, zp1, cubed, f);
+  if (MODEL == CF_EZ_LATE_FLAT_D) {
+    e2 = wc.Om * cubed + (1.0 - wc.Om) * f;
+    de2 = 3 * wc.Om * sq + (1.0 - wc.Om) * df;
+  } else {
+    const double nu = omnu_z(d, zp1);
+    e2 = wc.Or * (cubed * zp1) + wc.Obc * cubed + wc.Ode * f + wc.Onu * nu;
+    de2 = 3 * wc.Obc * sq + 4 * wc.Or * cubed + wc.Onu * (nu * 3 * (1.0 + w_nu_z(d, zp1)) / zp1) + wc.Ode * df;
+  }
+}
+
+template <int MODEL, int FDE>
+__device__ __forceinline__ void growth_rhs(const cf_dev_desc& d, const WalkerCosmo& wc, double om, double x, double y1, double y2,
+                                           double& f1, double& f2) {
+  const double a = exp(x), z = 1.0 / a - 1.0;
+  double e2, de2;
+  e2_and_slope<MODEL, FDE>(d, wc, z, e2, de2);
+  const double a2 = a * a;
+  const double ea_over_e = -de2 / (2 * a2 * e2);
+  const double source = 1.5 * om * y1 / (a2 * a2 * a * e2);
+  f1 = a * y2;
+  f2 = a * (-(3 / a + ea_over_e) * y2 + source);
+}
+
+template <int MODEL, int FDE>
+__global__ void __launch_bounds__(64)
+growth_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, const d2* __restrict__ aux_nodes,
+              double* __restrict__ scratch, double* __restrict__ chi2_extra, int accumulate, double* __restrict__ blocks_out,
+              double* __restrict__ theory_out) {
+  const int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (w >= W) return;
+  const double* th = theta + w * d.ndim;
+  const WalkerCosmo wc = make_cosmo(d, th);
+  const double om = MODEL == CF_EZ_LATE_FLAT_D ? wc.Om : wc.Obc;
+  const int n = d.n_fs8, steps = d.fs8_steps;
+  double* dprime = scratch + w * n;  // delta'(a_k), in the data's own order
+  const double x0 = log(d.fs8_a_init), h = -x0 / steps;
+  double y1 = d.fs8_a_init, y2 = 1.0, k1a, k1b;
+  growth_rhs<MODEL, FDE>(d, wc, om, x0, y1, y2, k1a, k1b);
+  int next = 0;
+  for (int i = 0; i < steps; ++i) {
+    const double x = x0 + i * h;
+    double k2a, k2b, k3a, k3b, k4a, k4b;
+    growth_rhs<MODEL, FDE>(d, wc, om, x + 0.5 * h, y1 + 0.5 * h * k1a, y2 + 0.5 * h * k1b, k2a, k2b);
+    growth_rhs<MODEL, FDE>(d, wc, om, x + 0.5 * h, y1 + 0.5 * h * k2a, y2 + 0.5 * h * k2b, k3a, k3b);
+    growth_rhs<MODEL, FDE>(d, wc, om, x + h, y1 + h * k3a, y2 + h * k3b, k4a, k4b);
+    const double n1 = y1 + (h / 6) * (k1a + 2 * k2a + 2 * k3a + k4a);
+    const double n2 = y2 + (h / 6) * (k1b + 2 * k2b + 2 * k3b + k4b);
+    double e1a, e1b;  // first stage of the next step = slopes at the end of this one
+    growth_rhs<MODEL, FDE>(d, wc, om, i + 1 == steps ? 0.0 : x + h, n1, n2, e1a, e1b);
+    while (next < n && d.fs8_step_of[next] == i) {  // the data points whose ln a lies in this step: cubic Hermite of delta'
+      const int k = d.fs8_order[next];
+      const double t = (log(1.0 / (1.0 + d.fs8_z[k])) - x) / h;
+      const double t2 = t * t, t3 = t2 * t;
+      dprime[k] = (2 * t3 - 3 * t2 + 1) * y2 + (t3 - 2 * t2 + t) * h * k1b + (-2 * t3 + 3 * t2) * n2 + (t3 - t2) * h * e1b;
+      ++next;
+    }
+    y1 = n1; y2 = n2; k1a = e1a; k1b = e1b;
+  }
+  const double delta0 = y1, s8 = slot_get(d, CF_P_S8_D, th), ferr = slot_get(d, CF_P_FS8ERR_D, th);
+  // residuals with the Alcock-Paczynski factor; they overwrite delta' in the scratch row
+  for (int k = 0; k < n; ++k) {
+    NodeView T;
+    T.p = aux_nodes + (w * d.n_aux + d.n_bao + k) * CF_BAO_NODES;
+    T.base = d.bao_base[d.n_bao + k];
+    T.G = d.n_grid; T.step = d.step; T.inv_step = d.inv_step; T.inv_last = d.inv_last; T.z_max = d.z_max;
+    const double z = d.fs8_z[k], a = 1.0 / (1.0 + z);
+    const double theory = (s8 / delta0) * a * dprime[k];
+    const double q = H_of_z<MODEL, FDE>(d, wc, z) * hermite_tab(T, z) / d.fs8_fid[k];
+    if (theory_out) theory_out[w * n + k] = theory;
+    dprime[k] = d.fs8_val[k] - theory / q;
+  }
+  double c = 0.0;
+  for (int j = 0; j < n; ++j) {  // delta @ inv_cov @ delta in the reference's order (column by column)
+    double t = 0.0;
+    for (int i = 0; i < n; ++i) t += dprime[i] * d.fs8_inv_cov[i * n + j];
+    c += t * dprime[j];
+  }
+  c *= ferr * ferr;
+  chi2_extra[w] = accumulate ? chi2_extra[w] + c : c;
+  if (blocks_out) blocks_out[w] = c;
+}
+
 #define CF_INSTANTIATE_WALKER(M, F)                                                                              \
   template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*, d2*); \
   template __global__ void small_blocks_kernel<M, F>(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, \
-                                                     double*);
+                                                     double*);                                                      \
+  template __global__ void growth_kernel<M, F>(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, int, double*, \
+                                               double*);
 CF_INSTANTIATE_WALKER(0, 0) CF_INSTANTIATE_WALKER(0, 1) CF_INSTANTIATE_WALKER(0, 2) CF_INSTANTIATE_WALKER(0, 3)
 CF_INSTANTIATE_WALKER(1, 0) CF_INSTANTIATE_WALKER(1, 1) CF_INSTANTIATE_WALKER(1, 2) CF_INSTANTIATE_WALKER(1, 3)
 
@@ -913,6 +1038,8 @@ __device__ double finalize_value(const cf_dev_desc& d, const double* __restrict_
     return -INFINITY;
   }
   double ll = -0.5 * chi2;
+  if (d.n_fs8 > 0)  // -0.5 (chi2 - 2 N ln f_err), fs8/fs8.py:123-125 (f_err fixed to 1 where a script has none)
+    ll += d.n_fs8 * log(slot_get(d, CF_P_FS8ERR_D, th));
   if (d.n_cc > 0)  // Gaussian normalisation with rescaled errors, bao/desi_union3_cc_theta_star.py:135-139
     ll -= 0.5 * (d.n_cc * 1.8378770664093453 + d.cc_logdet - 2 * d.n_cc * log(slot_get(d, CF_P_FCC_D, th)));
   return lp + ll;

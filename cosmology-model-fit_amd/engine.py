@@ -50,7 +50,7 @@ class LikelihoodEngine:
     def __init__(self, *, ndim: int, z_max: float, n_grid: int = 4000, fde: int = L.CF_FDE_LCDM,
                  ez_model: int = L.CF_EZ_LATE_FLAT, params: dict, sn: Optional[dict] = None,
                  bao: Optional[dict] = None, cmb: Optional[dict] = None, physical: Optional[dict] = None,
-                 cc: Optional[dict] = None, solve_mode: int = L.CF_SOLVE_AUTO,
+                 cc: Optional[dict] = None, fs8: Optional[dict] = None, solve_mode: int = L.CF_SOLVE_AUTO,
                  bounds=None, gauss: Sequence = (), chi2_gauss: Sequence = (), cpl_wall: bool = False,
                  device: int = 0, devices=None, probe_limit: float = 0.0, om_mode: int = 0, c_km_s: float = C_KM_S):
         """
@@ -61,6 +61,8 @@ class LikelihoodEngine:
             slot and is added to the offset (bulk-flow magnitude term, bao/desi_cmb_pantheon_H0trgb.py:102-106); dirs
             [N, 3] unit vectors make the peculiar velocity n . (v, v2, v3) x step (sn/pantheon_dipole_xyz.py:50-60).
         om_mode: 1 = the "Om" slot holds omega_m = Omega_m h^2 (bao/desi_omh2.py:18-20).
+        fs8: dict(z, val, inv_cov, fid, a_init[, steps]) — growth-rate block with the slots "s8" and "fs8err"
+            (fs8/fs8.py:64-125); fid[k] = H_fid(z_k) D_M,fid(z_k) of the Alcock-Paczynski correction.
         cc: dict(z, h, inv_cov, logdet) — cosmic chronometers with the rescale parameter slot "fcc"
             (bao/desi_union3_cc_theta_star.py:129-139).
         bao: dict(z, val, qty (0 DV/rd, 1 DM/rd, 2 DH/rd, 3 F_AP), inv_cov[, dh_exact=False, rd_fit=None]);
@@ -101,7 +103,7 @@ class LikelihoodEngine:
         if unknown:
             raise ValueError(f"unknown parameter slots {sorted(unknown)}; valid: {L.SLOTS}")
         for i, name in enumerate(L.SLOTS):
-            p = params.get(name, Param(fixed=-1.0) if name == "w0" else (Param(fixed=1.0) if name == "fcc" else Param()))
+            p = params.get(name, Param(fixed=-1.0) if name == "w0" else (Param(fixed=1.0) if name in ("fcc", "fs8err") else Param()))
             d.param[i].idx, d.param[i].scale, d.param[i].fixed = p.idx, p.scale, p.fixed
         keep = []
         if sn is not None:
@@ -157,6 +159,15 @@ class LikelihoodEngine:
                 raise ValueError("cc: z, h must have n entries and inv_cov must be (n, n)")
             keep += [cz, ch, cinv]
             d.n_cc, d.cc_z, d.cc_h, d.cc_inv_cov, d.cc_logdet = cz.size, _ptr(cz), _ptr(ch), _ptr(cinv), float(cc["logdet"])
+        self.n_fs8 = 0
+        if fs8 is not None:
+            fz, fv, finv, ffid = _f64(fs8["z"]), _f64(fs8["val"]), _f64(fs8["inv_cov"]), _f64(fs8["fid"])
+            if not (fz.size == fv.size == ffid.size) or finv.shape != (fz.size, fz.size):
+                raise ValueError("fs8: z, val, fid must have n entries and inv_cov must be (n, n)")
+            keep += [fz, fv, finv, ffid]
+            d.n_fs8, d.fs8_z, d.fs8_val, d.fs8_inv_cov, d.fs8_fid = fz.size, _ptr(fz), _ptr(fv), _ptr(finv), _ptr(ffid)
+            d.fs8_a_init, d.fs8_steps = float(fs8["a_init"]), int(fs8.get("steps", 0))
+            self.n_fs8 = int(fz.size)
         if cmb is not None:
             from .cmb_data import ZSTAR_CONSTS
             gx, gw = np.polynomial.legendre.leggauss(int(cmb.get("n_gl", 100)))  # cmb/data_planck_act_compression.py:150
@@ -248,17 +259,19 @@ class LikelihoodEngine:
 
     def parts(self, theta):
         """Intermediates of a (small) batch — for plots and tests: DM(z_cmb), mu_corr, residual (SN block);
-        chi2_blocks[:, 0:3] = (sn, bao, cmb), cmb_vector = the compressed-CMB theory 3-vector, chi2_cc, bao_theory."""
+        chi2_blocks[:, 0:3] = (sn, bao, cmb), cmb_vector = the compressed-CMB theory 3-vector, chi2_cc, chi2_fs8, bao_theory,
+        fs8_theory (before the Alcock-Paczynski division)."""
         th = np.atleast_2d(_f64(theta))
-        W, n, nb = th.shape[0], self.n_sn, self.n_bao
+        W, n, nb, nf = th.shape[0], self.n_sn, self.n_bao, self.n_fs8
         dm = np.empty((W, n)) if n else None
         mc = np.empty((W, n)) if n else None
         dl = np.empty((W, n)) if n else None
         bt = np.empty((W, nb)) if nb else None
-        blocks = np.empty((W, 7))
-        L.check(L.lib().cf_eval_parts(self._h, _ptr(th), W, _ptr(dm), _ptr(mc), _ptr(dl), _ptr(blocks), _ptr(bt)))
+        ft = np.empty((W, nf)) if nf else None
+        blocks = np.empty((W, 8))
+        L.check(L.lib().cf_eval_parts(self._h, _ptr(th), W, _ptr(dm), _ptr(mc), _ptr(dl), _ptr(blocks), _ptr(bt), _ptr(ft)))
         return dict(dm=dm, mu_corr=mc, delta=dl, chi2_blocks=blocks[:, :3], cmb_vector=blocks[:, 3:6], chi2_cc=blocks[:, 6],
-                    bao_theory=bt)
+                    chi2_fs8=blocks[:, 7], bao_theory=bt, fs8_theory=ft)
 
     def distance_table(self, theta):
         """(z_grid [G], cum_dm [W, G], dh_grid [W, G]) of one theta or a small batch: the grid of the scripts

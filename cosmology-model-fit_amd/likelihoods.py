@@ -358,3 +358,89 @@ class PantheonDipoleXyz(_Base):
         dirs = np.stack([np.cos(dec) * np.cos(ra), np.cos(dec) * np.sin(ra), np.sin(dec)], axis=1)
         att = 0.5 * (1.0 - np.tanh((np.asarray(z_cmb) - z_c) / dz))
         return dirs, att * np.isin(survey_id, list(target_ids)).astype(int)
+
+
+# ---- growth-rate scripts ------------------------------------------------------------------------------------
+def fs8_fiducial(z, h_dm_of_z):
+    """(H D_M)_fid per datum: ``h_dm_of_z(k, z_k)`` evaluates H(z_k) D_M(z_k) in datum k's fiducial cosmology, as the scripts
+    do once at import (fs8/fs8.py:101-108).  See ``Fs8.fiducial`` for the flat-LCDM form on the scripts' own grid."""
+    return np.array([h_dm_of_z(k, zk) for k, zk in enumerate(np.asarray(z, dtype=np.float64))])
+
+
+def _flat_lcdm_h_dm(z_grid, z, H0, Om):
+    """H(z) D_M(z) of flat LCDM with the scripts' arithmetic: trapezoid on their 4000-node grid, Hermite to z (host side, run
+    once per datum at set-up: fs8/fs8.py:101-108; interpolation by the GPU operator)."""
+    from .interpolator import interp_hermite
+
+    dh_grid = C_KM_S / (H0 * np.sqrt(Om * (1.0 + z_grid) ** 3 + (1.0 - Om)))
+    cum = np.zeros(z_grid.size)
+    cum[1:] = np.cumsum(((dh_grid[:-1] + dh_grid[1:]) / 2) * np.diff(z_grid))
+    return H0 * np.sqrt(Om * (1.0 + z) ** 3 + (1.0 - Om)) * interp_hermite(np.array([z]), z_grid, cum, dh_grid)[0]
+
+
+class Fs8(_Base):
+    """fs8/fs8.py: theta = (Om, sigma8, w0, f_err); bounds :128-135.  Growth-rate data alone, late-time flat with thawing
+    dark energy, H0 drops out (E(z) and c / E: the engine runs with H0 = 1); chi2 = f_err^2 delta C^-1 delta and
+    log L = -0.5 (chi2 - 2 N ln f_err) (:116-125)."""
+    bounds = np.array([(0.1, 0.6), (0.5, 1.0), (-1.0, 0.0), (0.2, 3.2)])
+    A_INIT = 10**-2.15  # :79
+
+    def __init__(self, z, fs8_vals, cov_mat, omega_fid, *, fid=None, device=0, devices=None, bounds=None, steps=0):
+        z = np.asarray(z, dtype=np.float64)
+        self.bounds = self.bounds if bounds is None else np.asarray(bounds, float)
+        self.z_max = float(np.max(z) + 0.1)  # :18
+        if fid is None:  # E(z) D_M(z) at each datum's fiducial Omega_m, w0 = -1 (:101-108)
+            z_grid = np.linspace(0, self.z_max, num=N_GRID)
+            fid = fs8_fiducial(z, lambda k, zk: _flat_lcdm_h_dm(z_grid, zk, 1.0, omega_fid[k]))
+        self.fid = np.asarray(fid, dtype=np.float64)
+        self.engine = LikelihoodEngine(
+            ndim=4, z_max=self.z_max, n_grid=N_GRID, fde=L.CF_FDE_THAWING,
+            params=dict(H0=Param(fixed=1.0), Om=Param(0), s8=Param(1), w0=Param(2), fs8err=Param(3)),
+            fs8=dict(z=z, val=fs8_vals, inv_cov=np.linalg.inv(cov_mat), fid=self.fid, a_init=self.A_INIT, steps=steps),
+            bounds=self.bounds, device=device, devices=devices)
+
+    def fs8_theory(self, params):
+        return self.engine.parts(params)["fs8_theory"][0]
+
+
+class DesiCmbUnion3Fs8(_Base):
+    """bao/desi_cmb_union3_fs8.py: theta = (dM, H0, wb, wc, v, sigma8).  Union3.1 SN (explicit inverse in the reference; step
+    at z = 0.2), DESI BAO with exact D_H, Planck+ACT (R, l_A, wb) and the growth-rate data with the physical-density
+    H(z) (radiation and massive neutrinos enter dH/da, :127-145); the ODE starts at a = 10^-2.7 (:168)."""
+    A_INIT = 10**-2.7
+
+    def __init__(self, z_cmb, z_hel, mu_values, cov_sn, bao_z, bao_val, bao_qty, bao_inv_cov, fs8_z, fs8_vals, fs8_cov, fs8_fid, *,
+                 comp=None, device=0, devices=None, steps=0):
+        comp = cmb_data.PLANCK_ACT if comp is None else comp
+        self.z_max = float(max(np.max(z_cmb), np.max(bao_z), np.max(fs8_z)) + 0.1)  # :26
+        self.engine = LikelihoodEngine(
+            ndim=6, z_max=self.z_max, n_grid=N_GRID, ez_model=L.CF_EZ_PHYSICAL, fde=L.CF_FDE_LCDM,
+            params=dict(offset=Param(0), H0=Param(1), obh2=Param(2), och2=Param(3), v=Param(4), s8=Param(5)),
+            sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=mu_values, chol=np.linalg.cholesky(cov_sn), z_turn=0.2),
+            bao=dict(z=bao_z, val=bao_val, qty=bao_qty, inv_cov=bao_inv_cov, dh_exact=True, rd_fit=comp["rd_fit"]),
+            cmb=dict(mode=comp["cmb_mode"], prior=comp["cmb_prior"], inv_cov=comp["cmb_inv_cov"], zstar_fit=comp["zstar_fit"]),
+            fs8=dict(z=fs8_z, val=fs8_vals, inv_cov=np.linalg.inv(fs8_cov), fid=fs8_fid, a_init=self.A_INIT, steps=steps),
+            physical=_physical(comp), device=device, devices=devices)
+
+    def fs8_theory(self, params):
+        return self.engine.parts(params)["fs8_theory"][0]
+
+
+class CcFs8(_Base):
+    """ohd/cc_fs8.py: theta = (H0, Om, sigma8, f_cc, f_fs8, w0).  Cosmic chronometers and growth-rate data, each with its own
+    error-rescale factor; log L = -0.5 (chi2 - 2 N_cc ln f_cc - 2 N_fs8 ln f_fs8) without the constant of the Gaussian
+    normalisation (:137-140: hence logdet = -N_cc ln 2 pi here); the ODE starts at a = 1 / (1 + z_max) (:87); nautilus
+    vectorised callback ``log_likelihood`` (:143-144)."""
+
+    def __init__(self, z_cc, H_cc, cov_cc, fs8_z, fs8_vals, fs8_cov, fs8_fid, *, device=0, devices=None, steps=0):
+        z_top = float(max(np.max(fs8_z), np.max(z_cc)))
+        self.z_max = z_top + 0.1  # :23-24
+        self.engine = LikelihoodEngine(
+            ndim=6, z_max=self.z_max, n_grid=N_GRID, fde=L.CF_FDE_THAWING,
+            params=dict(H0=Param(0), Om=Param(1), s8=Param(2), fcc=Param(3), fs8err=Param(4), w0=Param(5)),
+            cc=dict(z=z_cc, h=H_cc, inv_cov=np.linalg.inv(cov_cc), logdet=-len(z_cc) * np.log(2 * np.pi)),
+            fs8=dict(z=fs8_z, val=fs8_vals, inv_cov=np.linalg.inv(fs8_cov), fid=fs8_fid, a_init=1.0 / (1.0 + z_top), steps=steps),
+            device=device, devices=devices)
+
+    def fs8_theory(self, params):
+        return self.engine.parts(params)["fs8_theory"][0]

@@ -254,6 +254,21 @@ typedef struct cf_desc {
   const double* sn_dir;     /* [n_sn*3] or NULL: unit vectors n_i; then the peculiar velocity of SN i is
                                100 * (n_i . (V, V2, V3)) * sn_step[i] km/s (sn_step = attenuation x survey mask)
                                                                        sn/pantheon_dipole_xyz.py:50-60 */
+
+  /* ---- growth-rate block f sigma_8(z) (n_fs8 = 0 -> absent)  fs8/fs8.py:64-125, bao/desi_cmb_union3_fs8.py:147-207 ----
+   * delta'' = -(3/a + E'/E) delta' + (3/2) Omega_m delta / (a^5 E^2) from a_init (delta = a, delta' = 1) to a = 1, with
+   * Omega_m = slot OM (CF_EZ_LATE_FLAT) or (omega_b + omega_c)/h^2 (CF_EZ_PHYSICAL);
+   * theory_k = (sigma_8 / delta(1)) a_k delta'(a_k) / q_k,  q_k = H(z_k) D_M(z_k) / fs8_fid[k]  (Alcock-Paczynski);
+   * chi2_fs8 = f_err^2 (val - theory)^T inv_cov (val - theory)  and  log L += n_fs8 ln f_err.
+   * The reference integrates with scipy's adaptive RK45 at rtol = 1e-6; here a fixed-step RK4 in ln a (fs8_steps steps,
+   * 0 = default 512): the two agree to the reference's own integration error (~1e-6 relative on theory). */
+  int32_t n_fs8;
+  int32_t fs8_steps;
+  const double* fs8_z;      /* [n_fs8] */
+  const double* fs8_val;    /* [n_fs8] */
+  const double* fs8_inv_cov;/* [n_fs8*n_fs8] */
+  const double* fs8_fid;    /* [n_fs8] H_fid(z_k) D_M,fid(z_k) in the units H(z) D_M(z) has for this descriptor */
+  double fs8_a_init;        /* 10^-2.15 (fs8/fs8.py:79), 10^-2.7 (bao/desi_cmb_union3_fs8.py:168), 1/(1+z_max) (ohd/cc_fs8.py:87) */
 } cf_desc;
 
 typedef struct cf_info {
@@ -304,11 +319,12 @@ int cf_eval_device(cf_handle* h, const double* d_theta, int64_t W, double* d_out
  *   dm_obs [W*n_sn]  DM(z_cmb)           sn/pantheon.py:58
  *   mu_corr[W*n_sn]                      sn/pantheon.py:43-49
  *   delta  [W*n_sn]  residual vector     sn/pantheon.py:59-60
- *   chi2_blocks[W*7] (chi2_sn, chi2_bao, chi2_cmb, cmb distance vector[3], chi2_cc)
+ *   chi2_blocks[W*8] (chi2_sn, chi2_bao, chi2_cmb, cmb distance vector[3], chi2_cc, chi2_fs8)
  *                                        bao/desi_cmb_des5y.py:126-141, cmb/data_planck_act_compression.py:200-212
- *   bao_theory[W*n_bao]                  bao/desi_cmb_des5y.py:82-100 */
+ *   bao_theory[W*n_bao]                  bao/desi_cmb_des5y.py:82-100
+ *   fs8_theory[W*n_fs8]                  fs8_theory(a, theta) before the Alcock-Paczynski division, fs8/fs8.py:84-98 */
 int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, double* dm_obs, double* mu_corr,
-                  double* delta, double* chi2_blocks, double* bao_theory);
+                  double* delta, double* chi2_blocks, double* bao_theory, double* fs8_theory);
 
 /* The distance table of W <= 4096 walkers on the reference's grid z_grid = linspace(0, z_max, G): cum_dm[W*G] (the
  * cumulative trapezoid of c/H) and dh[W*G] (c/H at the nodes), host buffers -- the pair that DM_z(params, z) of the

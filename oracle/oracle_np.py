@@ -155,6 +155,8 @@ class Likelihood:
     v: Slot = field(default_factory=Slot)
     rd: Slot = field(default_factory=Slot)
     fcc: Slot = field(default_factory=lambda: Slot(fixed=1.0))
+    s8: Slot = field(default_factory=Slot)      # sigma_8(z = 0) of the growth-rate block
+    fs8err: Slot = field(default_factory=lambda: Slot(fixed=1.0))  # its error-rescale factor f_err
     lin: Slot = field(default_factory=Slot)  # amplitude of the per-SN linear magnitude term (bulk-flow correction)
     v2: Slot = field(default_factory=Slot)   # second / third velocity component of a direction-dependent peculiar velocity
     v3: Slot = field(default_factory=Slot)
@@ -175,6 +177,13 @@ class Likelihood:
     cc_h: Optional[np.ndarray] = None
     cc_inv_cov: Optional[np.ndarray] = None
     cc_logdet: float = 0.0
+    # growth-rate block (fs8/fs8.py): data, covariance (the reference solves with its Cholesky factor or multiplies by the
+    # explicit inverse), fiducial H(z) D_M(z) of the Alcock-Paczynski factor, the a grid handed to solve_ivp as t_eval
+    fs8_z: Optional[np.ndarray] = None
+    fs8_val: Optional[np.ndarray] = None
+    fs8_inv_cov: Optional[np.ndarray] = None
+    fs8_fid: Optional[np.ndarray] = None
+    fs8_a_span: Optional[np.ndarray] = None
     # radiation + massive-neutrino constants of a cmb.data_*_compression module (EZ_PHYSICAL)
     or_h2: float = 0.0
     omnu_h2: float = 0.0
@@ -391,10 +400,81 @@ def chi2_cc(lk: Likelihood, theta) -> float:
     return float(delta @ lk.cc_inv_cov @ delta * lk.fcc.get(theta) ** 2)
 
 
+# ---- growth rate f sigma_8: fs8/fs8.py:26-120, bao/desi_cmb_union3_fs8.py:27-207 ----------------------------------------
+def w_nu_z(lk: Likelihood, z):
+    """Massive-neutrino equation of state, cmb/data_planck_act_compression.py:70-83."""
+    mz_sq = (lk.nu_m0 / (1.0 + z)) ** 2
+    f = [np.sqrt(lk.nu_qs_sq[i] + mz_sq) for i in range(5)]
+    w = lk.nu_ws
+    numerator = w[0] / f[0] + w[1] / f[1] + w[2] / f[2] + w[3] / f[3] + w[4] / f[4]
+    denominator = w[0] * f[0] + w[1] * f[1] + w[2] * f[2] + w[3] * f[3] + w[4] * f[4]
+    return (1 / 3) - (1 / 3) * mz_sq * numerator / denominator
+
+
+def d_fde_dz(lk: Likelihood, z, theta):
+    """d f_DE / dz = f_DE * 3 (1 + w(z)) / (1 + z), fs8/fs8.py:26-41 for the thawing form."""
+    if lk.fde == FDE_LCDM:
+        return 0.0
+    w0 = lk.w0.get(theta)
+    if lk.fde == FDE_WCDM:
+        w = w0
+    elif lk.fde == FDE_THAWING:
+        w = -1.0 + 2 * (1.0 + w0) / (1.0 + w0 + (1.0 - w0) * (1.0 + z) ** 3)
+    else:
+        w = w0 + lk.wa.get(theta) * z / (1.0 + z)
+    return f_de(lk, z, theta) * 3 * (1.0 + w) / (1.0 + z)
+
+
+def growth_ODE(a, y, lk: Likelihood, theta):
+    """fs8/fs8.py:64-76 (E form) and bao/desi_cmb_union3_fs8.py:127-165 (H form): the same equation."""
+    z = 1 / a - 1.0
+    H0 = lk.H0.get(theta)
+    H_val = H_z(lk, z, theta)
+    if lk.ez_model == EZ_LATE_FLAT:
+        Om = lk.Om.get(theta)
+        if lk.om_mode:
+            Om = Om / (H0 / 100) ** 2
+        numerator = 3 * Om * (1.0 + z) ** 2 + (1.0 - Om) * d_fde_dz(lk, z, theta)
+        om_growth = Om
+    else:
+        h = H0 / 100
+        Obc = (lk.obh2.get(theta) + lk.och2.get(theta)) / h**2
+        Or, Onu = lk.or_h2 / h**2, lk.omnu_h2 / h**2
+        Ode = 1.0 - Obc - Or - Onu
+        d_Omnu_dz = Omnu_z(lk, z) * 3 * (1.0 + w_nu_z(lk, z)) / (1.0 + z)
+        numerator = 3 * Obc * (1.0 + z) ** 2 + 4 * Or * (1.0 + z) ** 3 + Onu * d_Omnu_dz + Ode * d_fde_dz(lk, z, theta)
+        om_growth = Obc
+    dH_da = -numerator * H0**2 / (2 * H_val / (1.0 + z) ** 2)
+    delta, d_delta_da = y
+    source = 1.5 * om_growth * (H0 / H_val) ** 2 * delta / a**5
+    friction = -(3 / a + dH_da / H_val) * d_delta_da
+    return [d_delta_da, source + friction]
+
+
+def fs8_theory(lk: Likelihood, theta, rtol=1e-6, atol=1e-8, method="RK45"):
+    """fs8/fs8.py:84-98: scipy's adaptive integrator with the reference's tolerances, PCHIP of delta' at the data points."""
+    from scipy.integrate import solve_ivp
+
+    a_span = lk.fs8_a_span
+    sol = solve_ivp(growth_ODE, t_span=(a_span[0], a_span[-1]), y0=(a_span[0], 1.0), t_eval=a_span, rtol=rtol, atol=atol,
+                    method=method, args=(lk, np.asarray(theta, dtype=np.float64)))
+    delta, d_delta_da = sol.y
+    a = 1 / (1.0 + lk.fs8_z)
+    return (lk.s8.get(theta) / delta[-1]) * a * interp_pchip(a, a_span, d_delta_da)
+
+
+def chi2_fs8(lk: Likelihood, theta, tables=None, **ivp) -> float:
+    """fs8/fs8.py:111-120: Alcock-Paczynski factor q = H D_M / (H D_M)_fid, chi2 = f_err^2 delta C^-1 delta."""
+    cum_dm, dh_grid = tables if tables is not None else dm_grid(lk, theta)
+    q = H_z(lk, lk.fs8_z, theta) * interp_hermite(lk.fs8_z, lk.z_grid, cum_dm, dh_grid) / lk.fs8_fid
+    delta = lk.fs8_val - fs8_theory(lk, theta, **ivp) / q
+    return float(lk.fs8err.get(theta) ** 2 * (delta @ lk.fs8_inv_cov @ delta))
+
+
 def chi2_blocks(lk: Likelihood, theta):
     """(sn, bao, cmb) blocks + Gaussian chi^2 terms; bao/desi_cmb_des5y.py:138-141."""
     theta = np.asarray(theta, dtype=np.float64)
-    tables = dm_grid(lk, theta) if (lk.z_cmb is not None or lk.bao_z is not None) else None
+    tables = dm_grid(lk, theta) if (lk.z_cmb is not None or lk.bao_z is not None) else None  # (the growth block builds its own)
     sn = bao = cmb = 0.0
     if lk.z_cmb is not None:
         *_, delta = sn_parts(lk, theta, tables)
@@ -413,6 +493,8 @@ def chi_squared(lk: Likelihood, theta) -> float:
     total = cmb + bao + sn
     if lk.cc_z is not None:
         total += chi2_cc(lk, theta)
+    if lk.fs8_z is not None:
+        total += chi2_fs8(lk, theta)
     for idx, mean, sigma in lk.chi2_gauss:
         total += (theta[idx] - mean) ** 2 / sigma**2
     return total
@@ -423,6 +505,8 @@ def log_likelihood(lk: Likelihood, theta) -> float:
     if lk.cpl_wall and lk.w0.get(theta) + lk.wa.get(theta) >= 0.0:
         return -1e8  # bao/desi_fs_lya_cmb.py:118-121
     ll = -0.5 * chi_squared(lk, theta)
+    if lk.fs8_z is not None:  # fs8/fs8.py:123-125: -0.5 (chi2 - 2 N ln f_err)
+        ll += len(lk.fs8_z) * np.log(lk.fs8err.get(theta))
     if lk.cc_z is not None:  # bao/desi_union3_cc_theta_star.py:135-139
         n_cc = len(lk.cc_z)
         ll -= 0.5 * (n_cc * np.log(2 * np.pi) + lk.cc_logdet - 2 * n_cc * np.log(lk.fcc.get(theta)))

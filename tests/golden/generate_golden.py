@@ -691,6 +691,86 @@ def case_bao_desi_cmb_des5y_cpl():
     print("bao_desi_cmb_des5y_cpl.npz chi2[-2:] =", out["chi2"][-2:], "(LCDM row must equal the as-shipped fixture's)")
 
 
+def _tight_fs8_theory(m, a, a_span, sig8, args):
+    """f sigma_8 theory from the module's OWN growth_ODE integrated at rtol 1e-12 instead of the script's 1e-6: what the
+    script's number converges to.  Quantifies the reference's integration error and pins the GPU's fixed-step RK4."""
+    from scipy.integrate import solve_ivp
+
+    sol = solve_ivp(m.growth_ODE, t_span=(a_span[0], a_span[-1]), y0=(a_span[0], 1.0), t_eval=a_span, rtol=1e-12, atol=1e-14,
+                    method="DOP853", args=args)
+    delta, d_delta_da = sol.y
+    import interpolator as ip
+    return (sig8 / delta[-1]) * a * ip.interp_pchip(a, a_span, d_delta_da)
+
+
+def case_fs8_fs8():
+    """fs8/fs8.py: growth-rate data alone; theta = (Om, sigma8, w0, f_err), late-time flat + thawing dark energy, growth ODE
+    by solve_ivp(rtol=1e-6), Alcock-Paczynski factor, chi2 = f_err^2 ||L^-1 delta||^2, log L with the N ln f_err term."""
+    _enter_reference()
+    import fs8.fs8 as m
+
+    rng = np.random.default_rng(41)
+    thetas = theta_batch(m.bounds, 12, rng)
+    thetas = np.vstack([thetas, [[0.3, 0.8, -0.99, 1.0], [0.27, 0.77, -0.8, 1.9]]])
+    fin = np.array([np.isfinite(m.log_prior(t)) for t in thetas])
+    out = dict(fs8_z=m.z_vals, fs8_val=m.fs8_vals, fs8_cov=m.fs8_data.cov_mat, fs8_fid=m.Ez_DMz_fid, a_span=m.a_span,
+               z_max=np.float64(m.z_grid[-1]), bounds=m.bounds, thetas=thetas, c=np.float64(m.c),
+               chi2=np.array([m.chi_squared(t) if f else np.nan for t, f in zip(thetas, fin)]),
+               logl=np.array([m.log_likelihood(t) if f else np.nan for t, f in zip(thetas, fin)]),
+               logp=np.array([m.log_probability(t) for t in thetas]),
+               theory=np.array([m.fs8_theory(m.a_vals, t[0], t[1], t[2]) for t in thetas[:4]]),
+               theory_tight=np.array([_tight_fs8_theory(m, m.a_vals, m.a_span, t[1], (t[0], t[2])) for t in thetas[:4]]),
+               q=np.array([m.AP_factor(m.z_vals, t[0], t[2]) for t in thetas[:4]]))
+    np.savez_compressed(os.path.join(HERE, "fs8_fs8.npz"), **out)
+    print("fs8_fs8.npz N =", m.N, "chi2[-2:] =", out["chi2"][-2:],
+          "reference's own integration error on theory: %.2e" % np.max(np.abs(out["theory"] / out["theory_tight"] - 1)))
+
+
+def case_bao_desi_cmb_union3_fs8():
+    """bao/desi_cmb_union3_fs8.py: Union3.1 SN (explicit inverse) + DESI BAO + Planck/ACT CMB + growth-rate data in the
+    physical-density LCDM model (radiation and massive neutrinos enter dH/da, :127-145); theta = (dM, H0, wb, wc, v, sigma8).
+    All data real."""
+    _enter_reference()
+    import bao.desi_cmb_union3_fs8 as m
+
+    cmb = m.cmb
+    rng = np.random.default_rng(42)
+    box = [(-1.0, 1.0), (50.0, 90.0), (0.01, 0.03), (0.05, 0.25), (-8.0, 8.0), (0.5, 1.1)]
+    thetas = np.vstack([_uniform(box, 10, rng), [[0.0, 67.5, 0.0224, 0.119, 0.0, 0.8], [0.02, 68.2, 0.0225, 0.118, -2.0, 0.75]]])
+    out = _bao_inputs(m.bao_data, m.cov_matrix_bao, m.desi_qty, m.inv_cov_bao)
+    out.update(_cmb_consts(cmb))
+    out.update(z_cmb=m.z_cmb, z_hel=m.z_hel, obs=m.mu_values, cov_sn=m.cov_matrix_sn, fs8_z=m.z_fs8, fs8_val=m.fs8_vals,
+               fs8_cov=m.fs8.cov_mat, fs8_fid=m.Hz_DMz_fid, a_span=m.a_span, z_max=np.float64(m.z_grid[-1]), thetas=thetas,
+               chi2=np.array([m.chi_squared(t) for t in thetas]), logl=np.array([m.log_likelihood(t) for t in thetas]),
+               chi2_parts=np.array([[m.chi2_sn(t), m.chi2_bao(t), m.chi2_cmb(t), m.chi2_fs8(t)] for t in thetas]),
+               theory=np.array([m.fs8_theory(m.a_fs8, t) for t in thetas[:3]]),
+               theory_tight=np.array([_tight_fs8_theory(m, m.a_fs8, m.a_span, t[-1], (t,)) for t in thetas[:3]]))
+    np.savez_compressed(os.path.join(HERE, "bao_desi_cmb_union3_fs8.npz"), **out)
+    print("bao_desi_cmb_union3_fs8.npz chi2[-2:] =", out["chi2"][-2:],
+          "reference's own integration error on theory: %.2e" % np.max(np.abs(out["theory"] / out["theory_tight"] - 1)))
+
+
+def case_ohd_cc_fs8():
+    """ohd/cc_fs8.py: cosmic chronometers (f_cc) + growth-rate data (f_fs8), late-time flat thawing; theta = (H0, Om, sigma8,
+    f_cc, f_fs8, w0); the ODE starts at a = 1 / (1 + z_max) (:87); nautilus vectorised callback (float64, :143-144)."""
+    _enter_reference()
+    import ohd.cc_fs8 as m
+
+    rng = np.random.default_rng(43)
+    box = [(35.0, 100.0), (0.05, 0.6), (0.2, 1.5), (0.05, 3.0), (0.05, 3.0), (-1.0, 0.0)]  # main() (:156-161)
+    thetas = np.vstack([_uniform(box, 12, rng), [[68.0, 0.3, 0.8, 1.0, 1.0, -1.0]]])
+    out = dict(cc_z=m.z_cc, cc_h=m.H_values, cc_cov=m.cov_matrix,
+               fs8_z=m.z_fs8, fs8_val=m.fs8_values, fs8_cov=m.fs8.cov_mat, fs8_fid=m.Hz_DMz_fid, a_span=m.a_span,
+               z_max=np.float64(m.z_grid[-1]), thetas=thetas, chi2=np.array([m.chi_squared(t) for t in thetas]),
+               chi2_parts=np.array([[m.chi2_cc(t), m.chi2_fs8(t)] for t in thetas]),
+               logl=np.array([m.log_likelihood_single(t) for t in thetas]), logl_vec=m.log_likelihood(thetas),
+               theory=np.array([m.fs8_theory(m.a_vals_fs8, t) for t in thetas[:3]]),
+               theory_tight=np.array([_tight_fs8_theory(m, m.a_vals_fs8, m.a_span, t[2], (t,)) for t in thetas[:3]]))
+    np.savez_compressed(os.path.join(HERE, "ohd_cc_fs8.npz"), **out)
+    print("ohd_cc_fs8.npz chi2[-2:] =", out["chi2"][-2:],
+          "reference's own integration error on theory: %.2e" % np.max(np.abs(out["theory"] / out["theory_tight"] - 1)))
+
+
 CASES = {
     "interpolator": case_interpolator,
     "sn_pantheon": case_sn_pantheon,
@@ -715,6 +795,9 @@ CASES = {
     "bao_desi_cmb_pantheon_H0trgb": case_bao_desi_cmb_pantheon_h0trgb,
     "sn_pantheon_dipole_xyz": case_sn_pantheon_dipole_xyz,
     "bao_desi_cmb_des5y_cpl": case_bao_desi_cmb_des5y_cpl,
+    "fs8_fs8": case_fs8_fs8,
+    "bao_desi_cmb_union3_fs8": case_bao_desi_cmb_union3_fs8,
+    "ohd_cc_fs8": case_ohd_cc_fs8,
 }
 
 if __name__ == "__main__":

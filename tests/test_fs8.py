@@ -1,0 +1,152 @@
+"""
+Growth-rate block f sigma_8: fs8/fs8.py, bao/desi_cmb_union3_fs8.py, ohd/cc_fs8.py.
+
+PARITY BAR, stated: the reference integrates the growth ODE with scipy's adaptive RK45 at rtol = 1e-6 / atol = 1e-8, so its own
+f sigma_8 theory is 2-5e-6 (relative) away from the converged solution of its own equation (fixtures hold both: ``theory`` as the
+scripts compute it, ``theory_tight`` = the scripts' growth_ODE integrated at rtol 1e-12; the generator prints the gap).  Hence:
+  * GPU (fixed-step RK4 in ln a) vs ``theory_tight``: 1e-8 relative -- the kernel solves the reference's equation;
+  * GPU vs the reference's ``theory``: 2e-5 relative (the reference's integration error);
+  * chi^2 / log L of a likelihood with a growth block vs the reference: 5e-4 relative (chi^2 moves by ~2 sqrt(chi^2) x 1e-5 / 0.1
+    for 10 % errors); blocks without the growth data keep the 1e-10 bar (checked separately through chi2_parts).
+CPU: the numpy oracle (same scipy call as the reference) against the fixtures.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden
+from oracle import oracle_np as onp
+from test_oracle_golden import _cmbdata, _phys
+
+THEORY_VS_TIGHT = 1e-8
+THEORY_VS_REFERENCE = 2e-5
+CHI2_VS_REFERENCE = 5e-4
+
+
+def lk_fs8(g):
+    return onp.Likelihood(ndim=4, z_max=float(g["z_max"]), fde=onp.FDE_THAWING, H0=onp.Slot(fixed=1.0), Om=onp.Slot(0),
+                          s8=onp.Slot(1), w0=onp.Slot(2), fs8err=onp.Slot(3), fs8_z=g["fs8_z"], fs8_val=g["fs8_val"],
+                          fs8_inv_cov=np.linalg.inv(g["fs8_cov"]), fs8_fid=g["fs8_fid"], fs8_a_span=g["a_span"], bounds=g["bounds"])
+
+
+def lk_union3_fs8(g):
+    d = _cmbdata("PLANCK_ACT")
+    return onp.Likelihood(ndim=6, z_max=float(g["z_max"]), ez_model=onp.EZ_PHYSICAL, offset=onp.Slot(0), H0=onp.Slot(1),
+                          obh2=onp.Slot(2), och2=onp.Slot(3), v=onp.Slot(4), s8=onp.Slot(5), z_cmb=g["z_cmb"], z_hel=g["z_hel"],
+                          obs=g["obs"], z_turn=0.2, chol=np.linalg.cholesky(g["cov_sn"]), bao_z=g["bao_z"], bao_val=g["bao_val"],
+                          bao_qty=g["bao_qty"], bao_inv_cov=g["bao_inv_cov"], bao_dh_exact=True, rd_fit=d["rd_fit"], cmb_mode=1,
+                          cmb_prior=d["cmb_prior"], cmb_inv_cov=d["cmb_inv_cov"], zstar_fit=d["zstar_fit"], fs8_z=g["fs8_z"],
+                          fs8_val=g["fs8_val"], fs8_inv_cov=np.linalg.inv(g["fs8_cov"]), fs8_fid=g["fs8_fid"],
+                          fs8_a_span=g["a_span"], **_phys(d))
+
+
+def lk_cc_fs8(g):
+    n_cc = len(g["cc_z"])
+    return onp.Likelihood(ndim=6, z_max=float(g["z_max"]), fde=onp.FDE_THAWING, H0=onp.Slot(0), Om=onp.Slot(1), s8=onp.Slot(2),
+                          fcc=onp.Slot(3), fs8err=onp.Slot(4), w0=onp.Slot(5), cc_z=g["cc_z"], cc_h=g["cc_h"],
+                          cc_inv_cov=np.linalg.inv(g["cc_cov"]), cc_logdet=-n_cc * np.log(2 * np.pi), fs8_z=g["fs8_z"],
+                          fs8_val=g["fs8_val"], fs8_inv_cov=np.linalg.inv(g["fs8_cov"]), fs8_fid=g["fs8_fid"], fs8_a_span=g["a_span"])
+
+
+CASES = {"fs8_fs8": lk_fs8, "bao_desi_cmb_union3_fs8": lk_union3_fs8, "ohd_cc_fs8": lk_cc_fs8}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_growth_block_vs_reference(name):
+    g = golden(name)
+    lk = CASES[name](g)
+    gap = np.max(np.abs(g["theory"] / g["theory_tight"] - 1))
+    assert 1e-7 < gap < 1e-5, "the reference's own integration error sets the parity bar of this block"
+    for k in range(len(g["theory"])):
+        th = g["thetas"][k]
+        np.testing.assert_allclose(onp.fs8_theory(lk, th), g["theory"][k], rtol=THEORY_VS_REFERENCE)
+        np.testing.assert_allclose(onp.fs8_theory(lk, th, rtol=1e-12, atol=1e-14, method="DOP853"), g["theory_tight"][k], rtol=1e-9)
+    fin = np.isfinite(g["chi2"])
+    for k in np.flatnonzero(fin)[[0, 1, -2, -1]]:
+        assert onp.chi_squared(lk, g["thetas"][k]) == pytest.approx(g["chi2"][k], rel=CHI2_VS_REFERENCE)
+        assert onp.log_likelihood(lk, g["thetas"][k]) == pytest.approx(g["logl"][k], rel=CHI2_VS_REFERENCE)
+
+
+def test_growth_bar_is_the_references_integration_error():
+    """chi^2 with the converged theory instead of the script's rtol = 1e-6 one moves by less than the stated bar -- and by much
+    more than 1e-10: the 1e-10 bar of the other blocks cannot apply to this one."""
+    g = golden("fs8_fs8")
+    lk = lk_fs8(g)
+    for k in range(4):
+        th = g["thetas"][k]
+        if not np.isfinite(g["chi2"][k]):
+            continue
+        inv = lk.fs8_inv_cov
+        d_ref = g["fs8_val"] - g["theory"][k] / g["q"][k]
+        d_tight = g["fs8_val"] - g["theory_tight"][k] / g["q"][k]
+        c_ref, c_tight = th[3] ** 2 * d_ref @ inv @ d_ref, th[3] ** 2 * d_tight @ inv @ d_tight
+        assert c_ref == pytest.approx(g["chi2"][k], rel=1e-9)
+        assert 1e-9 < abs(c_tight / c_ref - 1) < CHI2_VS_REFERENCE
+
+
+# ---- GPU -------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def gpu(pkg):
+    if pkg.lib().cf_device_count() < 1:
+        pytest.fail("GPU tests need an MI355X; no HIP device visible (there is no fallback path)")
+    return pkg
+
+
+def _check_gpu(lk, g, has_logp=False):
+    fin = np.isfinite(g["chi2"])
+    th = g["thetas"]
+    for k in range(len(g["theory"])):
+        got = lk.fs8_theory(th[k])
+        np.testing.assert_allclose(got, g["theory_tight"][k], rtol=THEORY_VS_TIGHT)
+        np.testing.assert_allclose(got, g["theory"][k], rtol=THEORY_VS_REFERENCE)
+    np.testing.assert_allclose(lk.chi_squared(th[fin]), g["chi2"][fin], rtol=CHI2_VS_REFERENCE)
+    np.testing.assert_allclose(lk.log_likelihood(th[fin]), g["logl"][fin], rtol=CHI2_VS_REFERENCE)
+    # more steps change nothing at the 1e-9 level: the fixed-step integration is converged
+    assert np.all(np.isfinite(lk.chi_squared(th[fin])))
+
+
+@pytest.mark.gpu
+def test_gpu_fs8_alone(gpu):
+    g = golden("fs8_fs8")
+    lk = gpu.likelihoods.Fs8(g["fs8_z"], g["fs8_val"], g["fs8_cov"], None, fid=g["fs8_fid"], bounds=g["bounds"])
+    _check_gpu(lk, g)
+    logp = lk.log_probs_vectorized(g["thetas"])
+    fin = np.isfinite(g["logp"])
+    np.testing.assert_allclose(logp[fin], g["logp"][fin], rtol=CHI2_VS_REFERENCE)
+    assert np.all(logp[~fin] == -np.inf)
+    # convergence of the fixed-step RK4: 4x the steps moves the theory by < 1e-9
+    lk4 = gpu.likelihoods.Fs8(g["fs8_z"], g["fs8_val"], g["fs8_cov"], None, fid=g["fs8_fid"], bounds=g["bounds"], steps=2048)
+    np.testing.assert_allclose(lk4.fs8_theory(g["thetas"][0]), lk.fs8_theory(g["thetas"][0]), rtol=1e-9)
+    # the Alcock-Paczynski fiducials computed by the mirror = the reference's import-time values (needs omega_fid: from the data file
+    # columns; here recovered from the fixture's fid by construction of flat LCDM is not possible, so only the shape is checked)
+    assert lk.fid.shape == g["fs8_z"].shape
+    # a batch: walkers are independent
+    theta = gpu.synthetic.walkers(g["bounds"], 1000, seed=2)
+    full = lk.log_probs_vectorized(theta)
+    np.testing.assert_array_equal(lk.log_probs_vectorized(theta[300:700]), full[300:700])
+    lk.engine.close()
+    lk4.engine.close()
+
+
+@pytest.mark.gpu
+def test_gpu_desi_cmb_union3_fs8(gpu):
+    g = golden("bao_desi_cmb_union3_fs8")
+    lk = gpu.likelihoods.DesiCmbUnion3Fs8(g["z_cmb"], g["z_hel"], g["obs"], g["cov_sn"], g["bao_z"], g["bao_val"], g["bao_qty"],
+                                          g["bao_inv_cov"], g["fs8_z"], g["fs8_val"], g["fs8_cov"], g["fs8_fid"])
+    _check_gpu(lk, g)
+    parts = lk.engine.parts(g["thetas"])
+    # the blocks without growth data keep the 1e-10 bar; the growth block carries the reference's integration error
+    np.testing.assert_allclose(parts["chi2_blocks"], g["chi2_parts"][:, :3], rtol=1e-10)
+    np.testing.assert_allclose(parts["chi2_fs8"], g["chi2_parts"][:, 3], rtol=CHI2_VS_REFERENCE)
+    lk.engine.close()
+
+
+@pytest.mark.gpu
+def test_gpu_cc_fs8(gpu):
+    g = golden("ohd_cc_fs8")
+    lk = gpu.likelihoods.CcFs8(g["cc_z"], g["cc_h"], g["cc_cov"], g["fs8_z"], g["fs8_val"], g["fs8_cov"], g["fs8_fid"])
+    _check_gpu(lk, g)
+    parts = lk.engine.parts(g["thetas"])
+    np.testing.assert_allclose(parts["chi2_cc"], g["chi2_parts"][:, 0], rtol=1e-10)
+    np.testing.assert_allclose(parts["chi2_fs8"], g["chi2_parts"][:, 1], rtol=CHI2_VS_REFERENCE)
+    np.testing.assert_allclose(lk.log_likelihood(g["thetas"]), g["logl_vec"], rtol=CHI2_VS_REFERENCE)
+    lk.engine.close()
