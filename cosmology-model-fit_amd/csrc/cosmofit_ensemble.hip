@@ -8,7 +8,8 @@
 //
 // Random numbers are counter-based (splitmix64 finaliser keyed by walker id, step, half and stream), bit-identical
 // to cosmology-model-fit_amd/ensemble.py's uniform01 / normal01: a chain does not depend on how walkers are sharded.
-// Walkers with an even / odd GLOBAL index form the two halves; the complementary set of half h is the other parity.
+// The two halves: walker 2c + b belongs to half b ^ flip_c, flip_c = 0 (fixed even / odd parity halves) or a counter-based
+// random bit per pair and step (split_key != 0); the complementary set of half h is the other member of every pair.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -39,15 +40,24 @@ __device__ __forceinline__ double ens_normal(uint64_t key0, int stream, int64_t 
   return sqrt(-2.0 * log(u1)) * cos((2.0 * 3.14159265358979323846) * u2);
 }
 
-// row c of the complementary set of half `half`
-__device__ __forceinline__ const double* comp_row(const double* all_pos, int ndim, int half, int64_t c) {
-  return all_pos + (2 * c + (1 - half)) * ndim;
+// 0 / 1 per walker pair c: this step's flip of the pair (2c, 2c + 1) between the two halves; split_key == 0 keeps the fixed
+// even / odd parity halves.  The top bit of the same two-round hash as ens_uniform (ensemble.py: _pair_flips).
+__device__ __forceinline__ int ens_flip(uint64_t split_key, int64_t c) {
+  if (split_key == 0) return 0;
+  uint64_t x = ens_mix((uint64_t)c * 0x9E3779B97F4A7C15ull + split_key);
+  x = ens_mix(x + 0x9E3779B97F4A7C15ull);
+  return (int)(x >> 63);
+}
+
+// row c of the complementary set of half `half`: walker 2c + ((1 - half) ^ flip_c)
+__device__ __forceinline__ const double* comp_row(const double* all_pos, int ndim, int half, uint64_t split_key, int64_t c) {
+  return all_pos + (2 * c + ((1 - half) ^ ens_flip(split_key, c))) * ndim;
 }
 
 // ---- KDE (scipy.stats.gaussian_kde, bw_method="silverman", as emcee's KDEMove uses it) -----------------
 // params = { chol[d*d] (lower), chol_inv_t[d*d], log_norm }, wc = comp @ chol_inv_t  [nc * d]
 extern "C" __global__ void __launch_bounds__(256)
-ens_kde_prepare_kernel(const double* __restrict__ all_pos, int64_t nc, int ndim, int half, double* __restrict__ params,
+ens_kde_prepare_kernel(const double* __restrict__ all_pos, int64_t nc, int ndim, int half, uint64_t split_key, double* __restrict__ params,
                        double* __restrict__ wc) {
   __shared__ double red[256];
   __shared__ double mean[CF_ENS_MAX_NDIM], cov[CF_ENS_MAX_NDIM * CF_ENS_MAX_NDIM], chol[CF_ENS_MAX_NDIM * CF_ENS_MAX_NDIM],
@@ -66,7 +76,7 @@ ens_kde_prepare_kernel(const double* __restrict__ all_pos, int64_t nc, int ndim,
   };
   for (int k = 0; k < d; ++k) {
     double s = 0.0;
-    for (int64_t c = tid; c < nc; c += 256) s += comp_row(all_pos, d, half, c)[k];
+    for (int64_t c = tid; c < nc; c += 256) s += comp_row(all_pos, d, half, split_key, c)[k];
     const double tot = block_sum(s);
     if (tid == 0) mean[k] = tot / (double)nc;
   }
@@ -76,7 +86,7 @@ ens_kde_prepare_kernel(const double* __restrict__ all_pos, int64_t nc, int ndim,
     for (int b = 0; b <= a; ++b) {
       double s = 0.0;
       for (int64_t c = tid; c < nc; c += 256) {
-        const double* r = comp_row(all_pos, d, half, c);
+        const double* r = comp_row(all_pos, d, half, split_key, c);
         s += (r[a] - mean[a]) * (r[b] - mean[b]);
       }
       const double tot = block_sum(s);
@@ -113,7 +123,7 @@ ens_kde_prepare_kernel(const double* __restrict__ all_pos, int64_t nc, int ndim,
   }
   __syncthreads();
   for (int64_t c = tid; c < nc; c += 256) {
-    const double* r = comp_row(all_pos, d, half, c);
+    const double* r = comp_row(all_pos, d, half, split_key, c);
     for (int m = 0; m < d; ++m) {
       double s = 0.0;
       for (int k = 0; k < d; ++k) s += r[k] * inv_t[k * d + m];
@@ -196,7 +206,8 @@ ens_kde_logfactor_kernel(const double* __restrict__ all_pos, int64_t nc, int ndi
 // proposal from the Gaussian KDE of the complementary set).  y[i] = proposal of active walker i, log_factor[i] = log of
 // the Hastings factor.
 extern "C" __global__ void __launch_bounds__(256)
-ens_propose_kernel(int kind, const double* __restrict__ all_pos, int64_t nc, int ndim, int half, const int64_t* __restrict__ ids,
+ens_propose_kernel(int kind, const double* __restrict__ all_pos, int64_t nc, int ndim, int half, uint64_t split_key,
+                   const int64_t* __restrict__ ids,
                    int64_t n_active, uint64_t key0, double a, double de_sigma, const double* __restrict__ kde_params,
                    const double* __restrict__ kde_wc, double* __restrict__ y, double* __restrict__ log_factor) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -206,7 +217,7 @@ ens_propose_kernel(int kind, const double* __restrict__ all_pos, int64_t nc, int
   const double* xa = all_pos + id * d;
   int64_t j = (int64_t)(ens_uniform(key0, 0, id) * (double)nc);
   j = j > nc - 1 ? nc - 1 : j;
-  const double* cj = comp_row(all_pos, d, half, j);
+  const double* cj = comp_row(all_pos, d, half, split_key, j);
   if (kind == 0) {
     const double t = (a - 1.0) * ens_uniform(key0, 1, id) + 1.0;
     const double z = t * t / a;
@@ -216,7 +227,7 @@ ens_propose_kernel(int kind, const double* __restrict__ all_pos, int64_t nc, int
     int64_t k2 = (int64_t)(ens_uniform(key0, 1, id) * (double)(nc - 1));
     k2 = k2 > nc - 2 ? nc - 2 : k2;
     k2 += k2 >= j ? 1 : 0;
-    const double* ck = comp_row(all_pos, d, half, k2);
+    const double* ck = comp_row(all_pos, d, half, split_key, k2);
     const double gamma = (2.38 / sqrt(2.0 * d)) * (1.0 + de_sigma * ens_normal(key0, 3, id));
     for (int k = 0; k < d; ++k) y[i * d + k] = xa[k] + gamma * (cj[k] - ck[k]);
     log_factor[i] = 0.0;
@@ -262,18 +273,18 @@ static int ens_check(int64_t w_total, int32_t ndim, int32_t half, const char* fn
   return 0;
 }
 
-extern "C" int cf_ens_kde_prepare(const double* d_all_pos, int64_t w_total, int32_t ndim, int32_t half, double* d_params,
-                                  double* d_wc, void* hip_stream) {
+extern "C" int cf_ens_kde_prepare(const double* d_all_pos, int64_t w_total, int32_t ndim, int32_t half, uint64_t split_key,
+                                  double* d_params, double* d_wc, void* hip_stream) {
   int rc = ens_check(w_total, ndim, half, "cf_ens_kde_prepare");
   if (rc) return rc;
   if (!d_all_pos || !d_params || !d_wc) return cf_set_error(CF_ERR_INVALID, "cf_ens_kde_prepare: null argument");
   hipLaunchKernelGGL(ens_kde_prepare_kernel, dim3(1), dim3(256), 0, (hipStream_t)hip_stream, d_all_pos, w_total / 2, (int)ndim,
-                     (int)half, d_params, d_wc);
+                     (int)half, split_key, d_params, d_wc);
   return hipGetLastError() == hipSuccess ? CF_OK : cf_set_error(CF_ERR_HIP, "cf_ens_kde_prepare: launch failed");
 }
 
 extern "C" int cf_ens_propose(int32_t kind, const double* d_all_pos, int64_t w_total, int32_t ndim, int32_t half,
-                              const int64_t* d_ids, int64_t n_active, uint64_t key0, double a, double de_sigma,
+                              uint64_t split_key, const int64_t* d_ids, int64_t n_active, uint64_t key0, double a, double de_sigma,
                               const double* d_kde_params, const double* d_kde_wc, double* d_y, double* d_log_factor,
                               void* hip_stream) {
   int rc = ens_check(w_total, ndim, half, "cf_ens_propose");
@@ -283,8 +294,8 @@ extern "C" int cf_ens_propose(int32_t kind, const double* d_all_pos, int64_t w_t
     return cf_set_error(CF_ERR_INVALID, "cf_ens_propose: null argument");
   if (n_active <= 0) return CF_OK;
   hipLaunchKernelGGL(ens_propose_kernel, dim3((unsigned)((n_active + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, (int)kind,
-                     d_all_pos, w_total / 2, (int)ndim, (int)half, d_ids, n_active, key0, a, de_sigma, d_kde_params, d_kde_wc, d_y,
-                     d_log_factor);
+                     d_all_pos, w_total / 2, (int)ndim, (int)half, split_key, d_ids, n_active, key0, a, de_sigma, d_kde_params, d_kde_wc,
+                     d_y, d_log_factor);
   if (kind == 2)
     hipLaunchKernelGGL(ens_kde_logfactor_kernel, dim3((unsigned)((n_active + 3) / 4)), dim3(256), 0, (hipStream_t)hip_stream,
                        d_all_pos, w_total / 2, (int)ndim, d_ids, n_active, d_kde_params, d_kde_wc, (const double*)d_y, d_log_factor);

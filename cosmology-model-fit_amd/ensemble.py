@@ -20,10 +20,16 @@ tests check.
 `log_prob_fn(theta[W, ndim] tensor) -> tensor[W]` is pluggable: on a GPU it is
 ``LikelihoodEngine.torch_log_prob`` (HIP kernels through cf_eval_device on the current stream).
 
-On a GPU the proposal and accept arithmetic runs in the library's own kernels (cf_ens_kde_prepare / cf_ens_propose /
-cf_ens_accept, csrc/cosmofit_ensemble.hip: the same counter-based random numbers and formulae as the tensor code
-below, two or three launches per half-step and no host round trip); the tensor code is the CPU path of the gloo
-tests and the statement of what those kernels compute.
+The proposal and accept arithmetic runs in the library's own kernels (cf_ens_kde_prepare / cf_ens_propose /
+cf_ens_accept, csrc/cosmofit_ensemble.hip: two or three launches per half-step, no host round trip).  This module is
+the DRIVER only: sharding, the all-gather, the step loop, the random-stream keys.  There is no tensor-library fallback:
+an ensemble on CPU tensors needs an explicit ``moves_impl`` -- the test-suite passes ``oracle.moves_torch.TensorMoves``,
+the tensor statement of the same moves, to rehearse the multi-rank logic under gloo and to check the kernels.
+
+Halves.  emcee's RedBlueMove re-draws the two halves every step; here ``randomize_split=True`` (default) flips each
+consecutive pair of walkers (2c, 2c + 1) with a counter-based random bit per step, so the halves change every step
+while every rank still owns exactly half of its walkers in each half (no host round trip, chains independent of the
+number of ranks); ``randomize_split=False`` keeps the even / odd parity classes for the whole run.
 """
 from __future__ import annotations
 
@@ -45,29 +51,15 @@ def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < extra else 0)
 
 
-# ---- counter-based uniform random numbers (splitmix64 finaliser), identical on CPU and GPU -----------------
-_M1 = -7046029254386353131  # 0x9E3779B97F4A7C15 as int64
-_M2 = -4658895280553007687  # 0xBF58476D1CE4E5B9
-_M3 = -7723592293110705685  # 0x94D049BB133111EB
-
-
-def _lsr(x: torch.Tensor, s: int) -> torch.Tensor:
-    """Logical shift right of int64 (torch's >> is arithmetic)."""
-    return (x >> s) & ((1 << (64 - s)) - 1)
-
-
-def _mix(x: torch.Tensor) -> torch.Tensor:
-    x = (x ^ _lsr(x, 30)) * _M2
-    x = (x ^ _lsr(x, 27)) * _M3
-    return x ^ _lsr(x, 31)
-
-
+# ---- random-stream keys (counter-based generator: splitmix64 finaliser, identical in the HIP kernels) ---------------
 _U64 = 0xFFFFFFFFFFFFFFFF
 MAX_STREAMS = 256  # random streams per (seed, step, half): the KDE move uses 4 + 2 ndim + 1 <= 37
+_SPLIT_STREAM = MAX_STREAMS - 2  # key of the per-step pair flips
+_MOVE_STREAM = MAX_STREAMS - 1   # key of the per-step move draw
 
 
 def _mix_int(x: int) -> int:
-    """splitmix64 finaliser on a Python int (the same bijection of 64-bit words as `_mix`)."""
+    """splitmix64 finaliser on a Python int (a bijection of 64-bit words)."""
     x &= _U64
     x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _U64
     x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _U64
@@ -87,32 +79,85 @@ def stream_key(seed: int, step: int, half: int, stream: int = 0) -> int:
     return (base + (half << 8) + stream) & _U64
 
 
-def uniform01(seed: int, step: int, half: int, walker_ids: torch.Tensor, stream: int) -> torch.Tensor:
-    """float64 uniforms in [0, 1), a pure function of its arguments (walker_ids: int64 tensor)."""
-    key = stream_key(seed, step, half, stream)
-    key = key - (1 << 64) if key >= (1 << 63) else key  # as signed int64
-    x = _mix(walker_ids * _M1 + key)
-    x = _mix(x + _M1)
-    return _lsr(x, 11).to(torch.float64) * (1.0 / 9007199254740992.0)
-
-
-def normal01(seed: int, step: int, half: int, walker_ids: torch.Tensor, stream: int) -> torch.Tensor:
-    """Standard normals by Box-Muller from two counter-based uniforms (streams `stream`, `stream + 1`)."""
-    u1 = 1.0 - uniform01(seed, step, half, walker_ids, stream)  # (0, 1]
-    u2 = uniform01(seed, step, half, walker_ids, stream + 1)
-    return torch.sqrt(-2.0 * torch.log(u1)) * torch.cos((2.0 * math.pi) * u2)
+def uniform01_scalar(key: int, counter: int) -> float:
+    """One uniform in [0, 1) for (key, counter): the kernels' ens_uniform on Python ints (the per-step move draw)."""
+    x = _mix_int(((counter & _U64) * 0x9E3779B97F4A7C15 + key) & _U64)
+    x = _mix_int((x + 0x9E3779B97F4A7C15) & _U64)
+    return (x >> 11) * (1.0 / 9007199254740992.0)
 
 
 REFERENCE_MOVES = (("kde", 0.30), ("de", 0.70))  # sn/pantheon.py:114-117
 STRETCH_ONLY = (("stretch", 1.0),)
+_KIND = {"stretch": 0, "de": 1, "kde": 2}
+
+
+class NativeMoves:
+    """The library's kernels on device-resident tensors, asynchronous on torch's current stream."""
+
+    def __init__(self, e):
+        from . import _lib as L
+
+        self.L, self.lib = L, L.lib()  # raises if the HIP library is missing
+        dev, nmax = e.x.device, max(1, (e.stop - e.start + 1) // 2)
+        self.y = torch.empty((nmax, e.ndim), dtype=torch.float64, device=dev)
+        self.logfac = torch.empty(nmax, dtype=torch.float64, device=dev)
+        self.kde_params = torch.empty(2 * e.ndim * e.ndim + 1, dtype=torch.float64, device=dev)
+        self.kde_wc = torch.empty((e.n_total // 2, e.ndim), dtype=torch.float64, device=dev)
+        self.n_acc = torch.zeros(1, dtype=torch.int64, device=dev)
+        # fixed-parity halves of this rank's shard (ragged shards and randomize_split=False)
+        self.fixed = [(e.ids[(e.ids % 2) == h].contiguous(), (e.ids[(e.ids % 2) == h] - e.start).contiguous()) for h in (0, 1)]
+
+    def half_step(self, e, move, half, allpos, split_key):
+        L, lib = self.L, self.lib
+        kind = _KIND[move]
+        stream = torch.cuda.current_stream(e.x.device).cuda_stream
+        if split_key:  # this step's halves: walker 2c + (half ^ flip_c) of every local pair -- elementwise, no host sync
+            from_key = split_key - (1 << 64) if split_key >= (1 << 63) else split_key
+            ids = 2 * e.local_pairs + (half ^ _pair_flips(from_key, e.local_pairs))
+            idx = ids - e.start
+        else:
+            ids, idx = self.fixed[half]
+        n = int(ids.numel())
+        if n == 0:
+            return
+        key0 = stream_key(e.seed, e.step_count, half)
+        if kind == 2:
+            L.check(lib.cf_ens_kde_prepare(allpos.data_ptr(), e.n_total, e.ndim, half, split_key, self.kde_params.data_ptr(),
+                                           self.kde_wc.data_ptr(), stream))
+        y, logfac = self.y[:n], self.logfac[:n]
+        L.check(lib.cf_ens_propose(kind, allpos.data_ptr(), e.n_total, e.ndim, half, split_key, ids.data_ptr(), n, key0,
+                                   float(e.a), float(e.de_sigma), self.kde_params.data_ptr(), self.kde_wc.data_ptr(),
+                                   y.data_ptr(), logfac.data_ptr(), stream))
+        lp_new = e.log_prob_fn(y)
+        L.check(lib.cf_ens_accept(ids.data_ptr(), idx.data_ptr(), n, e.ndim, key0, y.data_ptr(), lp_new.data_ptr(),
+                                  logfac.data_ptr(), e.x.data_ptr(), e.logp.data_ptr(), self.n_acc.data_ptr(), stream))
+        e._n_proposed += n
+
+
+def _pair_flips(signed_key: int, pairs: torch.Tensor) -> torch.Tensor:
+    """0 / 1 per pair index: the top bit of the kernels' two-round hash of (pair, key) (cosmofit_ensemble.hip: ens_flip)."""
+    m1, m2, m3 = -7046029254386353131, -4658895280553007687, -7723592293110705685
+
+    def lsr(x, s):
+        return (x >> s) & ((1 << (64 - s)) - 1)
+
+    def mix(x):
+        x = (x ^ lsr(x, 30)) * m2
+        x = (x ^ lsr(x, 27)) * m3
+        return x ^ lsr(x, 31)
+
+    return lsr(mix(mix(pairs * m1 + signed_key) + m1), 63)
 
 
 class ShardedEnsemble:
     def __init__(self, log_prob_fn: Callable[[torch.Tensor], torch.Tensor], positions: torch.Tensor, *,
-                 seed: int = 42, a: float = 2.0, moves=STRETCH_ONLY, de_sigma: float = 1e-5, group=None):
+                 seed: int = 42, a: float = 2.0, moves=STRETCH_ONLY, de_sigma: float = 1e-5, group=None,
+                 randomize_split: bool = True, moves_impl=None):
         """positions: [W_total, ndim] float64 initial ensemble, identical on every rank (it is sliced here).
-        moves: sequence of (name, weight), name in {"stretch", "de", "kde"}; one is drawn per step."""
-        names = {"stretch", "de", "kde"}
+        moves: sequence of (name, weight), name in {"stretch", "de", "kde"}; one is drawn per step.
+        randomize_split: re-draw the two halves every step (pair flips); needs shards of whole pairs.
+        moves_impl: None = the library's kernels (positions must live on a GPU); tests pass the tensor statement."""
+        names = set(_KIND)
         if not moves or any(m not in names or w <= 0 for m, w in moves):
             raise ValueError(f"moves must be a non-empty sequence of (name in {sorted(names)}, weight > 0)")
         tot = float(sum(w for _, w in moves))
@@ -126,33 +171,31 @@ class ShardedEnsemble:
         if self.n_total % 2:
             raise ValueError("the ensemble needs an even number of walkers (two halves)")
         self.start, self.stop = shard_bounds(self.n_total, self.world, self.rank)
+        counts = [shard_bounds(self.n_total, self.world, r) for r in range(self.world)]
+        whole_pairs = all(a_ % 2 == 0 and b % 2 == 0 for a_, b in counts)
+        if randomize_split and not whole_pairs:
+            raise ValueError("randomize_split needs every rank's shard to hold whole walker pairs (even shard boundaries); "
+                             "use a walker count divisible by 2 x the number of ranks, or randomize_split=False")
+        self.randomize_split = randomize_split
         self.log_prob_fn = log_prob_fn
         self.x = positions[self.start:self.stop].clone().contiguous()
         self.ids = torch.arange(self.start, self.stop, dtype=torch.int64, device=self.x.device)
+        self.local_pairs = (torch.arange(self.start // 2, self.stop // 2, dtype=torch.int64, device=self.x.device)
+                            if whole_pairs else None)
         self.seed, self.a, self.step_count = seed, a, 0
         self.logp = self.log_prob_fn(self.x)
         self._n_accepted = 0
         self._n_proposed = 0
-        counts = [shard_bounds(self.n_total, self.world, r) for r in range(self.world)]
         self._equal = len({b - a_ for a_, b in counts}) == 1
         self._max_local = max(b - a_ for a_, b in counts)
         self._counts = counts
         self._allpos = None
-        # the two halves of this rank's shard: local indices and global ids, fixed for the life of the ensemble
-        self._act_idx = [torch.nonzero((self.ids % 2) == h, as_tuple=False)[:, 0].contiguous() for h in (0, 1)]
-        self._act_ids = [self.ids[i].contiguous() for i in self._act_idx]
-        self._native = self.x.is_cuda
-        if self._native:
-            from . import _lib as L
-
-            self._L = L
-            self._lib = L.lib()  # raises if the HIP library is missing: no silent tensor-code fallback on a GPU
-            dev, nmax = self.x.device, max(int(i.numel()) for i in self._act_idx)
-            self._y = torch.empty((max(nmax, 1), self.ndim), dtype=torch.float64, device=dev)
-            self._logfac = torch.empty(max(nmax, 1), dtype=torch.float64, device=dev)
-            self._kde_params = torch.empty(2 * self.ndim * self.ndim + 1, dtype=torch.float64, device=dev)
-            self._kde_wc = torch.empty((self.n_total // 2, self.ndim), dtype=torch.float64, device=dev)
-            self._n_acc_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        if moves_impl is None:
+            if not self.x.is_cuda:
+                raise RuntimeError("ShardedEnsemble runs its moves in the library's HIP kernels: the positions must be on an "
+                                   "MI355X (there is no tensor-library fallback; tests pass oracle.moves_torch.TensorMoves)")
+            moves_impl = NativeMoves(self)
+        self.impl = moves_impl
 
     # ---- the exchange step ---------------------------------------------------------------------------
     def gather_positions(self) -> torch.Tensor:
@@ -171,52 +214,8 @@ class ShardedEnsemble:
         dist.all_gather_into_tensor(buf, pad, group=self.group)
         return torch.cat([buf[r * self._max_local: r * self._max_local + (b - a_)] for r, (a_, b) in enumerate(self._counts)])
 
-    # ---- proposals: (y [n, ndim], log of the Hastings factor [n]) for the active walkers ----------------
-    def _propose_stretch(self, xa, ids, comp, half):
-        nc = comp.shape[0]
-        j = torch.clamp((uniform01(self.seed, self.step_count, half, ids, 0) * nc).to(torch.int64), max=nc - 1)
-        z = ((self.a - 1.0) * uniform01(self.seed, self.step_count, half, ids, 1) + 1.0) ** 2 / self.a
-        partner = comp[j]
-        return partner + z[:, None] * (xa - partner), (self.ndim - 1) * torch.log(z)
-
-    def _propose_de(self, xa, ids, comp, half):
-        """emcee DEMove: q = s + g0 (1 + sigma N(0,1)) (c_j - c_k), j != k, g0 = 2.38 / sqrt(2 ndim); symmetric."""
-        nc = comp.shape[0]
-        j = torch.clamp((uniform01(self.seed, self.step_count, half, ids, 0) * nc).to(torch.int64), max=nc - 1)
-        k = torch.clamp((uniform01(self.seed, self.step_count, half, ids, 1) * (nc - 1)).to(torch.int64), max=nc - 2)
-        k = k + (k >= j).to(torch.int64)
-        gamma = (2.38 / math.sqrt(2 * self.ndim)) * (1.0 + self.de_sigma * normal01(self.seed, self.step_count, half, ids, 3))
-        return xa + gamma[:, None] * (comp[j] - comp[k]), torch.zeros_like(gamma)
-
-    def _kde_logpdf(self, pts, comp, chol_inv_t, log_norm):
-        """log of the Gaussian-KDE density of `comp` at `pts`; per-element arithmetic only (rank-count invariant)."""
-        out = torch.empty(pts.shape[0], dtype=pts.dtype, device=pts.device)
-        wc = comp @ chol_inv_t  # whitened data, same on every rank
-        chunk = max(1, (1 << 24) // max(1, comp.shape[0] * self.ndim))
-        for a0 in range(0, pts.shape[0], chunk):
-            wp = pts[a0:a0 + chunk] @ chol_inv_t
-            d2 = ((wp[:, None, :] - wc[None, :, :]) ** 2).sum(dim=2)
-            out[a0:a0 + chunk] = torch.logsumexp(-0.5 * d2, dim=1) + log_norm
-        return out
-
-    def _propose_kde(self, xa, ids, comp, half):
-        """emcee KDEMove(bw_method="silverman"): independence proposal from the Gaussian KDE of the complementary
-        set, factor = log kde(s) - log kde(q)."""
-        nc, d = comp.shape
-        h = (nc * (d + 2) / 4.0) ** (-1.0 / (d + 4))  # scipy.stats.gaussian_kde.silverman_factor
-        mean = comp.mean(dim=0)
-        cen = comp - mean
-        cov = (cen.T @ cen) / (nc - 1) * (h * h)
-        chol = torch.linalg.cholesky(cov)
-        chol_inv_t = torch.linalg.inv(chol).T.contiguous()
-        log_norm = -math.log(nc) - 0.5 * d * math.log(2.0 * math.pi) - float(torch.log(torch.diagonal(chol)).sum())
-        j = torch.clamp((uniform01(self.seed, self.step_count, half, ids, 0) * nc).to(torch.int64), max=nc - 1)
-        noise = torch.stack([normal01(self.seed, self.step_count, half, ids, 4 + 2 * k) for k in range(d)], dim=1)
-        q = comp[j] + noise @ chol.T
-        return q, self._kde_logpdf(xa, comp, chol_inv_t, log_norm) - self._kde_logpdf(q, comp, chol_inv_t, log_norm)
-
     def _pick_move(self) -> str:
-        u = float(uniform01(self.seed, self.step_count, 0, torch.tensor([-1], dtype=torch.int64), MAX_STREAMS - 1)[0])
+        u = uniform01_scalar(stream_key(self.seed, self.step_count, 0, _MOVE_STREAM), 0)
         acc = 0.0
         for name, w in self.moves:
             acc += w
@@ -225,60 +224,19 @@ class ShardedEnsemble:
         return self.moves[-1][0]
 
     # ---- one ensemble step = two red/blue half-steps --------------------------------------------------------
-    def _step_native(self, move: str):
-        """One step with the library's kernels: per half-step all-gather -> [KDE fit] -> propose -> log P -> accept,
-        everything asynchronous on the current stream."""
-        L, lib = self._L, self._lib
-        kind = {"stretch": 0, "de": 1, "kde": 2}[move]
-        stream = torch.cuda.current_stream(self.x.device).cuda_stream
-        for half in (0, 1):
-            allpos = self.gather_positions()
-            ids, idx = self._act_ids[half], self._act_idx[half]
-            n = int(ids.numel())
-            if n == 0:
-                continue
-            key0 = stream_key(self.seed, self.step_count, half)
-            if kind == 2:
-                L.check(lib.cf_ens_kde_prepare(allpos.data_ptr(), self.n_total, self.ndim, half, self._kde_params.data_ptr(),
-                                               self._kde_wc.data_ptr(), stream))
-            y, logfac = self._y[:n], self._logfac[:n]
-            L.check(lib.cf_ens_propose(kind, allpos.data_ptr(), self.n_total, self.ndim, half, ids.data_ptr(), n, key0,
-                                       float(self.a), float(self.de_sigma), self._kde_params.data_ptr(), self._kde_wc.data_ptr(),
-                                       y.data_ptr(), logfac.data_ptr(), stream))
-            lp_new = self.log_prob_fn(y)
-            L.check(lib.cf_ens_accept(ids.data_ptr(), idx.data_ptr(), n, self.ndim, key0, y.data_ptr(), lp_new.data_ptr(),
-                                      logfac.data_ptr(), self.x.data_ptr(), self.logp.data_ptr(), self._n_acc_dev.data_ptr(), stream))
-            self._n_proposed += n
-        self.step_count += 1
-
     def step(self):
+        """Per half-step: all-gather -> [KDE fit] -> propose -> log P -> accept; with the library's kernels everything is
+        asynchronous on the current stream."""
         move = self._pick_move()
-        if self._native:
-            return self._step_native(move)
-        propose = {"stretch": self._propose_stretch, "de": self._propose_de, "kde": self._propose_kde}[move]
+        split_key = stream_key(self.seed, self.step_count, 0, _SPLIT_STREAM) if self.randomize_split else 0
         for half in (0, 1):
-            allpos = self.gather_positions()
-            # active set: walkers with global index parity == half; the complementary set is the other parity
-            active = (self.ids % 2) == half
-            if bool(active.any()):
-                ids = self.ids[active]
-                comp = allpos[(1 - half)::2]
-                u_acc = uniform01(self.seed, self.step_count, half, ids, 2)
-                y, log_factor = propose(self.x[active], ids, comp, half)
-                lp_new = self.log_prob_fn(y.contiguous())
-                log_q = log_factor + lp_new - self.logp[active]
-                accept = torch.log(u_acc) < log_q
-                idx = torch.nonzero(active, as_tuple=False)[:, 0][accept]
-                self.x[idx] = y[accept]
-                self.logp[idx] = lp_new[accept]
-                self._n_accepted += int(accept.sum())
-                self._n_proposed += int(active.sum())
+            self.impl.half_step(self, move, half, self.gather_positions(), split_key)
         self.step_count += 1
 
     @property
     def n_accepted(self) -> int:
-        """Accepted moves of this rank's walkers so far (reads the device counter: synchronises)."""
-        return int(self._n_acc_dev.item()) if self._native else self._n_accepted
+        """Accepted moves of this rank's walkers so far (the kernels count on the device: reading synchronises)."""
+        return int(self.impl.n_acc.item()) if isinstance(self.impl, NativeMoves) else self._n_accepted
 
     @property
     def n_proposed(self) -> int:

@@ -1,0 +1,143 @@
+"""
+moves_torch — tensor statement (torch, CPU or GPU tensors) of the ensemble moves the reference configures on emcee.
+
+TEST INFRASTRUCTURE ONLY, like everything under ``oracle/``: the product's moves are the HIP kernels behind
+``cf_ens_kde_prepare / cf_ens_propose / cf_ens_accept`` (cosmology-model-fit_amd/csrc/cosmofit_ensemble.hip), driven by
+``cosmology-model-fit_amd/ensemble.py``.  This module states the same arithmetic with tensor-library calls so that
+  * ``tests/test_gpu_parity.py`` can check the kernels against it (same counter-based random numbers, same formulae), and
+  * the multi-rank logic of the driver (sharding, all-gather, rank-count invariance) can be rehearsed on CPU under gloo
+    (``tests/test_ensemble_gloo.py`` passes ``TensorMoves()`` as the driver's ``moves_impl``).
+
+What is restated (emcee is not installed here, so the pin is the published algorithm + scipy's gaussian_kde):
+  stretch move   Goodman & Weare 2010; emcee ``StretchMove(a=2)``: z ~ g(z) ∝ 1/sqrt(z) on [1/a, a], q = c_j + z (x - c_j),
+                 log factor (ndim - 1) ln z.
+  DE move        emcee ``DEMove``: q = x + g0 (1 + sigma N(0,1)) (c_j - c_k), j != k, g0 = 2.38 / sqrt(2 ndim), sigma = 1e-5.
+  KDE move       emcee ``KDEMove(bw_method="silverman")``: independence proposal from scipy.stats.gaussian_kde of the
+                 complementary set, log factor log kde(x) - log kde(q)          (reference: sn/pantheon.py:114-117).
+  red/blue split two halves updated in turn, each proposing from the other (emcee ``RedBlueMove``); the halves are either the
+                 fixed parity classes of the global walker index or, with a split key, re-drawn every step by flipping
+                 each consecutive pair (2c, 2c + 1) with a counter-based random bit.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+_M1 = -7046029254386353131  # 0x9E3779B97F4A7C15 as int64
+_M2 = -4658895280553007687  # 0xBF58476D1CE4E5B9
+_M3 = -7723592293110705685  # 0x94D049BB133111EB
+
+
+def _lsr(x: torch.Tensor, s: int) -> torch.Tensor:
+    """Logical shift right of int64 (torch's >> is arithmetic)."""
+    return (x >> s) & ((1 << (64 - s)) - 1)
+
+
+def _mix(x: torch.Tensor) -> torch.Tensor:
+    x = (x ^ _lsr(x, 30)) * _M2
+    x = (x ^ _lsr(x, 27)) * _M3
+    return x ^ _lsr(x, 31)
+
+
+def _signed(key: int) -> int:
+    return key - (1 << 64) if key >= (1 << 63) else key
+
+
+def _hash(key: int, ids: torch.Tensor) -> torch.Tensor:
+    x = _mix(ids * _M1 + _signed(key))
+    return _mix(x + _M1)
+
+
+def uniform_from_key(key: int, ids: torch.Tensor) -> torch.Tensor:
+    """float64 uniforms in [0, 1): two splitmix64 rounds of (id, key) -- cosmofit_ensemble.hip: ens_uniform."""
+    return _lsr(_hash(key, ids), 11).to(torch.float64) * (1.0 / 9007199254740992.0)
+
+
+def flips_from_key(split_key: int, pairs: torch.Tensor) -> torch.Tensor:
+    """0 / 1 per walker pair: the top bit of the same hash (0 everywhere for split_key == 0: fixed parity halves)."""
+    if split_key == 0:
+        return torch.zeros_like(pairs)
+    return _lsr(_hash(split_key, pairs), 63)
+
+
+class TensorMoves:
+    """``moves_impl`` of ``ensemble.ShardedEnsemble`` stated with tensor ops; see the module docstring."""
+
+    def __init__(self, stream_key):
+        self.stream_key = stream_key  # ensemble.stream_key: (seed, step, half, stream) -> unsigned 64-bit key
+
+    def uniform01(self, seed, step, half, ids, stream):
+        return uniform_from_key(self.stream_key(seed, step, half, stream), ids)
+
+    def normal01(self, seed, step, half, ids, stream):
+        """Box-Muller from streams `stream`, `stream + 1` (cosmofit_ensemble.hip: ens_normal)."""
+        u1 = 1.0 - self.uniform01(seed, step, half, ids, stream)  # (0, 1]
+        u2 = self.uniform01(seed, step, half, ids, stream + 1)
+        return torch.sqrt(-2.0 * torch.log(u1)) * torch.cos((2.0 * math.pi) * u2)
+
+    # ---- proposals: (y [n, ndim], log Hastings factor [n]) ------------------------------------------------------
+    def propose_stretch(self, e, xa, ids, comp, half):
+        nc = comp.shape[0]
+        j = torch.clamp((self.uniform01(e.seed, e.step_count, half, ids, 0) * nc).to(torch.int64), max=nc - 1)
+        z = ((e.a - 1.0) * self.uniform01(e.seed, e.step_count, half, ids, 1) + 1.0) ** 2 / e.a
+        partner = comp[j]
+        return partner + z[:, None] * (xa - partner), (e.ndim - 1) * torch.log(z)
+
+    def propose_de(self, e, xa, ids, comp, half):
+        nc = comp.shape[0]
+        j = torch.clamp((self.uniform01(e.seed, e.step_count, half, ids, 0) * nc).to(torch.int64), max=nc - 1)
+        k = torch.clamp((self.uniform01(e.seed, e.step_count, half, ids, 1) * (nc - 1)).to(torch.int64), max=nc - 2)
+        k = k + (k >= j).to(torch.int64)
+        gamma = (2.38 / math.sqrt(2 * e.ndim)) * (1.0 + e.de_sigma * self.normal01(e.seed, e.step_count, half, ids, 3))
+        return xa + gamma[:, None] * (comp[j] - comp[k]), torch.zeros_like(gamma)
+
+    @staticmethod
+    def kde_logpdf(pts, comp, chol_inv_t, log_norm):
+        """log of the Gaussian-KDE density of `comp` at `pts`; per-element arithmetic only (rank-count invariant)."""
+        out = torch.empty(pts.shape[0], dtype=pts.dtype, device=pts.device)
+        wc = comp @ chol_inv_t
+        d = comp.shape[1]
+        chunk = max(1, (1 << 24) // max(1, comp.shape[0] * d))
+        for a0 in range(0, pts.shape[0], chunk):
+            wp = pts[a0:a0 + chunk] @ chol_inv_t
+            d2 = ((wp[:, None, :] - wc[None, :, :]) ** 2).sum(dim=2)
+            out[a0:a0 + chunk] = torch.logsumexp(-0.5 * d2, dim=1) + log_norm
+        return out
+
+    def propose_kde(self, e, xa, ids, comp, half):
+        nc, d = comp.shape
+        h = (nc * (d + 2) / 4.0) ** (-1.0 / (d + 4))  # scipy.stats.gaussian_kde.silverman_factor
+        cen = comp - comp.mean(dim=0)
+        cov = (cen.T @ cen) / (nc - 1) * (h * h)
+        chol = torch.linalg.cholesky(cov)
+        chol_inv_t = torch.linalg.inv(chol).T.contiguous()
+        log_norm = -math.log(nc) - 0.5 * d * math.log(2.0 * math.pi) - float(torch.log(torch.diagonal(chol)).sum())
+        j = torch.clamp((self.uniform01(e.seed, e.step_count, half, ids, 0) * nc).to(torch.int64), max=nc - 1)
+        noise = torch.stack([self.normal01(e.seed, e.step_count, half, ids, 4 + 2 * k) for k in range(d)], dim=1)
+        q = comp[j] + noise @ chol.T
+        return q, self.kde_logpdf(xa, comp, chol_inv_t, log_norm) - self.kde_logpdf(q, comp, chol_inv_t, log_norm)
+
+    # ---- one red/blue half-step on the driver's state ---------------------------------------------------------------
+    def half_step(self, e, move, half, allpos, split_key):
+        """Active set: this rank's walkers 2c + (half ^ flip_c); complementary set: the walkers 2c + (1 - half) ^ flip_c of
+        every pair, in pair order (the same order the kernels' comp_row uses)."""
+        all_pairs = torch.arange(e.n_total // 2, dtype=torch.int64, device=allpos.device)
+        comp = allpos[2 * all_pairs + ((1 - half) ^ flips_from_key(split_key, all_pairs))]
+        if e.local_pairs is not None:
+            ids = 2 * e.local_pairs + (half ^ flips_from_key(split_key, e.local_pairs))
+        else:  # ragged shards (fixed parity only)
+            ids = e.ids[(e.ids % 2) == half]
+        if ids.numel() == 0:
+            return
+        li = ids - e.start
+        propose = {"stretch": self.propose_stretch, "de": self.propose_de, "kde": self.propose_kde}[move]
+        u_acc = self.uniform01(e.seed, e.step_count, half, ids, 2)
+        y, log_factor = propose(e, e.x[li], ids, comp, half)
+        lp_new = e.log_prob_fn(y.contiguous())
+        accept = torch.log(u_acc) < log_factor + lp_new - e.logp[li]  # NaN never accepts
+        idx = li[accept]
+        e.x[idx] = y[accept]
+        e.logp[idx] = lp_new[accept]
+        e._n_accepted += int(accept.sum())
+        e._n_proposed += int(ids.numel())

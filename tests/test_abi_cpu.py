@@ -172,14 +172,14 @@ def test_ensemble_entry_points_validate_their_arguments(pkg):
     ids = (C.c_int64 * 8)()
     p = lambda a: C.cast(a, C.c_void_p)
     with pytest.raises(pkg.CosmofitError, match="even number"):
-        L.check(lib.cf_ens_kde_prepare(p(buf), 7, 4, 0, p(buf), p(buf), None))
+        L.check(lib.cf_ens_kde_prepare(p(buf), 7, 4, 0, 0, p(buf), p(buf), None))
     with pytest.raises(pkg.CosmofitError, match="ndim"):
-        L.check(lib.cf_ens_propose(0, p(buf), 8, 17, 0, p(ids), 4, 1, 2.0, 1e-5, None, None, p(buf), p(buf), None))
+        L.check(lib.cf_ens_propose(0, p(buf), 8, 17, 0, 0, p(ids), 4, 1, 2.0, 1e-5, None, None, p(buf), p(buf), None))
     with pytest.raises(pkg.CosmofitError, match="half"):
-        L.check(lib.cf_ens_propose(0, p(buf), 8, 4, 2, p(ids), 4, 1, 2.0, 1e-5, None, None, p(buf), p(buf), None))
+        L.check(lib.cf_ens_propose(0, p(buf), 8, 4, 2, 0, p(ids), 4, 1, 2.0, 1e-5, None, None, p(buf), p(buf), None))
     with pytest.raises(pkg.CosmofitError, match="kind"):
-        L.check(lib.cf_ens_propose(3, p(buf), 8, 4, 0, p(ids), 4, 1, 2.0, 1e-5, None, None, p(buf), p(buf), None))
+        L.check(lib.cf_ens_propose(3, p(buf), 8, 4, 0, 0, p(ids), 4, 1, 2.0, 1e-5, None, None, p(buf), p(buf), None))
     with pytest.raises(pkg.CosmofitError, match="null"):
-        L.check(lib.cf_ens_propose(2, p(buf), 8, 4, 0, p(ids), 4, 1, 2.0, 1e-5, None, None, p(buf), p(buf), None))  # KDE without its fit
+        L.check(lib.cf_ens_propose(2, p(buf), 8, 4, 0, 0, p(ids), 4, 1, 2.0, 1e-5, None, None, p(buf), p(buf), None))  # KDE without its fit
     with pytest.raises(pkg.CosmofitError, match="null"):
         L.check(lib.cf_ens_accept(p(ids), p(ids), 4, 4, 1, p(buf), p(buf), p(buf), p(buf), p(buf), None, None))

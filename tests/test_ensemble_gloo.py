@@ -9,6 +9,12 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from conftest import load_pkg
+from oracle import moves_torch
+
+
+def _tensor_moves():
+    """The tensor statement of the moves (oracle/): the driver has no built-in CPU path."""
+    return moves_torch.TensorMoves(load_pkg().ensemble.stream_key)
 
 
 def _free_port():
@@ -30,10 +36,11 @@ def _init_positions(W):
     return MU + SIG * torch.randn(W, 3, generator=g, dtype=torch.float64)
 
 
-def _worker(rank, world, port, W, steps, path, moves):
+def _worker(rank, world, port, W, steps, path, moves, randomize):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    ens = load_pkg().ensemble.ShardedEnsemble(gauss_logp, _init_positions(W), seed=11, moves=moves)
+    ens = load_pkg().ensemble.ShardedEnsemble(gauss_logp, _init_positions(W), seed=11, moves=moves, randomize_split=randomize,
+                                              moves_impl=_tensor_moves())
     ens.run(steps)
     pos, lp = ens.full_state()
     acc = ens.acceptance_fraction()
@@ -43,14 +50,15 @@ def _worker(rank, world, port, W, steps, path, moves):
     dist.destroy_process_group()
 
 
-def _run(world, W, steps, tmp_path, moves=(("stretch", 1.0),)):
+def _run(world, W, steps, tmp_path, moves=(("stretch", 1.0),), randomize=True):
     path = str(tmp_path / f"w{world}.pt")
     if world == 1:
-        ens = load_pkg().ensemble.ShardedEnsemble(gauss_logp, _init_positions(W), seed=11, moves=moves)
+        ens = load_pkg().ensemble.ShardedEnsemble(gauss_logp, _init_positions(W), seed=11, moves=moves, randomize_split=randomize,
+                                                  moves_impl=_tensor_moves())
         ens.run(steps)
         pos, lp = ens.full_state()
         return {"pos": pos, "lp": lp, "acc": ens.acceptance_fraction()}
-    mp.spawn(_worker, args=(world, _free_port(), W, steps, path, moves), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), W, steps, path, moves, randomize), nprocs=world, join=True)
     return torch.load(path)
 
 
@@ -65,7 +73,7 @@ def test_shard_bounds_partition():
 
 
 def test_counter_rng_is_a_pure_function_and_uniform():
-    ens = load_pkg().ensemble
+    ens = _tensor_moves()
     ids = torch.arange(0, 200000, dtype=torch.int64)
     u = ens.uniform01(42, 3, 1, ids, 2)
     assert torch.equal(u, ens.uniform01(42, 3, 1, ids, 2))
@@ -78,11 +86,12 @@ def test_counter_rng_is_a_pure_function_and_uniform():
     assert abs(float(((u - 0.5) * (v - 0.5)).mean())) < 1e-3  # consecutive steps uncorrelated
 
 
-@pytest.mark.parametrize("world,W", [(2, 64), (3, 50)])
-def test_chain_is_bit_identical_for_any_number_of_ranks(tmp_path, world, W):
-    """world_size 2 (equal shards) and 3 (ragged shards) reproduce the single-process chain exactly."""
-    ref = _run(1, W, 25, tmp_path)
-    got = _run(world, W, 25, tmp_path)
+@pytest.mark.parametrize("world,W,randomize", [(2, 64, True), (2, 64, False), (3, 48, True), (3, 50, False)])
+def test_chain_is_bit_identical_for_any_number_of_ranks(tmp_path, world, W, randomize):
+    """world_size 2 (equal shards) and 3 (whole-pair shards with the per-step split; ragged shards with the fixed parity
+    halves) reproduce the single-process chain exactly."""
+    ref = _run(1, W, 25, tmp_path, randomize=randomize)
+    got = _run(world, W, 25, tmp_path, randomize=randomize)
     assert torch.equal(ref["pos"], got["pos"])
     assert torch.equal(ref["lp"], got["lp"])
     assert ref["acc"] == got["acc"] and 0.2 < ref["acc"] < 0.9
@@ -117,17 +126,15 @@ def test_de_and_kde_moves_sample_the_target(tmp_path, moves):
 
 def test_kde_density_matches_scipy():
     from scipy.stats import gaussian_kde
-    ens_mod = load_pkg().ensemble
     g = torch.Generator().manual_seed(3)
     comp = MU + SIG * torch.randn(200, 3, generator=g, dtype=torch.float64)
     pts = MU + SIG * torch.randn(50, 3, generator=g, dtype=torch.float64)
-    ens = ens_mod.ShardedEnsemble(gauss_logp, _init_positions(8), moves=(("kde", 1.0),))
     nc, d = comp.shape
     h = (nc * (d + 2) / 4.0) ** (-1.0 / (d + 4))
     cen = comp - comp.mean(0)
     chol = torch.linalg.cholesky((cen.T @ cen) / (nc - 1) * h * h)
     log_norm = -np.log(nc) - 0.5 * d * np.log(2 * np.pi) - float(torch.log(torch.diagonal(chol)).sum())
-    got = ens._kde_logpdf(pts, comp, torch.linalg.inv(chol).T.contiguous(), log_norm)
+    got = moves_torch.TensorMoves.kde_logpdf(pts, comp, torch.linalg.inv(chol).T.contiguous(), log_norm)
     ref = gaussian_kde(comp.numpy().T, bw_method="silverman").logpdf(pts.numpy().T)
     np.testing.assert_allclose(got.numpy(), ref, rtol=1e-10)
 
@@ -146,13 +153,54 @@ def test_stream_keys_never_collide_across_steps_halves_and_streams():
                     assert k not in keys, f"key collision: {(seed, step, half, s)} vs {keys[k]}"
                     keys[k] = (seed, step, half, s)
     ids = torch.arange(0, 4096, dtype=torch.int64)
+    tm = _tensor_moves()
     # the two collisions the advisor ran
-    assert not torch.equal(ens.uniform01(42, 5, 0, ids, 10), ens.uniform01(42, 6, 0, ids, 2))
-    assert not torch.equal(ens.uniform01(42, 5, 0, ids, 8), ens.uniform01(42, 6, 0, ids, 0))
-    assert not torch.equal(ens.uniform01(42, 5, 1, ids, 8), ens.uniform01(42, 6, 1, ids, 0))
-    assert not torch.equal(ens.uniform01(42, 1000003, 0, ids, 0), ens.uniform01(43, 0, 0, ids, 0))
+    assert not torch.equal(tm.uniform01(42, 5, 0, ids, 10), tm.uniform01(42, 6, 0, ids, 2))
+    assert not torch.equal(tm.uniform01(42, 5, 0, ids, 8), tm.uniform01(42, 6, 0, ids, 0))
+    assert not torch.equal(tm.uniform01(42, 5, 1, ids, 8), tm.uniform01(42, 6, 1, ids, 0))
+    assert not torch.equal(tm.uniform01(42, 1000003, 0, ids, 0), tm.uniform01(43, 0, 0, ids, 0))
     # per-walker numbers of two (step, stream) pairs are uncorrelated
-    a, b = ens.uniform01(42, 5, 0, ids, 10), ens.uniform01(42, 6, 0, ids, 2)
+    a, b = tm.uniform01(42, 5, 0, ids, 10), tm.uniform01(42, 6, 0, ids, 2)
     assert abs(float(((a - 0.5) * (b - 0.5)).mean())) < 5e-3
     with pytest.raises(ValueError):
         ens.stream_key(1, 0, 0, ens.MAX_STREAMS)
+
+
+def test_the_driver_has_no_cpu_fallback():
+    with pytest.raises(RuntimeError, match="no tensor-library fallback"):
+        load_pkg().ensemble.ShardedEnsemble(gauss_logp, _init_positions(8))
+
+
+def test_randomized_halves_change_every_step_and_stay_balanced():
+    """emcee's RedBlueMove re-draws the halves every step; here whole pairs flip (counter-based bit per pair and step):
+    each half holds exactly one member of every pair, the assignment differs from step to step, both hashes (driver and
+    oracle) agree, and odd shard boundaries are refused."""
+    E = load_pkg().ensemble
+    pairs = torch.arange(0, 4096, dtype=torch.int64)
+    flips = []
+    for step in range(4):
+        key = E.stream_key(7, step, 0, E._SPLIT_STREAM)
+        f = moves_torch.flips_from_key(key, pairs)
+        signed = key - (1 << 64) if key >= (1 << 63) else key
+        assert torch.equal(f, E._pair_flips(signed, pairs))
+        assert set(f.tolist()) == {0, 1} and abs(float(f.double().mean()) - 0.5) < 0.03
+        flips.append(f)
+    assert not torch.equal(flips[0], flips[1]) and not torch.equal(flips[1], flips[2])
+    assert torch.equal(moves_torch.flips_from_key(0, pairs), torch.zeros_like(pairs))
+
+
+def _ragged_worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        load_pkg().ensemble.ShardedEnsemble(gauss_logp, _init_positions(50), moves_impl=_tensor_moves(), randomize_split=True)
+        ok = False
+    except ValueError as e:
+        ok = "whole walker pairs" in str(e)
+    assert ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_randomize_split_refuses_shards_that_cut_a_pair():
+    mp.spawn(_ragged_worker, args=(3, _free_port()), nprocs=3, join=True)

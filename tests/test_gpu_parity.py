@@ -254,7 +254,9 @@ def test_device_ensemble_stretch_move_matches_oracle_driven_chain(gpu):
         bounds=gpu.sn_pantheon.bounds, gauss=[gpu.sn_pantheon.H0_PRIOR]))
     start = gpu.synthetic.THETA_TRUE + 1e-2 * np.random.default_rng(1).standard_normal((96, 4))
     ens_gpu = gpu.ensemble.ShardedEnsemble(lk.engine.torch_log_prob(), torch.from_numpy(start).to("cuda:0"), seed=3)
-    ens_cpu = gpu.ensemble.ShardedEnsemble(lambda t: torch.from_numpy(co.logp(t.numpy())), torch.from_numpy(start), seed=3)
+    from oracle import moves_torch
+    ens_cpu = gpu.ensemble.ShardedEnsemble(lambda t: torch.from_numpy(co.logp(t.numpy())), torch.from_numpy(start), seed=3,
+                                           moves_impl=moves_torch.TensorMoves(gpu.ensemble.stream_key))
     ens_gpu.run(12)
     ens_cpu.run(12)
     torch.cuda.synchronize()
@@ -265,38 +267,52 @@ def test_device_ensemble_stretch_move_matches_oracle_driven_chain(gpu):
 
 
 @pytest.mark.parametrize("ndim,n_total", [(4, 512), (6, 130), (1, 64)])
-def test_native_ensemble_moves_match_the_tensor_code(gpu, ndim, n_total):
-    """cf_ens_kde_prepare / cf_ens_propose / cf_ens_accept against ensemble.py's tensor formulation of the same moves
-    (same counter-based random numbers): proposals, Hastings factors, KDE fit, accept decisions."""
+@pytest.mark.parametrize("randomize", [False, True])
+def test_native_ensemble_moves_match_the_tensor_statement(gpu, ndim, n_total, randomize):
+    """cf_ens_kde_prepare / cf_ens_propose / cf_ens_accept against oracle/moves_torch.py's tensor statement of the same moves
+    (same counter-based random numbers): proposals, Hastings factors, KDE fit, accept decisions -- with the fixed parity
+    halves and with the per-step pair flips."""
     torch = pytest.importorskip("torch")
+    from oracle import moves_torch
+
     E = gpu.ensemble
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(ndim)
     pos = torch.from_numpy(rng.standard_normal((n_total, ndim)) * np.linspace(0.5, 2.0, ndim) + 3.0).to(dev)
     f = lambda t: -0.5 * ((t - 3.0) ** 2).sum(dim=1)
-    ens = E.ShardedEnsemble(f, pos, seed=11, moves=E.REFERENCE_MOVES)
-    assert ens._native
+    ens = E.ShardedEnsemble(f, pos, seed=11, moves=E.REFERENCE_MOVES, randomize_split=randomize)
+    assert isinstance(ens.impl, E.NativeMoves)
+    tm = moves_torch.TensorMoves(E.stream_key)
     lib, L, stream = gpu.lib(), gpu._lib, torch.cuda.current_stream(dev).cuda_stream
+    pairs = torch.arange(n_total // 2, dtype=torch.int64, device=dev)
+    kde_params = torch.empty(2 * ndim * ndim + 1, dtype=torch.float64, device=dev)
+    kde_wc = torch.empty((n_total // 2, ndim), dtype=torch.float64, device=dev)
     for step in (0, 5):
         ens.step_count = step
+        split_key = E.stream_key(ens.seed, step, 0, E._SPLIT_STREAM) if randomize else 0
+        flips = moves_torch.flips_from_key(split_key, pairs)
+        if randomize:
+            assert 0 < int(flips.sum()) < n_total // 2
         for half in (0, 1):
-            ids, idx = ens._act_ids[half], ens._act_idx[half]
-            n, comp, key0 = int(ids.numel()), pos[(1 - half)::2], E.stream_key(ens.seed, step, half)
+            ids = (2 * pairs + (half ^ flips)).contiguous()
+            idx = ids.clone()  # one rank: local index = global index
+            comp = pos[2 * pairs + ((1 - half) ^ flips)]
+            n, key0 = int(ids.numel()), E.stream_key(ens.seed, step, half)
             for kind, name in enumerate(("stretch", "de", "kde")):
-                want_y, want_lf = getattr(ens, "_propose_" + name)(pos[ids], ids, comp, half)
+                want_y, want_lf = getattr(tm, "propose_" + name)(ens, pos[ids], ids, comp, half)
                 if kind == 2:
-                    L.check(lib.cf_ens_kde_prepare(pos.data_ptr(), n_total, ndim, half, ens._kde_params.data_ptr(),
-                                                   ens._kde_wc.data_ptr(), stream))
+                    L.check(lib.cf_ens_kde_prepare(pos.data_ptr(), n_total, ndim, half, split_key, kde_params.data_ptr(),
+                                                   kde_wc.data_ptr(), stream))
                 y, lf = torch.empty((n, ndim), dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev)
-                L.check(lib.cf_ens_propose(kind, pos.data_ptr(), n_total, ndim, half, ids.data_ptr(), n, key0, ens.a, ens.de_sigma,
-                                           ens._kde_params.data_ptr(), ens._kde_wc.data_ptr(), y.data_ptr(), lf.data_ptr(), stream))
+                L.check(lib.cf_ens_propose(kind, pos.data_ptr(), n_total, ndim, half, split_key, ids.data_ptr(), n, key0, ens.a,
+                                           ens.de_sigma, kde_params.data_ptr(), kde_wc.data_ptr(), y.data_ptr(), lf.data_ptr(), stream))
                 torch.cuda.synchronize()
                 np.testing.assert_allclose(y.cpu().numpy(), want_y.cpu().numpy(), rtol=1e-11, atol=1e-12, err_msg=name)
                 np.testing.assert_allclose(lf.cpu().numpy(), want_lf.cpu().numpy(), rtol=1e-9, atol=1e-9, err_msg=name)
                 # accept: same decisions as log(u) < log_factor + lp_new - lp_old, counted on the device
                 x_loc, lp_loc = ens.x.clone(), ens.logp.clone()
                 lp_new = f(y)
-                u = E.uniform01(ens.seed, step, half, ids, 2)
+                u = tm.uniform01(ens.seed, step, half, ids, 2)
                 want_acc = torch.log(u) < (lf + lp_new - lp_loc[idx])
                 count = torch.zeros(1, dtype=torch.int64, device=dev)
                 L.check(lib.cf_ens_accept(ids.data_ptr(), idx.data_ptr(), n, ndim, key0, y.data_ptr(), lp_new.data_ptr(),
@@ -306,6 +322,14 @@ def test_native_ensemble_moves_match_the_tensor_code(gpu, ndim, n_total):
                 exp_x = ens.x.clone()
                 exp_x[idx[want_acc]] = y[want_acc]
                 assert torch.equal(x_loc, exp_x)
+    # whole steps of the driver: the kernels' chain == the tensor statement's chain on the same target
+    e_native = E.ShardedEnsemble(f, pos.clone(), seed=4, moves=E.REFERENCE_MOVES, randomize_split=randomize)
+    e_tensor = E.ShardedEnsemble(f, pos.clone(), seed=4, moves=E.REFERENCE_MOVES, randomize_split=randomize, moves_impl=tm)
+    e_native.run(8)
+    e_tensor.run(8)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(e_native.x.cpu().numpy(), e_tensor.x.cpu().numpy(), rtol=1e-9, atol=1e-11)
+    assert e_native.n_accepted == e_tensor.n_accepted and e_native.n_proposed == e_tensor.n_proposed
 
 
 def test_in_kernel_log10_is_within_one_ulp(gpu):
@@ -513,7 +537,9 @@ def test_posterior_means_match_the_oracle_driven_chain_to_sampling_noise(gpu):
     start = gpu.synthetic.THETA_TRUE + np.array([0.02, 1.0, 0.03, 0.3]) * np.random.default_rng(4).standard_normal((128, 4))
     moves = gpu.ensemble.REFERENCE_MOVES
     e_gpu = gpu.ensemble.ShardedEnsemble(lk.engine.torch_log_prob(), torch.from_numpy(start).to("cuda:0"), seed=5, moves=moves)
-    e_cpu = gpu.ensemble.ShardedEnsemble(lambda t: torch.from_numpy(co.logp(t.numpy())), torch.from_numpy(start), seed=5, moves=moves)
+    from oracle import moves_torch
+    e_cpu = gpu.ensemble.ShardedEnsemble(lambda t: torch.from_numpy(co.logp(t.numpy())), torch.from_numpy(start), seed=5, moves=moves,
+                                         moves_impl=moves_torch.TensorMoves(gpu.ensemble.stream_key))
     burn, keep = 60, 120
     chain_g, chain_c = [], []
     for step in range(burn + keep):
