@@ -429,8 +429,10 @@ class DesiCmbUnion3Fs8(_Base):
 class CcFs8(_Base):
     """ohd/cc_fs8.py: theta = (H0, Om, sigma8, f_cc, f_fs8, w0).  Cosmic chronometers and growth-rate data, each with its own
     error-rescale factor; log L = -0.5 (chi2 - 2 N_cc ln f_cc - 2 N_fs8 ln f_fs8) without the constant of the Gaussian
-    normalisation (:137-140: hence logdet = -N_cc ln 2 pi here); the ODE starts at a = 1 / (1 + z_max) (:87); nautilus
+    normalisation (:137-140: hence logdet = -N_cc ln 2 pi here); the ODE starts at a = 1 / (1 + 200) (:86-87); nautilus
     vectorised callback ``log_likelihood`` (:143-144)."""
+
+    A_INIT = 1.0 / (1.0 + 200.0)  # max_z = 200, :86-87
 
     def __init__(self, z_cc, H_cc, cov_cc, fs8_z, fs8_vals, fs8_cov, fs8_fid, *, device=0, devices=None, steps=0):
         z_top = float(max(np.max(fs8_z), np.max(z_cc)))
@@ -439,7 +441,7 @@ class CcFs8(_Base):
             ndim=6, z_max=self.z_max, n_grid=N_GRID, fde=L.CF_FDE_THAWING,
             params=dict(H0=Param(0), Om=Param(1), s8=Param(2), fcc=Param(3), fs8err=Param(4), w0=Param(5)),
             cc=dict(z=z_cc, h=H_cc, inv_cov=np.linalg.inv(cov_cc), logdet=-len(z_cc) * np.log(2 * np.pi)),
-            fs8=dict(z=fs8_z, val=fs8_vals, inv_cov=np.linalg.inv(fs8_cov), fid=fs8_fid, a_init=1.0 / (1.0 + z_top), steps=steps),
+            fs8=dict(z=fs8_z, val=fs8_vals, inv_cov=np.linalg.inv(fs8_cov), fid=fs8_fid, a_init=self.A_INIT, steps=steps),
             device=device, devices=devices)
 
     def fs8_theory(self, params):
