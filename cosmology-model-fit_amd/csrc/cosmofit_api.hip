@@ -259,8 +259,8 @@ struct cf_handle {
   // timing ring: per evaluation and chunk 3 events (before the walker kernel, between it and the solve, after the solve)
   std::vector<hipEvent_t> ev;
   std::vector<int> ev_chunks;  // chunks of the evaluation in each ring slot
-  int timing_slots = 0;
-  int64_t timed_calls = 0;
+  int timing_slots = 0, timing_stride = 1;
+  int64_t timed_calls = 0, eval_calls = 0;
   cf_dev_desc d{};
   PackedFactor pack;
   DevBuf z_cmb, z_hel, obs, sn_step, sn_rec, log10_tab;
@@ -843,6 +843,16 @@ extern "C" int cf_enable_timing(cf_handle* h, int slots) {
   return CF_OK;
 }
 
+// Sample the kernel timing: events are recorded on every `stride`-th evaluation only (each evaluation with events pays for
+// four event records on its stream; sampled timing keeps the timed loop undisturbed).
+extern "C" int cf_set_timing_stride(cf_handle* h, int stride) {
+  if (!h || stride < 1) return fail(CF_ERR_INVALID, "cf_set_timing_stride: stride must be >= 1");
+  std::lock_guard<std::mutex> lk(h->mu);
+  h->timing_stride = stride;
+  h->eval_calls = 0;
+  return CF_OK;
+}
+
 extern "C" int64_t cf_timed_calls(cf_handle* h) { return h ? h->timed_calls : 0; }
 
 extern "C" int cf_kernel_ms(cf_handle* h, int64_t call, float t[2]) {
@@ -1025,8 +1035,9 @@ static int launch_path(cf_handle* h, const double* d_theta, int64_t W, double* d
     if (o < W) offs[n_chunks++] = o;  // the last chunk takes what is left
   }
   offs[n_chunks] = W;
-  const int slot = h->timing_slots ? (int)(h->timed_calls % h->timing_slots) : 0;
-  hipEvent_t* ev = h->timing_slots ? &h->ev[3 * slot * CF_MAX_CHUNKS] : nullptr;
+  const bool timed = h->timing_slots && (h->eval_calls++ % h->timing_stride) == 0;
+  const int slot = timed ? (int)(h->timed_calls % h->timing_slots) : 0;
+  hipEvent_t* ev = timed ? &h->ev[3 * slot * CF_MAX_CHUNKS] : nullptr;
   if (n_chunks == 1) {
     int rc = launch_chunk(h, d_theta, 0, W, d_out, out_kind, st, dm_out, mucorr_out, blocks_out, bao_out, chi2_sn_out, ev, nullptr,
                           fs8_block_out, fs8_theory_out);

@@ -290,9 +290,10 @@ class LikelihoodEngine:
         z_grid, cum, dh = self.distance_table(np.asarray(theta, dtype=np.float64).reshape(1, -1))
         return interp_hermite(np.atleast_1d(_f64(z)), z_grid, cum[0], dh[0])
 
-    def enable_timing(self, slots=1):
-        """Keep HIP-event timings of the last `slots` evaluations (0 = off)."""
+    def enable_timing(self, slots=1, stride=1):
+        """Keep HIP-event timings of the last `slots` timed evaluations (0 = off); only every `stride`-th evaluation is timed."""
         L.check(L.lib().cf_enable_timing(self._h, int(slots)))
+        L.check(L.lib().cf_set_timing_stride(self._h, int(stride)))
 
     def kernel_ms(self):
         """[(residual_ms, solve_ms), ...] for every evaluation still in the timing ring."""

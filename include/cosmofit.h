@@ -338,6 +338,8 @@ int cf_eval_table(cf_handle* h, const double* theta, int64_t W, double* cum_dm, 
  * kernel (and the small-blocks kernel of a joint likelihood), t[1] = solve + chi^2 kernel of evaluation number `call` (0-based since
  * cf_enable_timing); waits for that call.  cf_last_kernel_ms = the most recent call. */
 int cf_enable_timing(cf_handle* h, int slots);
+/* record the events on every `stride`-th evaluation only (default 1): sampled timing of a long loop */
+int cf_set_timing_stride(cf_handle* h, int stride);
 int64_t cf_timed_calls(cf_handle* h);
 int cf_kernel_ms(cf_handle* h, int64_t call, float t[2]);
 int cf_last_kernel_ms(cf_handle* h, float t[2]);

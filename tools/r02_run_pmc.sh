@@ -21,3 +21,4 @@ timeout -k 10 300 python bench.py --workload desi_des5y_bbn_theta_star > $O/benc
 for f in $O/bench_*.json; do python -c "
 import json,sys
 d=json.load(open('$f')); print('$f', '%.4e'%d['value'], '%.4f'%d['ms_per_step'], d['kernels_ms'], 'frac %.3f'%d['roofline']['frac'], d['roofline']['traffic_source'])"; done
+timeout -k 10 200 python tools/event_overhead_probe.py > $O/event_overhead_probe.txt 2>&1; cat $O/event_overhead_probe.txt
