@@ -61,6 +61,10 @@ def main():
     ap.add_argument("--n-sn", type=int, default=1701)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-seconds of work of the cpu_baseline sample (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precondition-ms", type=float, default=300.0,
+                    help="untimed evaluations of the same workload BEFORE the W warm-up steps, until the device has been busy this "
+                         "long: a GPU that has just left idle ramps its clock over ~0.1 s (profiles/r02_event_overhead.txt), and a "
+                         "sampler runs for hours at the sustained clock.  0 = none")
     ap.add_argument("--solve", default="default", choices=["default", "blocked", "inverse"],
                     help="solve kernel: blocked TRSM or the inverse-GEMM form (default: the library's choice)")
     ap.add_argument("--workload", default="pantheon", choices=["pantheon", "desi_cmb_des5y", "desi_des5y_bbn_theta_star"],
@@ -174,10 +178,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    n_pre = 0
+    if args.precondition_ms > 0:  # same work as a step, untimed, not part of W or K
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) * 1e3 < args.precondition_ms:
+            for _ in range(16):
+                eng.eval_device(theta_local.data_ptr(), Wl, logp.data_ptr(), kind, stream)
+            torch.cuda.synchronize()
+            n_pre += 16
     for _ in range(args.warmup):
         step()
     fence()
-    eng.enable_timing(min(args.steps, 4096))
+    # kernel durations from HIP events on the stream the kernels run on, SAMPLED over the timed region: recording them on
+    # every step costs 5 % of the step (profiles/r02_event_overhead.txt)
+    stride = max(1, min(8, args.steps // 5))
+    eng.enable_timing(min(args.steps, 4096), stride)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -237,6 +252,7 @@ def main():
                 (f"bao/desi_des5y_bbn_theta_star.py joint log P: {args.n_sn} SNe + 13 BAO (exact D_H) + l_A + BBN prior, "
                  f"physical-density E(z) with thawing dark energy, {Wl} walkers per GPU per step"),
                 "workload_key": args.workload if args.fde == "lcdm" else f"{args.workload}:{args.fde}",
+                "dispatches_per_step": None if os.environ.get("CF_CHUNKS") else 1,
                 "walkers_per_gpu": Wl, "walkers_total": W_total, "n_sn": args.n_sn, "n_grid": 4000, "ndim": ndim,
                 "parallelism": f"walkers sharded over {world} GPU(s)" + (
                     "" if world == 1 else
@@ -262,6 +278,8 @@ def main():
                 "frac_of_measured_ceiling": achieved / FP64_MFMA_MEASURED_TFLOPS,
             },
             "kernels_ms": {"walker_kernel": resid_ms, solve_kernel: solve_ms},
+            "kernel_timing": f"HIP events on the launch stream, every {stride}th of the {args.steps} timed steps ({len(kms)} samples)",
+            "preconditioning": {"untimed_evaluations_before_warmup": n_pre, "ms": args.precondition_ms},
             "device": {k: eng.info()[k] for k in ("gcn_arch", "cu_count")},
         }
         # the HBM view next to the matrix-core view.  `hbm_gbps_measured` = PMC bytes of the solve

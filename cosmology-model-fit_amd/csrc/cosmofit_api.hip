@@ -930,10 +930,14 @@ struct TriGemmArgs {
 template <int NP, int PF>
 static int launch_tri_gemm_t(const TriGemmArgs& a, hipStream_t st) {
   const int panels = (int)((a.W + 16 * NP - 1) / (16 * NP));
-  // optional panel groups (CF_GEMM_GROUP = panels per group, multiples of 8 so that a panel stays on one XCD): keeps a
-  // group's residual rows in L2 while its row blocks pass.  Measured at N = 1701, W = 4096: no gain (one group 226 us,
-  // two groups 229 us, four 249 us -- the factor streams are re-read per group), so the default is a single group.
-  static const int max_group = [] { const char* e = getenv("CF_GEMM_GROUP"); return e ? atoi(e) : 0; }();
+  // Panel groups: the grid runs group by group (a group = `ppg` panels x all row blocks), so that a group's residual rows
+  // stay in the 256 MB Infinity Cache while its 27 row blocks pass over them.  Up to 8192 walkers (256 panels of 32: 113 MB
+  // of residual rows) one group is best (W = 4096: one group 226 us, two 229 us, four 249 us -- the factor streams are
+  // re-read per group); beyond that the rows no longer fit and every row block would stream them from HBM again
+  // (W = 65536: 0.9 GB x 14 passes), so larger batches run in groups of 256 panels.  CF_GEMM_GROUP=<panels> overrides
+  // (multiples of 8 so that a panel stays on one XCD; 0 = one group).
+  static const int env_group = [] { const char* e = getenv("CF_GEMM_GROUP"); return e ? atoi(e) : -1; }();
+  const int max_group = env_group >= 0 ? env_group : (panels > 256 ? 256 : 0);
   int ppg = panels;
   if (max_group > 0 && panels > max_group) {
     const int n_groups = (panels + max_group - 1) / max_group;

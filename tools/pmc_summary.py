@@ -34,7 +34,7 @@ for k, cs in acc.items():
         name = "trsm_chi2_kernel" if "trsm" in k else ("tri_gemm_chi2_kernel" if "tri_gemm" in k else ("walker_kernel" if "walker" in k else None))
         if name:
             # a chunked evaluation dispatches the kernel several times per step: bytes per step = per-dispatch mean x dispatches
-            per_step = max(1, round(len(cs["FETCH_SIZE"]) / steps_total)) if steps_total else 1
+            per_step = cfg.get("dispatches_per_step") or (max(1, round(len(cs["FETCH_SIZE"]) / steps_total)) if steps_total else 1)
             f = cs["FETCH_SIZE"][2 * per_step:] or cs["FETCH_SIZE"]
             w = cs["WRITE_SIZE"][2 * per_step:] or cs["WRITE_SIZE"]
             fk, wk = sum(f) / len(f), sum(w) / len(w)
