@@ -934,10 +934,11 @@ static int launch_tri_gemm_t(const TriGemmArgs& a, hipStream_t st) {
   // stay in the 256 MB Infinity Cache while its 27 row blocks pass over them.  Up to 8192 walkers (256 panels of 32: 113 MB
   // of residual rows) one group is best (W = 4096: one group 226 us, two 229 us, four 249 us -- the factor streams are
   // re-read per group); beyond that the rows no longer fit and every row block would stream them from HBM again
-  // (W = 65536: 0.9 GB x 14 passes), so larger batches run in groups of 256 panels.  CF_GEMM_GROUP=<panels> overrides
-  // (multiples of 8 so that a panel stays on one XCD; 0 = one group).
+  // (W = 65536: 0.9 GB x 14 passes), so larger batches run in groups of 128 panels = 4096 walkers (measured at W = 65536,
+  // profiles/r02_panel_groups.txt: one group 3.66 ms = 0.66 of peak, groups of 256 panels 3.05 ms = 0.79, of 128 panels
+  // 2.96 ms = 0.82).  CF_GEMM_GROUP=<panels> overrides (multiples of 8 so that a panel stays on one XCD; 0 = one group).
   static const int env_group = [] { const char* e = getenv("CF_GEMM_GROUP"); return e ? atoi(e) : -1; }();
-  const int max_group = env_group >= 0 ? env_group : (panels > 256 ? 256 : 0);
+  const int max_group = env_group >= 0 ? env_group : (panels > 256 ? 128 : 0);
   int ppg = panels;
   if (max_group > 0 && panels > max_group) {
     const int n_groups = (panels + max_group - 1) / max_group;

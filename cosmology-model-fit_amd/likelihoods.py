@@ -446,3 +446,28 @@ class CcFs8(_Base):
 
     def fs8_theory(self, params):
         return self.engine.parts(params)["fs8_theory"][0]
+
+
+class DesiUnion3ThetaStarSubset(_Base):
+    """bao/desi_union3_omh2_theta_star.py: theta = (dM, H0, wb, wc, v).  Union3.1 SN + DESI BAO + a sub-vector of the early-LCDM
+    CMB compression (theta*, omega_b, omega_m): ``components=(0, 2)`` keeps (theta*, omega_m) with the inverse of the 2 x 2
+    sub-covariance (:17,110-112); (0, 1) and (1, 2) are the (theta*, omega_b) / (omega_b, omega_m) forms of
+    bao/desi_pantheon_obh2_theta_star.py:23 and bao/desi_union3_obh2_theta_star.py:17,128.  The engine's 3 x 3 form takes the
+    sub-inverse embedded in zeros: the omitted component drops out of the quadratic form exactly."""
+
+    def __init__(self, z_cmb, z_hel, mu_vals, cov_sn, bao_z, bao_val, bao_qty, bao_inv_cov, *, components=(0, 2), comp=None,
+                 z_turn=0.2, chol=None, device=0, devices=None, solve="auto"):
+        comp = cmb_data.EARLY_LCDM if comp is None else comp
+        idx = list(components)
+        inv = np.zeros((3, 3))
+        inv[np.ix_(idx, idx)] = np.linalg.inv(np.asarray(comp["cmb_cov"])[np.ix_(idx, idx)])
+        if chol is None:
+            chol = np.linalg.cholesky(cov_sn)
+        self.z_max = float(max(np.max(z_cmb), np.max(bao_z)) + 0.1)  # :19
+        self.engine = LikelihoodEngine(
+            ndim=5, z_max=self.z_max, n_grid=N_GRID, ez_model=L.CF_EZ_PHYSICAL, fde=L.CF_FDE_LCDM,
+            params=dict(offset=Param(0), H0=Param(1), obh2=Param(2), och2=Param(3), v=Param(4)),
+            sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=mu_vals, chol=chol, z_turn=z_turn),
+            bao=dict(z=bao_z, val=bao_val, qty=bao_qty, inv_cov=bao_inv_cov, dh_exact=True, rd_fit=comp["rd_fit"]),
+            cmb=dict(mode=comp["cmb_mode"], prior=comp["cmb_prior"], inv_cov=inv, zstar_fit=comp["zstar_fit"]),
+            physical=_physical(comp), device=device, devices=devices, solve_mode=solve_mode_of(solve))

@@ -771,6 +771,26 @@ def case_ohd_cc_fs8():
           "reference's own integration error on theory: %.2e" % np.max(np.abs(out["theory"] / out["theory_tight"] - 1)))
 
 
+def case_bao_desi_union3_omh2_theta_star():
+    """bao/desi_union3_omh2_theta_star.py: Union3.1 SN (explicit inverse, step at z = 0.2) + DESI BAO (exact D_H, r_drag fit) + a
+    TWO-component CMB block: (theta*, omega_m) of the early-LCDM compression with the inverse of the 2 x 2 sub-covariance
+    (:17,110-112).  All data real."""
+    _enter_reference()
+    import bao.desi_union3_omh2_theta_star as m
+
+    cmb = m.cmb
+    rng = np.random.default_rng(51)
+    box = [(-1.0, 1.0), (50.0, 90.0), (0.01, 0.04), (0.05, 0.3), (-8.5, 8.5)]  # main() (:137-141)
+    thetas = np.vstack([_uniform(box, 14, rng), [[0.0, 67.5, 0.0224, 0.119, 0.0]]])
+    out = _bao_inputs(m.bao_data, m.cov_matrix_bao, m.desi_qty, m.inv_cov_bao)
+    out.update(_cmb_consts(cmb))
+    out.update(z_cmb=m.z_cmb, z_hel=m.z_hel, obs=m.mu_vals, cov_sn=m.cov_matrix_sn, inv_cov_cmb_2x2=m.inv_cov_cmb, thetas=thetas,
+               z_max=np.float64(m.z_grid[-1]), chi2=np.array([m.chi_squared(t) for t in thetas]),
+               logl=np.array([m.log_likelihood(t) for t in thetas]))
+    np.savez_compressed(os.path.join(HERE, "bao_desi_union3_omh2_theta_star.npz"), **out)
+    print("bao_desi_union3_omh2_theta_star.npz chi2[-2:] =", out["chi2"][-2:])
+
+
 CASES = {
     "interpolator": case_interpolator,
     "sn_pantheon": case_sn_pantheon,
@@ -798,6 +818,7 @@ CASES = {
     "fs8_fs8": case_fs8_fs8,
     "bao_desi_cmb_union3_fs8": case_bao_desi_cmb_union3_fs8,
     "ohd_cc_fs8": case_ohd_cc_fs8,
+    "bao_desi_union3_omh2_theta_star": case_bao_desi_union3_omh2_theta_star,
 }
 
 if __name__ == "__main__":

@@ -228,3 +228,32 @@ def test_gpu_reference_accessor_signatures(gpu, pantheon_golden):
     assert lk.log_prior(np.array([-19.3, 70.0, 0.3, 0.0])) == pytest.approx(
         -np.sum(np.log(g["bounds"][:, 1] - g["bounds"][:, 0])) - 0.5 * ((70.0 - 70.39) / 1.80) ** 2)
     lk.engine.close()
+
+
+# ---- two-component CMB sub-vector (bao/desi_union3_omh2_theta_star.py) ---------------------------------------------------------
+def lk_bao_desi_union3_omh2_theta_star(g):
+    d = _cmbdata("EARLY_LCDM")
+    inv = np.zeros((3, 3))
+    inv[np.ix_([0, 2], [0, 2])] = g["inv_cov_cmb_2x2"]
+    return onp.Likelihood(ndim=5, z_max=float(g["z_max"]), ez_model=onp.EZ_PHYSICAL, offset=onp.Slot(0), H0=onp.Slot(1),
+                          obh2=onp.Slot(2), och2=onp.Slot(3), v=onp.Slot(4), z_cmb=g["z_cmb"], z_hel=g["z_hel"], obs=g["obs"],
+                          z_turn=0.2, chol=np.linalg.cholesky(g["cov_sn"]), bao_z=g["bao_z"], bao_val=g["bao_val"],
+                          bao_qty=g["bao_qty"], bao_inv_cov=g["bao_inv_cov"], bao_dh_exact=True, rd_fit=d["rd_fit"], cmb_mode=3,
+                          cmb_prior=d["cmb_prior"], cmb_inv_cov=inv, zstar_fit=d["zstar_fit"], **_phys(d))
+
+
+def test_oracle_cmb_sub_vector():
+    g = golden("bao_desi_union3_omh2_theta_star")
+    _check_oracle(lk_bao_desi_union3_omh2_theta_star(g), g)
+    # the mirror's embedding of the 2 x 2 inverse = the reference's own matrix
+    d = _cmbdata("EARLY_LCDM")
+    np.testing.assert_allclose(np.linalg.inv(np.asarray(d["cmb_cov"])[np.ix_([0, 2], [0, 2])]), g["inv_cov_cmb_2x2"], rtol=1e-12)
+
+
+@pytest.mark.gpu
+def test_gpu_cmb_sub_vector(gpu):
+    g = golden("bao_desi_union3_omh2_theta_star")
+    lk = gpu.likelihoods.DesiUnion3ThetaStarSubset(g["z_cmb"], g["z_hel"], g["obs"], g["cov_sn"], *_bao_args(g), components=(0, 2))
+    np.testing.assert_allclose(lk.chi_squared(g["thetas"]), g["chi2"], rtol=RTOL)
+    np.testing.assert_allclose(lk.log_likelihood(g["thetas"]), g["logl"], rtol=RTOL)
+    lk.engine.close()
