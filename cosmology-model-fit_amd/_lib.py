@@ -117,6 +117,7 @@ EXPORTS = {
     "cf_selftest_invpack_host": (C.c_int, [_VP, _I64, _I64, _VP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "cf_selftest_log10": (C.c_int, [_VP, _I64, _VP]),
     "cf_selftest_log10_tab": (C.c_int, [_VP, _I64, _VP]),
+    "cf_ens_active_set": (C.c_int, [C.c_uint64, _I64, _I64, C.c_int32, _I64, _VP, _VP, _VP]),
     "cf_ens_kde_prepare": (C.c_int, [_VP, _I64, C.c_int32, C.c_int32, C.c_uint64, _VP, _VP, _VP]),
     "cf_ens_propose": (C.c_int, [C.c_int32, _VP, _I64, C.c_int32, C.c_int32, C.c_uint64, _VP, _I64, C.c_uint64, C.c_double,
                                  C.c_double, _VP, _VP, _VP, _VP, _VP]),

@@ -265,6 +265,18 @@ ens_accept_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ l
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_accepted, (unsigned long long)__popcll(m));
 }
 
+// The active walkers of half `half` among the local pairs [pair_begin, pair_begin + n_pairs): global index
+// 2c + (half ^ flip_c) and its index in this process's shard.
+extern "C" __global__ void __launch_bounds__(256)
+ens_active_set_kernel(uint64_t split_key, int64_t pair_begin, int64_t n_pairs, int half, int64_t shard_start,
+                      int64_t* __restrict__ ids, int64_t* __restrict__ local_idx) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n_pairs) return;
+  const int64_t c = pair_begin + i, id = 2 * c + (half ^ ens_flip(split_key, c));
+  ids[i] = id;
+  local_idx[i] = id - shard_start;
+}
+
 // ------------------------------------------------------------------------------------------------
 static int ens_check(int64_t w_total, int32_t ndim, int32_t half, const char* fn) {
   if (w_total < 4 || (w_total & 1)) return cf_set_error(CF_ERR_INVALID, std::string(fn) + ": the ensemble needs an even number (>= 4) of walkers");
@@ -313,4 +325,16 @@ extern "C" int cf_ens_accept(const int64_t* d_ids, const int64_t* d_local_idx, i
                      d_local_idx, n_active, (int)ndim, key0, d_y, d_lp_new, d_log_factor, d_x_local, d_logp_local,
                      (unsigned long long*)d_n_accepted);
   return hipGetLastError() == hipSuccess ? CF_OK : cf_set_error(CF_ERR_HIP, "cf_ens_accept: launch failed");
+}
+
+extern "C" int cf_ens_active_set(uint64_t split_key, int64_t pair_begin, int64_t n_pairs, int32_t half, int64_t shard_start,
+                                 int64_t* d_ids, int64_t* d_local_idx, void* hip_stream) {
+  if (half != 0 && half != 1) return cf_set_error(CF_ERR_INVALID, "cf_ens_active_set: half must be 0 or 1");
+  if (pair_begin < 0 || n_pairs < 0 || shard_start != 2 * pair_begin)
+    return cf_set_error(CF_ERR_INVALID, "cf_ens_active_set: the shard must start at its first pair (shard_start = 2 pair_begin)");
+  if (!d_ids || !d_local_idx) return cf_set_error(CF_ERR_INVALID, "cf_ens_active_set: null argument");
+  if (n_pairs == 0) return CF_OK;
+  hipLaunchKernelGGL(ens_active_set_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, split_key,
+                     pair_begin, n_pairs, (int)half, shard_start, d_ids, d_local_idx);
+  return hipGetLastError() == hipSuccess ? CF_OK : cf_set_error(CF_ERR_HIP, "cf_ens_active_set: launch failed");
 }

@@ -104,6 +104,8 @@ class NativeMoves:
         self.kde_params = torch.empty(2 * e.ndim * e.ndim + 1, dtype=torch.float64, device=dev)
         self.kde_wc = torch.empty((e.n_total // 2, e.ndim), dtype=torch.float64, device=dev)
         self.n_acc = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.ids = torch.empty(nmax, dtype=torch.int64, device=dev)
+        self.idx = torch.empty(nmax, dtype=torch.int64, device=dev)
         # fixed-parity halves of this rank's shard (ragged shards and randomize_split=False)
         self.fixed = [(e.ids[(e.ids % 2) == h].contiguous(), (e.ids[(e.ids % 2) == h] - e.start).contiguous()) for h in (0, 1)]
 
@@ -111,10 +113,10 @@ class NativeMoves:
         L, lib = self.L, self.lib
         kind = _KIND[move]
         stream = torch.cuda.current_stream(e.x.device).cuda_stream
-        if split_key:  # this step's halves: walker 2c + (half ^ flip_c) of every local pair -- elementwise, no host sync
-            from_key = split_key - (1 << 64) if split_key >= (1 << 63) else split_key
-            ids = 2 * e.local_pairs + (half ^ _pair_flips(from_key, e.local_pairs))
-            idx = ids - e.start
+        if split_key:  # this step's halves: walker 2c + (half ^ flip_c) of every local pair -- one small launch, no host sync
+            n_pairs = (e.stop - e.start) // 2
+            ids, idx = self.ids[:n_pairs], self.idx[:n_pairs]
+            L.check(lib.cf_ens_active_set(split_key, e.start // 2, n_pairs, half, e.start, ids.data_ptr(), idx.data_ptr(), stream))
         else:
             ids, idx = self.fixed[half]
         n = int(ids.numel())
@@ -132,21 +134,6 @@ class NativeMoves:
         L.check(lib.cf_ens_accept(ids.data_ptr(), idx.data_ptr(), n, e.ndim, key0, y.data_ptr(), lp_new.data_ptr(),
                                   logfac.data_ptr(), e.x.data_ptr(), e.logp.data_ptr(), self.n_acc.data_ptr(), stream))
         e._n_proposed += n
-
-
-def _pair_flips(signed_key: int, pairs: torch.Tensor) -> torch.Tensor:
-    """0 / 1 per pair index: the top bit of the kernels' two-round hash of (pair, key) (cosmofit_ensemble.hip: ens_flip)."""
-    m1, m2, m3 = -7046029254386353131, -4658895280553007687, -7723592293110705685
-
-    def lsr(x, s):
-        return (x >> s) & ((1 << (64 - s)) - 1)
-
-    def mix(x):
-        x = (x ^ lsr(x, 30)) * m2
-        x = (x ^ lsr(x, 27)) * m3
-        return x ^ lsr(x, 31)
-
-    return lsr(mix(mix(pairs * m1 + signed_key) + m1), 63)
 
 
 class ShardedEnsemble:

@@ -387,7 +387,11 @@ int cf_selftest_log10_tab(const double* x, int64_t n, double* out);
  *   cf_ens_propose: kind 0 stretch (scale a), 1 differential evolution (gamma0 = 2.38 / sqrt(2 ndim), jitter de_sigma),
  *     2 KDE independence proposal; d_y [n_active * ndim], d_log_factor [n_active] = log Hastings factor.
  *   cf_ens_accept: accept with probability min(1, exp(log_factor + lp_new - lp_old)) (NaN never accepts); updates
- *     d_x_local / d_logp_local at d_local_idx [n_active] and adds the number of accepted moves to *d_n_accepted. */
+ *     d_x_local / d_logp_local at d_local_idx [n_active] and adds the number of accepted moves to *d_n_accepted.
+ *   cf_ens_active_set: the active walkers of half `half` among this process's pairs [pair_begin, pair_begin + n_pairs):
+ *     d_ids [n_pairs] = 2c + (half ^ flip_c), d_local_idx [n_pairs] = d_ids - shard_start (shard_start = 2 pair_begin). */
+int cf_ens_active_set(uint64_t split_key, int64_t pair_begin, int64_t n_pairs, int32_t half, int64_t shard_start,
+                      int64_t* d_ids, int64_t* d_local_idx, void* hip_stream);
 int cf_ens_kde_prepare(const double* d_all_pos, int64_t w_total, int32_t ndim, int32_t half, uint64_t split_key,
                        double* d_params, double* d_wc, void* hip_stream);
 int cf_ens_propose(int32_t kind, const double* d_all_pos, int64_t w_total, int32_t ndim, int32_t half, uint64_t split_key,

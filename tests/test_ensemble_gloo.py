@@ -173,16 +173,14 @@ def test_the_driver_has_no_cpu_fallback():
 
 def test_randomized_halves_change_every_step_and_stay_balanced():
     """emcee's RedBlueMove re-draws the halves every step; here whole pairs flip (counter-based bit per pair and step):
-    each half holds exactly one member of every pair, the assignment differs from step to step, both hashes (driver and
-    oracle) agree, and odd shard boundaries are refused."""
+    each half holds exactly one member of every pair, the assignment differs from step to step (the kernels' own hash is
+    checked against this one in tests/test_gpu_parity.py), and odd shard boundaries are refused."""
     E = load_pkg().ensemble
     pairs = torch.arange(0, 4096, dtype=torch.int64)
     flips = []
     for step in range(4):
         key = E.stream_key(7, step, 0, E._SPLIT_STREAM)
         f = moves_torch.flips_from_key(key, pairs)
-        signed = key - (1 << 64) if key >= (1 << 63) else key
-        assert torch.equal(f, E._pair_flips(signed, pairs))
         assert set(f.tolist()) == {0, 1} and abs(float(f.double().mean()) - 0.5) < 0.03
         flips.append(f)
     assert not torch.equal(flips[0], flips[1]) and not torch.equal(flips[1], flips[2])

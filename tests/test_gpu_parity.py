@@ -296,6 +296,11 @@ def test_native_ensemble_moves_match_the_tensor_statement(gpu, ndim, n_total, ra
         for half in (0, 1):
             ids = (2 * pairs + (half ^ flips)).contiguous()
             idx = ids.clone()  # one rank: local index = global index
+            if randomize:  # the library's own active set (cf_ens_active_set) = the oracle's pair flips
+                k_ids, k_idx = torch.empty_like(ids), torch.empty_like(ids)
+                L.check(lib.cf_ens_active_set(split_key, 0, n_total // 2, half, 0, k_ids.data_ptr(), k_idx.data_ptr(), stream))
+                torch.cuda.synchronize()
+                assert torch.equal(k_ids, ids) and torch.equal(k_idx, idx)
             comp = pos[2 * pairs + ((1 - half) ^ flips)]
             n, key0 = int(ids.numel()), E.stream_key(ens.seed, step, half)
             for kind, name in enumerate(("stretch", "de", "kde")):
