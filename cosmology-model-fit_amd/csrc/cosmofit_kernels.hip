@@ -248,26 +248,6 @@ __device__ __forceinline__ double hermite_fast(const DistTable& T, double xi) {
   return fma(t, fma(t, fma(t, dd, cc), b), e0.x);
 }
 
-// hermite_fast without branches (the same arithmetic, bit for bit): the two extrapolation forms are computed beside the
-// cubic and selected.  With no branch in it, three independent evaluations in one loop body form ONE basic block and the
-// scheduler interleaves their dependent chains (the production SN loop is latency-, not issue-bound at 4 waves per SIMD).
-__device__ __forceinline__ double hermite_select(const DistTable& T, double xi) {
-  const int G = T.G;
-  const double u = xi * T.inv_step;
-  int i = (int)u;
-  i = i < 0 ? 0 : (i > G - 2 ? G - 2 : i);
-  const double t = u - (double)i;
-  const d2 e0 = T.at(i), e1 = T.at(i + 1);
-  const double b = T.step * e0.y, hm1 = T.step * e1.y, dy = e1.x - e0.x;
-  const double sm = b + hm1;
-  const double dd = fma(-2.0, dy, sm);
-  const double cc = fma(3.0, dy, -(sm + b));
-  const double cub = fma(t, fma(t, fma(t, dd, cc), b), e0.x);
-  const double lo = e0.x + e0.y * xi;               // xi <= 0: i = 0, e0 = node 0
-  const double hi = e1.x + e1.y * (xi - T.z_max);   // xi >= z_max: i = G - 2, e1 = node G - 1
-  return xi <= 0.0 ? lo : (xi >= T.z_max ? hi : cub);
-}
-
 // log10 for positive, finite, normal arguments (distances in Mpc): the fdlibm / msun algorithm
 // (log1p kernel: 14-term odd polynomial in s = f/(2+f); hi/lo split of 1/ln10 and log10(2)), < 1 ulp.
 // About a third of the instructions of the generic library call, which also handles zero, negative,
@@ -322,29 +302,6 @@ __device__ __forceinline__ double log10_tab(double x, const d2* __restrict__ tab
                C4 = -1.08573620475812956913e-01, C5 = 8.68588963806503655303e-02, C6 = -7.23824136505419712752e-02,
                C7 = 6.20420688433216896645e-02, C8 = -5.42868102379064784564e-02;
   const double log10_2hi = 3.01029995663611771306e-01, log10_2lo = 3.69423907715893078616e-13;
-  const int e = __builtin_amdgcn_frexp_exp(x);
-  const double m = __builtin_amdgcn_frexp_mant(x);
-  const d2 t = tab[(__double2hiint(m) >> 14) & 63];
-  const double r = fma(m, t.x, -1.0);
-  double p = fma(C8, r, C7);
-  p = fma(p, r, C6);
-  p = fma(p, r, C5);
-  p = fma(p, r, C4);
-  p = fma(p, r, C3);
-  p = fma(p, r, C2);
-  p = fma(p, r, C1);
-  const double ek = (double)e;
-  return fma(ek, log10_2hi, t.y) + fma(r, p, ek * log10_2lo);
-}
-
-// log10_tab without its guard branch: arguments outside the positive normal range set `bad` (the caller redoes those
-// entries on the guarded path); for all others the same arithmetic, bit for bit.
-__device__ __forceinline__ double log10_tab_flag(double x, const d2* __restrict__ tab, bool& bad) {
-  const double C1 = 4.34294481903251827651e-01, C2 = -2.17147240951625913826e-01, C3 = 1.44764827301083942550e-01,
-               C4 = -1.08573620475812956913e-01, C5 = 8.68588963806503655303e-02, C6 = -7.23824136505419712752e-02,
-               C7 = 6.20420688433216896645e-02, C8 = -5.42868102379064784564e-02;
-  const double log10_2hi = 3.01029995663611771306e-01, log10_2lo = 3.69423907715893078616e-13;
-  bad = bad || !(x > 2.2250738585072014e-308 && x < 1.7976931348623157e308);
   const int e = __builtin_amdgcn_frexp_exp(x);
   const double m = __builtin_amdgcn_frexp_mant(x);
   const d2 t = tab[(__double2hiint(m) >> 14) & 63];
@@ -628,8 +585,10 @@ __device__ __forceinline__ void sn_fast_loop(const cf_dev_desc& d, const DistTab
     const double off_i = LIN ? off + lin * st : off;
     out[i] = ob - off_i - (25.0 + 5 * log10_tab(zhp1 * hermite_fast(T, z_cosmo), log_tab));
   };
-#ifdef CF_SN_LOOP_V1
-  // round-1 loop (A/B builds): two records in flight, ping-pong; one supernova at a time, guarded helpers
+  // two records in flight, ping-pong (no register copies); the record array carries 512 spare entries past n_ld.
+  // (A variant with three branch-free evaluations per iteration -- selects instead of the extrapolation / range guards, so
+  // that the three dependent chains share one basic block -- measured the same 0.051 ms: the loop is issue-, not
+  // latency-bound; profiles/r02_sn_loop_ab.txt.)
   d4 ra = rec[0], rb;
   int i = tid;
   while (i < n_sn) {
@@ -642,46 +601,6 @@ __device__ __forceinline__ void sn_fast_loop(const cf_dev_desc& d, const DistTab
     one_sn(rb, i);
     i += CF_TPB_A;
   }
-#else
-  // THREE supernovae per iteration, branch-free (hermite_select / log10_tab_flag: the same arithmetic as the guarded
-  // helpers): their three dependent chains -- Hermite, then the log10 polynomial -- interleave in one basic block.  At
-  // N = 1701 a thread owns three supernovae (tid, tid + 512, tid + 1024) and a third of the threads a fourth one, whose
-  // record is fetched before the triple is computed.  An argument outside log10_tab's range (never for physical theta)
-  // flags the thread, which then redoes its entries on the guarded path.
-  bool bad = false;
-  const bool vstep = !LIN && d.has_vstep;
-  auto resid = [&](const d4& r) {
-    const double za = r[0], st = r[1], zhp1 = r[2], ob = r[3];
-    // selects, not branches (vstep is uniform, but a branch here would split the block the three chains share)
-    const double zc = PM1 ? -1.0 + za * (st > 0.0 ? r_pos : r_neg) : -1.0 + za / (1.0 + (v100 * st) / d.c);
-    const double z_cosmo = vstep ? zc : za;
-    const double off_i = LIN ? off + lin * st : off;
-    return ob - off_i - (25.0 + 5 * log10_tab_flag(zhp1 * hermite_select(T, z_cosmo), log_tab, bad));
-  };
-  int i = tid;
-  while (i + 2 * CF_TPB_A < n_sn) {  // a full triple
-    const d4 r0 = rec[0], r1 = rec[CF_TPB_A], r2 = rec[2 * CF_TPB_A];
-    const bool more = i + 3 * CF_TPB_A < n_sn;
-    d4 rn = r0;
-    if (more) rn = rec[3 * CF_TPB_A];  // the next (often last) record of this thread, in flight during the triple
-    const double a = resid(r0), b = resid(r1), c = resid(r2);
-    out[i] = a;
-    out[i + CF_TPB_A] = b;
-    out[i + 2 * CF_TPB_A] = c;
-    i += 3 * CF_TPB_A;
-    rec += 3 * CF_TPB_A;
-    if (more && !(i + 2 * CF_TPB_A < n_sn)) {  // one is left but no further triple: it is the prefetched record
-      out[i] = resid(rn);
-      i += CF_TPB_A;
-      rec += CF_TPB_A;
-    }
-  }
-  for (; i < n_sn; i += CF_TPB_A, rec += CF_TPB_A) out[i] = resid(rec[0]);
-  if (bad) {
-    rec = reinterpret_cast<const d4*>(d.sn_rec) + tid;
-    for (int k = tid; k < n_sn; k += CF_TPB_A, rec += CF_TPB_A) one_sn(rec[0], k);
-  }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
