@@ -264,7 +264,7 @@ struct cf_handle {
   cf_dev_desc d{};
   PackedFactor pack;
   DevBuf z_cmb, z_hel, obs, sn_step, sn_rec, log10_tab;
-  DevBuf bao_z, bao_val, bao_inv_cov, bao_qty, gl_x, gl_w, fixed_mu, cc_z, cc_h, cc_inv_cov, nu_grid, sn_lin, sn_dir;
+  DevBuf bao_z, bao_val, bao_inv_cov, bao_qty, gl_x, gl_w, fixed_mu, cc_z, cc_h, cc_inv_cov, nu_grid, ln_grid, sn_lin, sn_dir;
   DevBuf theta, out, delta, ypk, chi2_extra, nonfinite;
   DevBuf fs8_z, fs8_val, fs8_inv_cov, fs8_fid, fs8_step_of, fs8_order, fs8_scratch;
   DevBuf bao_nodes, bao_base;  // [max_walkers][n_bao][CF_BAO_NODES] table nodes for small_blocks_kernel; first node per datum
@@ -687,6 +687,17 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
     int rc;
     if ((rc = upload_vec(h->nu_grid, nu.data(), c->n_grid))) return bail(rc);
     d.nu_grid = h->nu_grid.as<const double>();
+  }
+  if (c->fde == CF_FDE_WCDM || c->fde == CF_FDE_CPL) {
+    // ln(1 + z) at the grid nodes, correctly rounded from extended precision: the power-law dark-energy forms become one exp
+    std::vector<double> ln((size_t)c->n_grid);
+    for (int g = 0; g < c->n_grid; ++g) {
+      const double z = g == c->n_grid - 1 ? c->z_max : (double)g * d.step;
+      ln[g] = (double)log1pl((long double)z);
+    }
+    int rc;
+    if ((rc = upload_vec(h->ln_grid, ln.data(), c->n_grid))) return bail(rc);
+    d.ln_grid = h->ln_grid.as<const double>();
   }
   if (c->n_cc > 0) {
     int rc;

@@ -102,6 +102,7 @@ struct cf_dev_desc {
   double or_h2, omnu_h2, o_gamma_h2, nu_m0, nu_rho0;
   double nu_qs_sq[5], nu_ws[5];
   const double* nu_grid;  // [n_grid] massive-neutrino density ratio at the grid nodes (theta-independent), or null
+  const double* ln_grid;  // [n_grid] ln(1 + z) at the grid nodes (wCDM / CPL dark energy: zp1^a = exp(a ln zp1)), or null
   // BAO block
   int32_t n_bao, bao_dh_exact, rd_from_fit, pad2;
   const double* bao_z;

@@ -82,14 +82,18 @@ extern "C" int cf_debug_walker_stamps(unsigned long long* out) {
 #define CF_WSTAMP(k)
 #endif
 
+// `lnzp1` >= 0: ln(1 + z) of a grid node, tabulated at cf_create (theta-independent): the power of the wCDM / CPL forms
+// becomes ONE exp of a product instead of pow (+ exp): zp1^a = exp(a ln zp1), a few ulp from the library pow and a third
+// of its instructions -- the table build of the CPL model was 2.3x the LCDM one.  Absent (< 0): the reference's expression.
 template <int FDE>
-__device__ __forceinline__ double f_de(const WalkerCosmo& wc, double z, double zp1, double cubed) {
+__device__ __forceinline__ double f_de(const WalkerCosmo& wc, double z, double zp1, double cubed, double lnzp1 = -1.0) {
   if (FDE == CF_FDE_LCDM_D) return 1.0;
-  if (FDE == CF_FDE_WCDM_D) return pow(zp1, 3 * (1 + wc.w0));
+  if (FDE == CF_FDE_WCDM_D) return lnzp1 >= 0.0 ? exp(3 * (1 + wc.w0) * lnzp1) : pow(zp1, 3 * (1 + wc.w0));
   if (FDE == CF_FDE_THAWING_D) {
     double r = 2 * cubed / ((1.0 + wc.w0) + (1.0 - wc.w0) * cubed);
     return r * r;
   }
+  if (lnzp1 >= 0.0) return exp(fma(3 * (1 + wc.w0 + wc.wa), lnzp1, -3 * wc.wa * z / zp1));
   return pow(zp1, 3 * (1 + wc.w0 + wc.wa)) * exp(-3 * wc.wa * z / zp1);
 }
 
@@ -107,13 +111,13 @@ __device__ __forceinline__ double omnu_z(const cf_dev_desc& d, double zp1) {
 // value tabulated at cf_create for this grid node (it does not depend on theta: 5 sqrt + 2 divides saved
 // per node and per walker, and the tabulated value is the reference's own arithmetic).
 template <int MODEL, int FDE>
-__device__ __forceinline__ double e2_of_z(const cf_dev_desc& d, const WalkerCosmo& wc, double z, double nu = -1.0) {
+__device__ __forceinline__ double e2_of_z(const cf_dev_desc& d, const WalkerCosmo& wc, double z, double nu = -1.0, double lnzp1 = -1.0) {
   const double zp1 = 1.0 + z;
   const double cubed = zp1 * zp1 * zp1;
   if (MODEL == CF_EZ_LATE_FLAT_D)
     return (FDE == CF_FDE_LCDM_D) ? wc.Om * cubed + (1.0 - wc.Om)
-                                  : wc.Om * cubed + (1.0 - wc.Om) * f_de<FDE>(wc, z, zp1, cubed);
-  const double de = (FDE == CF_FDE_LCDM_D) ? wc.Ode : wc.Ode * f_de<FDE>(wc, z, zp1, cubed);
+                                  : wc.Om * cubed + (1.0 - wc.Om) * f_de<FDE>(wc, z, zp1, cubed, lnzp1);
+  const double de = (FDE == CF_FDE_LCDM_D) ? wc.Ode : wc.Ode * f_de<FDE>(wc, z, zp1, cubed, lnzp1);
   if (nu < 0.0) nu = omnu_z(d, zp1);
   return wc.Or * (cubed * zp1) + wc.Obc * cubed + de + wc.Onu * nu;  // bao/desi_cmb_des5y.py:43-48
 }
@@ -354,17 +358,21 @@ template <int MODEL, int FDE, int CH, bool INTERIOR>
 __device__ __forceinline__ double chunk_eval(const cf_dev_desc& d, const WalkerCosmo& wc, double c_over_H0, int g0, int lane,
                                              const double (&nu_pre)[CH], double (&dh)[CH], double (&loc)[CH]) {
   const int G = d.n_grid;
-  double z[CH];
+  double z[CH], ln[CH];
+  // ln(1 + z) of the nodes for the power-law dark-energy forms (theta-independent table, L2-resident)
+  constexpr bool POWER_LAW = FDE == CF_FDE_WCDM_D || FDE == CF_FDE_CPL_D;
+#pragma unroll
+  for (int k = 0; k < CH; ++k) ln[k] = (POWER_LAW && d.ln_grid) ? d.ln_grid[min(g0 + k, G - 1)] : -1.0;
 #pragma unroll
   for (int k = 0; k < CH; ++k) {
     const int g = g0 + k;
     if (INTERIOR) {
       z[k] = (double)g * d.step;
-      dh[k] = c_over_H0 * rsqrt_pos(e2_of_z<MODEL, FDE>(d, wc, z[k], nu_pre[k]));
+      dh[k] = c_over_H0 * rsqrt_pos(e2_of_z<MODEL, FDE>(d, wc, z[k], nu_pre[k], ln[k]));
     } else {
       const int gc = g < G ? g : G - 1;  // evaluations past the grid repeat the last node and are discarded
       z[k] = gc == G - 1 ? d.z_max : (double)gc * d.step;
-      const double v = c_over_H0 * rsqrt_pos(e2_of_z<MODEL, FDE>(d, wc, z[k], nu_pre[k]));
+      const double v = c_over_H0 * rsqrt_pos(e2_of_z<MODEL, FDE>(d, wc, z[k], nu_pre[k], ln[k]));
       dh[k] = g < G ? v : 0.0;
     }
   }
