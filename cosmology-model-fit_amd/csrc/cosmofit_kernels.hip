@@ -348,17 +348,22 @@ __device__ __forceinline__ double wave_inclusive_scan(double v) {
 // registers, wave64 DPP scan over the chunk totals, wave totals and the wave-boundary intervals carried
 // through LDS, then ONE 16-byte LDS store per node.
 // One thread's chunk: dh at its CH nodes and the chunk-local trapezoid prefix, branch-free (the CH evaluation
-// chains are independent and interleave; a per-node branch would serialise them: the two edge waves took 4x
-// the interior ones, and the whole workgroup waits for them at the barrier).  INTERIOR = the whole WAVE lies
-// strictly inside the grid (no node 0, no last node, nothing past G): the bounds selects drop out.
+// chains are independent and interleave; a per-node branch would serialise them).  Every wave runs the same arithmetic:
+// nodes at g * step and the nominal half step as the one factor of every interval -- the reference's np.diff(z_grid)
+// is `step` up to the rounding of i * step (1 ulp of z, i.e. <= 4e-13 of step, and the deviations telescope), also in the
+// last interval (z_max vs (G-1) * step: a rounding apart).  LAST = the wave that holds the last grid node and the threads
+// past the grid: the last node sits at z_max exactly (np.linspace forces it) and the nodes past the grid contribute
+// nothing -- two selects per node, no other difference.  (Until round 2 the first and the last wave ran a separate path
+// with true node differences; in-kernel stamps showed the other six waves waiting ~2.6 k of the workgroup's 13 k cycles
+// for them at the barrier: profiles/r02_walker_stamps.txt.)
 // The interval in front of a chunk belongs to it, with dh of the node before taken from the neighbouring lane
 // (DPP wave_shr:1); lane 0 leaves its first interval out -- build_distance_table_regs adds the eight
 // wave-boundary intervals with the carries.
-template <int MODEL, int FDE, int CH, bool INTERIOR>
+template <int MODEL, int FDE, int CH, bool LAST>
 __device__ __forceinline__ double chunk_eval(const cf_dev_desc& d, const WalkerCosmo& wc, double c_over_H0, int g0, int lane,
                                              const double (&nu_pre)[CH], double (&dh)[CH], double (&loc)[CH]) {
   const int G = d.n_grid;
-  double z[CH], ln[CH];
+  double ln[CH];
   // ln(1 + z) of the nodes for the power-law dark-energy forms (theta-independent table, L2-resident)
   constexpr bool POWER_LAW = FDE == CF_FDE_WCDM_D || FDE == CF_FDE_CPL_D;
 #pragma unroll
@@ -366,38 +371,20 @@ __device__ __forceinline__ double chunk_eval(const cf_dev_desc& d, const WalkerC
 #pragma unroll
   for (int k = 0; k < CH; ++k) {
     const int g = g0 + k;
-    if (INTERIOR) {
-      z[k] = (double)g * d.step;
-      dh[k] = c_over_H0 * rsqrt_pos(e2_of_z<MODEL, FDE>(d, wc, z[k], nu_pre[k], ln[k]));
-    } else {
-      const int gc = g < G ? g : G - 1;  // evaluations past the grid repeat the last node and are discarded
-      z[k] = gc == G - 1 ? d.z_max : (double)gc * d.step;
-      const double v = c_over_H0 * rsqrt_pos(e2_of_z<MODEL, FDE>(d, wc, z[k], nu_pre[k], ln[k]));
-      dh[k] = g < G ? v : 0.0;
-    }
+    double z = (double)g * d.step;
+    if (LAST) z = g >= G - 1 ? d.z_max : z;
+    const double v = c_over_H0 * rsqrt_pos(e2_of_z<MODEL, FDE>(d, wc, z, nu_pre[k], ln[k]));
+    dh[k] = (LAST && g >= G) ? 0.0 : v;
   }
   double prev = dpp_move<0x138, 0xF>(dh[CH - 1]);  // wave_shr:1; lane 0 gets 0 and skips its first interval
   double run = 0.0;
-  if (INTERIOR) {
-    // the reference's np.diff(z_grid) is `step` up to the rounding of i*step (1 ulp of z, i.e. <= 4e-13 of step,
-    // and the deviations telescope): half the nominal step as one factor saves three operations per node
-    const double half = 0.5 * d.step;
+  const double half = 0.5 * d.step;
 #pragma unroll
-    for (int k = 0; k < CH; ++k) {
-      run = (k > 0 || lane > 0) ? fma(prev + dh[k], half, run) : run;
-      loc[k] = run;
-      prev = dh[k];
-    }
-  } else {
-    double z_prev = (double)(g0 - 1) * d.step;  // g0 - 1 is never the last node
-#pragma unroll
-    for (int k = 0; k < CH; ++k) {
-      const double inc = (prev + dh[k]) / 2 * (z[k] - z_prev);
-      run += ((k > 0 || lane > 0) && g0 + k < G) ? inc : 0.0;
-      loc[k] = run;
-      prev = dh[k];
-      z_prev = z[k];
-    }
+  for (int k = 0; k < CH; ++k) {
+    const bool counts = (k > 0 || lane > 0) && (!LAST || g0 + k < G);
+    run = counts ? fma(prev + dh[k], half, run) : run;
+    loc[k] = run;
+    prev = dh[k];
   }
   return run;
 }
@@ -411,10 +398,9 @@ __device__ __forceinline__ void build_distance_table_regs(const cf_dev_desc& d, 
   const int base = g0 + tid;  // skewed position of node g0
   const double c_over_H0 = wc.c / wc.H0;
   double dh[CH], loc[CH];
-  const int wave_first = (tid - lane) * CH, wave_last = wave_first + 64 * CH - 1;
-  const double run = (wave_first > 0 && wave_last < G - 1)
-                         ? chunk_eval<MODEL, FDE, CH, true>(d, wc, c_over_H0, g0, lane, nu_pre, dh, loc)
-                         : chunk_eval<MODEL, FDE, CH, false>(d, wc, c_over_H0, g0, lane, nu_pre, dh, loc);
+  const int wave_last = (tid - lane) * CH + 64 * CH - 1;  // last node of this wave
+  const double run = wave_last < G - 1 ? chunk_eval<MODEL, FDE, CH, false>(d, wc, c_over_H0, g0, lane, nu_pre, dh, loc)
+                                       : chunk_eval<MODEL, FDE, CH, true>(d, wc, c_over_H0, g0, lane, nu_pre, dh, loc);
   CF_WSTAMP(2);
   const double incl = wave_inclusive_scan(run);
   // per wave: {sum of its intervals, dh of its first node, dh of its last node}
