@@ -106,7 +106,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # under torch.distributed.run (RANK in the environment) the rank joins the process group and every step carries the
+    # all-gather of positions -- also with ONE rank, so that `torchrun --nproc-per-node 1 bench.py` exercises RCCL
+    # initialisation and the device collective on a one-GPU box; plain `python bench.py` has no process group
+    use_dist = "RANK" in os.environ
+    if use_dist:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
@@ -162,7 +166,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        if world > 1:
+        if use_dist:
             # exchange step of an ensemble move: every rank needs the complementary walkers' positions
             if backend == "nccl":
                 dist.all_gather_into_tensor(theta_all, theta_local)
@@ -174,7 +178,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -200,7 +204,7 @@ def main():
     dt = time.perf_counter() - t0
     kms = eng.kernel_ms()
     eng.enable_timing(0)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -215,7 +219,7 @@ def main():
     ident = "%s pci %04x:%02x:%02x uuid %s" % (props.name, getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0),
                                               getattr(props, "pci_device_id", 0), getattr(props, "uuid", "?"))
     idents = [ident]
-    if world > 1:
+    if use_dist:
         idents = [None] * world
         dist.all_gather_object(idents, ident)
 
@@ -255,11 +259,11 @@ def main():
                 "dispatches_per_step": None if os.environ.get("CF_CHUNKS") else 1,
                 "walkers_per_gpu": Wl, "walkers_total": W_total, "n_sn": args.n_sn, "n_grid": 4000, "ndim": ndim,
                 "parallelism": f"walkers sharded over {world} GPU(s)" + (
-                    "" if world == 1 else
+                    "" if not use_dist else
                     ", RCCL all-gather of positions per step" if backend == "nccl" else
                     f", {backend} all-gather of positions staged through the host (rehearsal: not RCCL)"),
             },
-            "backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if world > 1 else None,
+            "backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if use_dist else None,
             "world_size": world,
             "device_ids": idents,
             "distinct_devices": len(set(idents)),
@@ -309,7 +313,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(pkg, syn, lk, theta_all_host, result, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

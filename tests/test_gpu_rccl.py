@@ -1,0 +1,35 @@
+"""GPU (-m gpu): the process-per-GPU launch path of bench.py on the ONE GPU of the test box.  RCCL refuses two ranks on one
+device, so what can execute here is the one-rank case under torch.distributed.run: process-group creation over RCCL
+(backend "nccl"), the device all-gather of walker positions in every step, the barrier / max-over-ranks timing and the
+gathered device identities -- the same code the N = 2, 4, 8 runs execute, minus the inter-GPU transport.  The multi-rank
+logic itself (sharding, all-gather of ragged shards, rank-count invariance) is covered over gloo in test_ensemble_gloo.py."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_under_torchrun_runs_rccl_with_one_rank(pkg):
+    if pkg.lib().cf_device_count() < 1:
+        pytest.fail("GPU tests need an MI355X; no HIP device visible (there is no fallback path)")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1",
+           "--no-cpu-baseline", "--precondition-ms", "0", "--walkers-per-gpu", "1024", "--n-sn", "300"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["backend"] == "rccl (torch.distributed nccl)" and d["world_size"] == 1 and d["n_gpus"] == 1
+    assert "RCCL all-gather of positions per step" in d["config"]["parallelism"]
+    assert d["distinct_devices"] == 1 and len(d["device_ids"]) == 1 and d["value"] > 0
