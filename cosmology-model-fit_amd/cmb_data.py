@@ -33,7 +33,7 @@ ZSTAR_CONSTS = (-0.7316314841257655, 391.6723594873167, 0.9368102670600895, -0.3
 RDRAG_A = (0.00257366, 0.05032, 0.013, 0.7720642, 0.24346362, 0.00641072, 0.5350899, 32.7525, 0.315473)
 
 
-def _neutrino(omnu_denominator):
+def _neutrino(omnu_denominator, N_EFF=N_EFF):
     T_nu0 = (4 / 11) ** (1 / 3) * (N_EFF / 3) ** (1 / 4) * TCMB
     m0 = MNU_TOT / (T_nu0 * K_B)
     qs = np.array([a + b / (m0**d + c) for a, b, c, d in _NU_COEFFS], dtype=np.float64)
@@ -47,8 +47,8 @@ def _neutrino(omnu_denominator):
                 o_gamma_h2=O_GAMMA_H2)
 
 
-def _compression(priors, covariance, omnu_den, zstar_sbm, rdrag_bm, mode):
-    d = _neutrino(omnu_den)
+def _compression(priors, covariance, omnu_den, zstar_sbm, rdrag_bm, mode, n_eff=N_EFF):
+    d = _neutrino(omnu_den, n_eff)
     d.update(cmb_prior=np.array(priors), cmb_cov=np.array(covariance), cmb_inv_cov=np.linalg.inv(np.array(covariance)),
              zstar_fit=tuple(zstar_sbm), rd_fit=tuple(rdrag_bm) + RDRAG_A, cmb_mode=mode)
     return d
@@ -68,5 +68,13 @@ EARLY_LCDM = _compression(
                      [0.124442058, 21.3441666, -94.0008323],
                      [-1.19287532, -94.0008323, 1488.41714]]),
     94.07, (0.75717491, 1.00737989, 1.02737182, 1.20432292), (1.00140649, 1.00072621), 3)
+
+# cmb/data_planck_compression.py:12-33,87,103 (Planck 2018 (R, l_A, omega_b), N_eff = 3.046)
+PLANCK = _compression(
+    [1.75063846, 301.760701, 0.0223597502],
+    [[2.09107356e-05, 1.78419597e-04, -4.46283183e-07],
+     [1.78419597e-04, 7.81249750e-03, -4.24834772e-06],
+     [-4.46283183e-07, -4.24834772e-06, 2.21402189e-08]],
+    94.07, (0.73491615, 1.00820929, 1.01709662, 1.17030559), (1.00078696, 1.00128548), 1, n_eff=3.046)
 
 BBN_SCHONEBERG = (0.02218, 0.00055)  # omega_b mean, sigma: y2024BBN/prior_lcdm_schoneberg.py:2-3

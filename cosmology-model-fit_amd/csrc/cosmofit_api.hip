@@ -404,6 +404,7 @@ static int validate_desc(const cf_desc* c) {
         return fail(CF_ERR_INVALID, "cf_create: growth-rate data must lie in a_init <= a <= 1");
   }
   if (c->om_mode != 0 && c->om_mode != 1) return fail(CF_ERR_INVALID, "cf_create: om_mode must be 0 or 1");
+  if (c->rd_wm_mode != 0 && c->rd_wm_mode != 1) return fail(CF_ERR_INVALID, "cf_create: rd_wm_mode must be 0 or 1");
   if (c->n_devices < -1 || c->n_devices > 64 || (c->n_devices > 0 && !c->devices))
     return fail(CF_ERR_INVALID, "cf_create: n_devices must be -1 (all), 0 (cf_desc.device) or 1..64 with a devices array");
   if (!(c->probe_limit >= 0.0)) return fail(CF_ERR_INVALID, "cf_create: probe_limit must be >= 0 (0 = default)");
@@ -488,6 +489,7 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
   d.n_bao = c->n_bao;
   d.bao_dh_exact = c->bao_dh_mode == CF_BAO_DH_EXACT;
   d.rd_from_fit = c->rd_mode == CF_RD_FIT;
+  d.rd_wm_late = c->rd_wm_mode == 1;
   for (int i = 0; i < 11; ++i) {
     d.rd_fit[i] = c->rd_fit[i];
     d.zstar_fit[i] = c->zstar_fit[i];

@@ -104,7 +104,7 @@ struct cf_dev_desc {
   const double* nu_grid;  // [n_grid] massive-neutrino density ratio at the grid nodes (theta-independent), or null
   const double* ln_grid;  // [n_grid] ln(1 + z) at the grid nodes (wCDM / CPL dark energy: zp1^a = exp(a ln zp1)), or null
   // BAO block
-  int32_t n_bao, bao_dh_exact, rd_from_fit, pad2;
+  int32_t n_bao, bao_dh_exact, rd_from_fit, rd_wm_late;  // rd_wm_late: the r_drag fit takes wm = Omega_m h^2 (late-time flat model)
   const double* bao_z;
   const double* bao_val;
   const double* bao_inv_cov;

@@ -758,7 +758,8 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
   double* dl = delta_s[grp];
   double z_star = 0.0, r_d = 0.0;
   if (d.cmb_mode || d.rd_from_fit) {
-    const double wm_z = Oc + Ob + d.omnu_h2, wm_r = Ob + Oc + d.omnu_h2;
+    const double h_late = wc.H0 / 100;
+    const double wm_z = Oc + Ob + d.omnu_h2, wm_r = d.rd_wm_late ? wc.Om * (h_late * h_late) : Ob + Oc + d.omnu_h2;
     const double* fz = d.zstar_fit;  // s1 s2 b m e0 c1 e1 e2 c2 e3 e4
     const double* fr = d.rd_fit;     // b m a1..a9
     // round 1: lane 0 wb^b(z*), 1 wm^m(z*), 2 wb^b(rd), 3 wm^m(rd)

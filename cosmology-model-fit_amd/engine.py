@@ -66,7 +66,8 @@ class LikelihoodEngine:
         cc: dict(z, h, inv_cov, logdet) — cosmic chronometers with the rescale parameter slot "fcc"
             (bao/desi_union3_cc_theta_star.py:129-139).
         bao: dict(z, val, qty (0 DV/rd, 1 DM/rd, 2 DH/rd, 3 F_AP), inv_cov[, dh_exact=False, rd_fit=None]);
-            rd_fit = (b, m, a1..a9) selects the r_drag fitting formula, otherwise the "rd" slot is used.
+            rd_fit = (b, m, a1..a9) selects the r_drag fitting formula, otherwise the "rd" slot is used; rd_wm_late=True hands
+            it wm = Omega_m h^2 of the late-time flat model instead of omega_b + omega_c + omega_nu (bao/desi_bbn.py:46-60).
         cmb: dict(mode (1 R-lA-wb, 2 lA only, 3 theta*-wb-wm), prior[3], inv_cov[3,3], zstar_fit (s1,s2,b,m)[, n_gl=100]).
         physical: dict(or_h2, omnu_h2, o_gamma_h2, nu_m0, nu_rho0, nu_qs_sq[5], nu_ws[5]) — required by
             ez_model=CF_EZ_PHYSICAL (see cmb_data.PLANCK_ACT / EARLY_LCDM).
@@ -152,6 +153,7 @@ class LikelihoodEngine:
             if bao.get("rd_fit") is not None:
                 d.rd_mode = 1
                 d.rd_fit[:] = [float(x) for x in bao["rd_fit"]]
+                d.rd_wm_mode = 1 if bao.get("rd_wm_late", False) else 0
             self.n_bao = int(bz.size)
         if cc is not None:
             cz, ch, cinv = _f64(cc["z"]), _f64(cc["h"]), _f64(cc["inv_cov"])

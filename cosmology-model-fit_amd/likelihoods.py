@@ -471,3 +471,50 @@ class DesiUnion3ThetaStarSubset(_Base):
             bao=dict(z=bao_z, val=bao_val, qty=bao_qty, inv_cov=bao_inv_cov, dh_exact=True, rd_fit=comp["rd_fit"]),
             cmb=dict(mode=comp["cmb_mode"], prior=comp["cmb_prior"], inv_cov=inv, zstar_fit=comp["zstar_fit"]),
             physical=_physical(comp), device=device, devices=devices, solve_mode=solve_mode_of(solve))
+
+
+class DesiBbn(_Base):
+    """bao/desi_bbn.py: theta = (H0, Om, wb, w0); bounds :70-77.  BAO only in the late-time flat thawing model with PCHIP D_H; the
+    sound horizon comes from the r_drag fit of the Planck compression with wm = Om h^2 (:46-60); the BBN omega_b measurement is a
+    Gaussian term of the prior (:84-88)."""
+    bounds = np.array([(55.0, 75.0), (0.17, 0.50), (0.016, 0.030), (-1.0, -1 / 3)])
+
+    def __init__(self, z, val, qty, inv_cov, *, comp=None, bbn=cmb_data.BBN_SCHONEBERG, device=0, devices=None, bounds=None):
+        comp = cmb_data.PLANCK if comp is None else comp
+        self.bounds = self.bounds if bounds is None else np.asarray(bounds, float)
+        self.z_max = float(np.max(z) + 0.1)  # :11
+        self.engine = LikelihoodEngine(
+            ndim=4, z_max=self.z_max, n_grid=N_GRID, fde=L.CF_FDE_THAWING,
+            params=dict(H0=Param(0), Om=Param(1), obh2=Param(2), w0=Param(3)),
+            bao=dict(z=z, val=val, qty=qty, inv_cov=inv_cov, rd_fit=comp["rd_fit"], rd_wm_late=True),
+            bounds=self.bounds, gauss=[(2, bbn[0], bbn[1])], device=device, devices=devices)
+
+
+class DesiCc(_Base):
+    """bao/desi_cc.py: theta = (f_cc, H0, r_d, Om, w0); bounds :89-97.  DESI BAO (D_H = c / H exactly, free r_d) + cosmic
+    chronometers with the error-rescale factor f_cc and the Gaussian normalisation in log L (:107-110)."""
+    bounds = np.array([(0.5, 2.5), (45.0, 90.0), (120.0, 175.0), (0.1, 0.7), (-1.0, 0.0)])
+
+    def __init__(self, bao_z, bao_val, bao_qty, bao_inv_cov, z_cc, H_cc, cov_cc, *, device=0, devices=None, bounds=None):
+        self.bounds = self.bounds if bounds is None else np.asarray(bounds, float)
+        self.z_max = float(np.max(bao_z) + 0.1)  # :19
+        self.engine = LikelihoodEngine(
+            ndim=5, z_max=self.z_max, n_grid=N_GRID, fde=L.CF_FDE_THAWING,
+            params=dict(fcc=Param(0), H0=Param(1), rd=Param(2), Om=Param(3), w0=Param(4)),
+            bao=dict(z=bao_z, val=bao_val, qty=bao_qty, inv_cov=bao_inv_cov, dh_exact=True),
+            cc=dict(z=z_cc, h=H_cc, inv_cov=np.linalg.inv(cov_cc), logdet=np.linalg.slogdet(cov_cc)[1]),
+            bounds=self.bounds, device=device, devices=devices)
+
+
+class Cc(_Base):
+    """ohd/cc.py: theta = (H0, Om, f).  Cosmic chronometers alone, flat LCDM: chi2 = f^2 delta C^-1 delta and
+    log L = -0.5 (chi2 + N ln 2 pi + logdet - 2 N ln f) (:22-35).  No distance table is needed (z_max is nominal)."""
+
+    def __init__(self, z_cc, H_cc, cov_cc, *, device=0, devices=None, bounds=None):
+        self.bounds = None if bounds is None else np.asarray(bounds, float)
+        self.z_max = float(np.max(z_cc) + 0.1)
+        self.engine = LikelihoodEngine(
+            ndim=3, z_max=self.z_max, n_grid=N_GRID, fde=L.CF_FDE_LCDM,
+            params=dict(H0=Param(0), Om=Param(1), fcc=Param(2)),
+            cc=dict(z=z_cc, h=H_cc, inv_cov=np.linalg.inv(cov_cc), logdet=np.linalg.slogdet(cov_cc)[1]),
+            bounds=self.bounds, device=device, devices=devices)

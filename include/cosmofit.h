@@ -247,7 +247,9 @@ typedef struct cf_desc {
   /* ---- parameterisation variants of the scripts ("Physics variants") ---- */
   int32_t om_mode;          /* 0: Omega_m = slot CF_P_OM; 1: slot CF_P_OM is omega_m = Omega_m h^2 and
                                Omega_m = omega_m / (H0/100)^2          bao/desi_omh2.py:18-20 */
-  int32_t _pad6;
+  int32_t rd_wm_mode;       /* matter density handed to the r_drag fit (CF_RD_FIT): 0 = omega_b + omega_c + omega_nu (physical
+                               densities, bao/desi_cmb_des5y.py:84-85); 1 = Omega_m (H0/100)^2 of the late-time flat model with
+                               omega_b from slot CF_P_OBH2                bao/desi_bbn.py:46-60 */
   const double* sn_lin_coef;/* [n_sn] or NULL: the SN offset becomes offset + theta_LIN * sn_lin_coef[i]; with
                                sn_lin_coef[i] = 100 (5/ln 10) / (c z_cmb,i) this is the linearised bulk-flow magnitude
                                term                                    bao/desi_cmb_pantheon_H0trgb.py:102-106 */

@@ -83,7 +83,8 @@ class COracle:
     """Built from an ``oracle_np.Likelihood`` so both oracles share one description of a case."""
 
     def __init__(self, lk):
-        if getattr(lk, "lin_coef", None) is not None or getattr(lk, "dirs", None) is not None or getattr(lk, "om_mode", 0):
+        if getattr(lk, "lin_coef", None) is not None or getattr(lk, "dirs", None) is not None or getattr(lk, "om_mode", 0) \
+                or getattr(lk, "rd_wm_late", False) or getattr(lk, "fs8_z", None) is not None:
             raise NotImplementedError("the C oracle restates the BASELINE configs; the parameterisation variants "
                                       "(linear magnitude term, direction-dependent velocity, omega_m slot) are checked "
                                       "against oracle_np and the golden fixtures")

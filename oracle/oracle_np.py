@@ -199,6 +199,7 @@ class Likelihood:
     bao_inv_cov: Optional[np.ndarray] = None
     bao_dh_exact: bool = False  # False: PCHIP on the dh grid; True: c/H(z) at the datum
     rd_fit: Optional[Sequence] = None  # (b, m, a1..a9) -> r_drag fitting formula; None -> slot `rd`
+    rd_wm_late: bool = False  # the fit takes wm = Omega_m h^2 of the late-time flat model (bao/desi_bbn.py:46-60)
     # compressed CMB block
     cmb_mode: int = 0  # 0 none, 1 (R, lA, wb), 2 lA only, 3 (theta*, wb, wm)
     cmb_prior: Optional[np.ndarray] = None
@@ -335,7 +336,10 @@ def bao_theory(lk: Likelihood, theta, tables=None):
     """bao/desi_cmb_des5y.py:82-100, bao/desi.py:38-56, bao/desi_cmb.py:79-91."""
     cum_dm, dh_grid = tables if tables is not None else dm_grid(lk, theta)
     z, qty = lk.bao_z, lk.bao_qty
-    if lk.rd_fit is not None:
+    if lk.rd_fit is not None and lk.rd_wm_late:  # bao/desi_bbn.py:47,60: h, Om, Obh2 -> r_drag(Obh2, Om * h**2)
+        h = lk.H0.get(theta) / 100
+        rd = r_drag(lk.rd_fit, lk.obh2.get(theta), lk.Om.get(theta) * h**2)
+    elif lk.rd_fit is not None:
         Obh2, Och2 = lk.obh2.get(theta), lk.och2.get(theta)
         rd = r_drag(lk.rd_fit, Obh2, Obh2 + Och2 + lk.omnu_h2)
     else:

@@ -791,6 +791,59 @@ def case_bao_desi_union3_omh2_theta_star():
     print("bao_desi_union3_omh2_theta_star.npz chi2[-2:] =", out["chi2"][-2:])
 
 
+def case_bao_desi_bbn():
+    """bao/desi_bbn.py: BAO only, late-time flat + thawing dark energy, PCHIP D_H, r_d from the Planck-compression r_drag fit
+    with wm = Om h^2 (:46-60), BBN omega_b term in the prior (:84-88); theta = (H0, Om, wb, w0).  All data real."""
+    _enter_reference()
+    import bao.desi_bbn as m
+    import cmb.data_planck_compression as pc
+
+    rng = np.random.default_rng(61)
+    thetas = theta_batch(m.bounds, 14, rng)
+    out = _bao_inputs(m.bao, m.cov_matrix, m.bao_qty, m.inv_cov)
+    with np.errstate(all="ignore"):
+        out.update(bounds=m.bounds, thetas=thetas, z_max=np.float64(m.z_grid[-1]), bbn=np.array([m.bbn.Obh2, m.bbn.Obh2_sigma]),
+                   chi2=np.array([m.chi_squared(t) for t in thetas]), logp=np.array([m.log_probability(t) for t in thetas]),
+                   theory=np.array([m.bao_theory(m.bao["z"], m.bao_qty, t) for t in thetas[:4]]),
+                   rdrag_planck=np.array([pc.r_drag(0.0224, 0.143), pc.r_drag(0.02, 0.12)]),
+                   zstar_planck=np.array([pc.z_star(0.0224, 0.143), pc.z_star(0.02, 0.12)]),
+                   planck_consts=np.array([pc.Or_h2, pc.Omnu_h2, pc.m0, pc.rho0]), planck_priors=pc.DISTANCE_PRIORS,
+                   planck_cov=pc.covariance)
+    np.savez_compressed(os.path.join(HERE, "bao_desi_bbn.npz"), **out)
+    print("bao_desi_bbn.npz chi2[:3] =", out["chi2"][:3])
+
+
+def case_bao_desi_cc():
+    """bao/desi_cc.py: DESI BAO (exact D_H, free r_d) + cosmic chronometers with f_cc and the Gaussian normalisation in log L;
+    theta = (f_cc, H0, r_d, Om, w0), late-time flat thawing, box prior.  All data real."""
+    _enter_reference()
+    import bao.desi_cc as m
+
+    rng = np.random.default_rng(62)
+    thetas = theta_batch(m.bounds, 14, rng)
+    out = _bao_inputs(m.data, m.bao_cov_matrix, m.desi_qty, m.inv_cov_bao)
+    with np.errstate(all="ignore"):
+        out.update(cc_z=m.z_cc_vals, cc_h=m.H_cc_vals, cc_cov=m.cc_cov_matrix, bounds=m.bounds, thetas=thetas,
+                   z_max=np.float64(m.z_grid[-1]), chi2=np.array([m.chi_squared(t) for t in thetas]),
+                   logl=np.array([m.log_likelihood(t) for t in thetas]), logp=np.array([m.log_probability(t) for t in thetas]))
+    np.savez_compressed(os.path.join(HERE, "bao_desi_cc.npz"), **out)
+    print("bao_desi_cc.npz chi2[:3] =", out["chi2"][:3])
+
+
+def case_ohd_cc():
+    """ohd/cc.py: cosmic chronometers alone, flat LCDM, theta = (H0, Om, f); chi2 = f^2 ||L^-1 delta||^2 and the Gaussian
+    normalisation N ln 2 pi + logdet - 2 N ln f in log L (:22-35).  All data real."""
+    _enter_reference()
+    import ohd.cc as m
+
+    rng = np.random.default_rng(63)
+    thetas = np.vstack([_uniform([(30.0, 100.0), (0.0, 1.0), (0.1, 3.3)], 14, rng), [[67.8, 0.32, 1.0]]])
+    out = dict(cc_z=m.z_values, cc_h=m.H_values, cc_cov=m.cov_matrix, thetas=thetas,
+               chi2=np.array([m.chi_squared(t) for t in thetas]), logl=np.array([m.log_likelihood(t) for t in thetas]))
+    np.savez_compressed(os.path.join(HERE, "ohd_cc.npz"), **out)
+    print("ohd_cc.npz chi2[-2:] =", out["chi2"][-2:])
+
+
 CASES = {
     "interpolator": case_interpolator,
     "sn_pantheon": case_sn_pantheon,
@@ -819,6 +872,9 @@ CASES = {
     "bao_desi_cmb_union3_fs8": case_bao_desi_cmb_union3_fs8,
     "ohd_cc_fs8": case_ohd_cc_fs8,
     "bao_desi_union3_omh2_theta_star": case_bao_desi_union3_omh2_theta_star,
+    "bao_desi_bbn": case_bao_desi_bbn,
+    "bao_desi_cc": case_bao_desi_cc,
+    "ohd_cc": case_ohd_cc,
 }
 
 if __name__ == "__main__":

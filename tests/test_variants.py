@@ -257,3 +257,82 @@ def test_gpu_cmb_sub_vector(gpu):
     np.testing.assert_allclose(lk.chi_squared(g["thetas"]), g["chi2"], rtol=RTOL)
     np.testing.assert_allclose(lk.log_likelihood(g["thetas"]), g["logl"], rtol=RTOL)
     lk.engine.close()
+
+
+# ---- three more block combinations: r_drag fit in the late-time flat model, BAO + chronometers, chronometers alone -------------------
+def lk_bao_desi_bbn(g):
+    d = _cmbdata("PLANCK")
+    return onp.Likelihood(ndim=4, z_max=float(g["z_max"]), fde=onp.FDE_THAWING, H0=onp.Slot(0), Om=onp.Slot(1), obh2=onp.Slot(2),
+                          w0=onp.Slot(3), bao_z=g["bao_z"], bao_val=g["bao_val"], bao_qty=g["bao_qty"], bao_inv_cov=g["bao_inv_cov"],
+                          rd_fit=d["rd_fit"], rd_wm_late=True, bounds=g["bounds"], gauss=[(2, float(g["bbn"][0]), float(g["bbn"][1]))])
+
+
+def lk_bao_desi_cc(g):
+    return onp.Likelihood(ndim=5, z_max=float(g["z_max"]), fde=onp.FDE_THAWING, fcc=onp.Slot(0), H0=onp.Slot(1), rd=onp.Slot(2),
+                          Om=onp.Slot(3), w0=onp.Slot(4), bao_z=g["bao_z"], bao_val=g["bao_val"], bao_qty=g["bao_qty"],
+                          bao_inv_cov=g["bao_inv_cov"], bao_dh_exact=True, cc_z=g["cc_z"], cc_h=g["cc_h"],
+                          cc_inv_cov=np.linalg.inv(g["cc_cov"]), cc_logdet=np.linalg.slogdet(g["cc_cov"])[1], bounds=g["bounds"])
+
+
+def lk_ohd_cc(g):
+    return onp.Likelihood(ndim=3, z_max=float(np.max(g["cc_z"]) + 0.1), H0=onp.Slot(0), Om=onp.Slot(1), fcc=onp.Slot(2),
+                          cc_z=g["cc_z"], cc_h=g["cc_h"], cc_inv_cov=np.linalg.inv(g["cc_cov"]),
+                          cc_logdet=np.linalg.slogdet(g["cc_cov"])[1])
+
+
+def test_planck_compression_constants_match_the_reference_module(pkg):
+    g = golden("bao_desi_bbn")
+    d = _cmbdata("PLANCK")
+    np.testing.assert_allclose([onp.r_drag(d["rd_fit"], 0.0224, 0.143), onp.r_drag(d["rd_fit"], 0.02, 0.12)], g["rdrag_planck"], rtol=1e-14)
+    np.testing.assert_allclose([onp.z_star(d["zstar_fit"], 0.0224, 0.143), onp.z_star(d["zstar_fit"], 0.02, 0.12)], g["zstar_planck"], rtol=1e-14)
+    np.testing.assert_allclose([d["or_h2"], d["omnu_h2"], d["nu_m0"], d["nu_rho0"]], g["planck_consts"], rtol=1e-14)
+    np.testing.assert_array_equal(d["cmb_prior"], g["planck_priors"])
+    np.testing.assert_array_equal(d["cmb_cov"], g["planck_cov"])
+
+
+@pytest.mark.parametrize("name", ["bao_desi_bbn", "bao_desi_cc", "ohd_cc"])
+def test_oracle_more_block_combinations(name):
+    g = golden(name)
+    lk = globals()["lk_" + name](g)
+    with np.errstate(all="ignore"):
+        for k in range(len(g["thetas"])):
+            th = g["thetas"][k]
+            if "logp" in g:
+                want = g["logp"][k]
+                got = onp.log_probability(lk, th)
+                assert (got == -np.inf and want == -np.inf) or got == pytest.approx(want, rel=RTOL)
+                if not np.isfinite(want):
+                    continue
+            assert onp.chi_squared(lk, th) == pytest.approx(g["chi2"][k], rel=RTOL)
+            if "logl" in g:
+                assert onp.log_likelihood(lk, th) == pytest.approx(g["logl"][k], rel=RTOL)
+
+
+@pytest.mark.gpu
+def test_gpu_more_block_combinations(gpu):
+    g = golden("bao_desi_bbn")
+    lk = gpu.likelihoods.DesiBbn(*_bao_args(g), bounds=g["bounds"], bbn=(float(g["bbn"][0]), float(g["bbn"][1])))
+    fin = np.isfinite(g["logp"])
+    np.testing.assert_allclose(lk.chi_squared(g["thetas"])[fin], g["chi2"][fin], rtol=RTOL)
+    logp = lk.log_probs_vectorized(g["thetas"])
+    np.testing.assert_allclose(logp[fin], g["logp"][fin], rtol=RTOL)
+    assert np.all(logp[~fin] == -np.inf)
+    for k in range(4):
+        np.testing.assert_allclose(lk.bao_theory(g["thetas"][k]), g["theory"][k], rtol=1e-12)
+    lk.engine.close()
+
+    g = golden("bao_desi_cc")
+    lk = gpu.likelihoods.DesiCc(*_bao_args(g), g["cc_z"], g["cc_h"], g["cc_cov"], bounds=g["bounds"])
+    fin = np.isfinite(g["logp"])
+    np.testing.assert_allclose(lk.chi_squared(g["thetas"])[fin], g["chi2"][fin], rtol=RTOL)
+    np.testing.assert_allclose(lk.log_likelihood(g["thetas"])[fin], g["logl"][fin], rtol=RTOL)
+    logp = lk.log_probs_vectorized(g["thetas"])
+    np.testing.assert_allclose(logp[fin], g["logp"][fin], rtol=RTOL)
+    assert np.all(logp[~fin] == -np.inf)
+    lk.engine.close()
+
+    g = golden("ohd_cc")
+    lk = gpu.likelihoods.Cc(g["cc_z"], g["cc_h"], g["cc_cov"])
+    np.testing.assert_allclose(lk.chi_squared(g["thetas"]), g["chi2"], rtol=RTOL)
+    np.testing.assert_allclose(lk.log_likelihood(g["thetas"]), g["logl"], rtol=RTOL)
+    lk.engine.close()
