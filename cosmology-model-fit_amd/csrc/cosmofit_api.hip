@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <algorithm>
 #include <utility>
@@ -1105,6 +1106,26 @@ extern "C" int cf_eval_device(cf_handle* h, const double* d_theta, int64_t W, do
   return launch_path(h, d_theta, W, d_out, out_kind, (hipStream_t)hip_stream, nullptr, nullptr, nullptr, nullptr);
 }
 
+// Wait for the handle's stream from a synchronous host call: poll (hipStreamQuery) for up to 5 ms before blocking -- a
+// blocking hipStreamSynchronize sleeps on an interrupt and adds tens of microseconds to a call that takes 0.07-0.3 ms, and
+// the caller (an MCMC step) has nothing else to do meanwhile.  CF_HOST_WAIT=block restores the plain blocking wait.
+static int wait_stream(hipStream_t st) {
+#ifndef CF_HOST_WAIT_BLOCK
+  static const bool block = [] { const char* e = getenv("CF_HOST_WAIT"); return e && !strcmp(e, "block"); }();
+  if (!block) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t q = hipStreamQuery(st);
+      if (q == hipSuccess) return 0;
+      if (q != hipErrorNotReady) return fail(CF_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+    }
+  }
+#endif
+  HIP_TRY(hipStreamSynchronize(st));
+  return 0;
+}
+
 // One replica, host buffers: stage through the handle's pinned block, run on the handle's stream, wait.
 static int eval_host_single(cf_handle* h, const double* theta, int64_t W, double* out, int out_kind) {
   int rc;
@@ -1117,7 +1138,7 @@ static int eval_host_single(cf_handle* h, const double* theta, int64_t W, double
                         nullptr, nullptr)))
     return rc;
   HIP_TRY(hipMemcpyAsync(h->stage_out.p, h->out.p, (size_t)W * 8, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  if ((rc = wait_stream(h->stream))) return rc;
   memcpy(out, h->stage_out.p, (size_t)W * 8);
   return CF_OK;
 }

@@ -316,4 +316,6 @@ class LikelihoodEngine:
     def info(self) -> dict:
         i = L.cf_info()
         L.check(L.lib().cf_get_info(self._h, C.byref(i)))
-        return {k: (getattr(i, k).decode() if k == "gcn_arch" else getattr(i, k)) for k, _ in L.cf_info._fields_}
+        out = {k: (getattr(i, k).decode() if k == "gcn_arch" else getattr(i, k)) for k, _ in L.cf_info._fields_}
+        out["devices"] = list(i.devices)[: min(int(i.n_devices), 16)]
+        return out
