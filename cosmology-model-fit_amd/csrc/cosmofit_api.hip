@@ -1260,6 +1260,8 @@ extern "C" int cf_eval_table(cf_handle* h, const double* theta, int64_t W, doubl
   const int G = d.n_grid;
   d.n_sn = 0;
   d.n_bao = 0;
+  d.n_fs8 = 0;
+  d.n_aux = 0;  // no table-node copies either: their buffer is not passed
   d.n_ld = 0;
   DevBuf tab;
   if (tab.ensure((size_t)W * G * sizeof(d2))) return CF_ERR_HIP;

@@ -57,6 +57,11 @@ class _Base:
     def cmb_distances(self, params):
         return self.engine.parts(params)["cmb_vector"][0]
 
+    def DM_z(self, z, params):
+        """``DM_z(z, params)`` of the joint scripts (bao/desi_cmb_des5y.py:60-66 + interp_hermite): comoving distance at
+        arbitrary redshifts from the walker's table (GPU) and the GPU Hermite operator."""
+        return self.engine.DM_z(params, z)
+
 
 class DesiBao(_Base):
     """bao/desi.py: theta = (h, Om, w0); bounds bao/desi.py:69-75; r_d = 147.09 Mpc fixed (:10)."""

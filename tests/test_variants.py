@@ -192,6 +192,10 @@ def test_gpu_config3_as_worded_w0wa_full_size(gpu):
     for k in range(4):
         np.testing.assert_allclose(parts["bao_theory"][k], g["theory"][k], rtol=1e-12)
         np.testing.assert_allclose(parts["cmb_vector"][k], g["cmb_dist"][k], rtol=1e-12)
+    # the table accessor on a joint likelihood (BAO / CMB blocks present: their node copies must stay off in that launch)
+    zq = np.array([0.0, 0.295, 0.51, 1.317, 2.33])
+    cum, dh = onp.dm_grid(lk_bao_desi_cmb_des5y_cpl(g, base, chol), g["thetas"][0])
+    np.testing.assert_allclose(lk.DM_z(zq, g["thetas"][0]), onp.interp_hermite(zq, np.linspace(0, lk.z_max, 4000), cum, dh), rtol=1e-12, atol=1e-9)
     box = np.array([(-0.5, 0.5), (60.0, 75.0), (0.010, 0.030), (0.01, 0.25), (-4.5, 4.5), (-3.0, -0.2), (-3.0, 0.1)])
     theta = gpu.synthetic.walkers(box, 4096, seed=3)
     got = lk.log_likelihood(theta)
