@@ -970,7 +970,7 @@ static int launch_tri_gemm(const TriGemmArgs& a, hipStream_t st) {
     const char* e = getenv("CF_GEMM_SHAPE");
     return (e && strlen(e) == 3 && e[1] == 'x') ? (e[0] - '0') * 16 + (e[2] - '0') : 0;
   }();
-  int np = a.W > 256 ? 2 : 1, pf = 2;
+  int np = a.W > 768 ? 2 : 1, pf = 2;  // measured: NP = 1 wins up to 512 walkers (48 vs 53 us), ties at 1024-2048, loses 10 % at 4096
   if (shape) { np = shape / 16; pf = shape % 16; }
   switch (np * 16 + pf) {
     case 1 * 16 + 2: return launch_tri_gemm_t<1, 2>(a, st);
