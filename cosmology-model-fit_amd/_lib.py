@@ -78,7 +78,7 @@ class cf_desc(C.Structure):
         ("om_mode", C.c_int32), ("rd_wm_mode", C.c_int32), ("sn_lin_coef", C.c_void_p), ("sn_dir", C.c_void_p),
         ("n_fs8", C.c_int32), ("fs8_steps", C.c_int32),
         ("fs8_z", C.c_void_p), ("fs8_val", C.c_void_p), ("fs8_inv_cov", C.c_void_p), ("fs8_fid", C.c_void_p),
-        ("fs8_a_init", C.c_double),
+        ("logl_const", C.c_double), ("fs8_a_init", C.c_double),
     ]
 
 

@@ -404,6 +404,7 @@ static int validate_desc(const cf_desc* c) {
       if (!(1.0 / (1.0 + c->fs8_z[k]) >= c->fs8_a_init) || c->fs8_z[k] < 0.0)
         return fail(CF_ERR_INVALID, "cf_create: growth-rate data must lie in a_init <= a <= 1");
   }
+  if (!std::isfinite(c->logl_const)) return fail(CF_ERR_INVALID, "cf_create: logl_const must be finite");
   if (c->om_mode != 0 && c->om_mode != 1) return fail(CF_ERR_INVALID, "cf_create: om_mode must be 0 or 1");
   if (c->rd_wm_mode != 0 && c->rd_wm_mode != 1) return fail(CF_ERR_INVALID, "cf_create: rd_wm_mode must be 0 or 1");
   if (c->n_devices < -1 || c->n_devices > 64 || (c->n_devices > 0 && !c->devices))
@@ -508,6 +509,7 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
   d.fs8_a_init = c->fs8_a_init;
   d.n_aux = c->n_bao + c->n_fs8;
   d.cpl_wall = c->cpl_wall;
+  d.logl_const = c->logl_const;
   d.has_bounds = c->bounds != nullptr;
   d.log_norm = 0.0;
   if (c->bounds) {

@@ -1035,7 +1035,7 @@ __device__ double finalize_value(const cf_dev_desc& d, const double* __restrict_
     atomicAdd(nonfinite, 1ull);
     return -INFINITY;
   }
-  double ll = -0.5 * chi2;
+  double ll = -0.5 * chi2 + d.logl_const;
   if (d.n_fs8 > 0)  // -0.5 (chi2 - 2 N ln f_err), fs8/fs8.py:123-125 (f_err fixed to 1 where a script has none)
     ll += d.n_fs8 * log(slot_get(d, CF_P_FS8ERR_D, th));
   if (d.n_cc > 0)  // Gaussian normalisation with rescaled errors, bao/desi_union3_cc_theta_star.py:135-139

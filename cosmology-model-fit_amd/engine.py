@@ -52,7 +52,7 @@ class LikelihoodEngine:
                  bao: Optional[dict] = None, cmb: Optional[dict] = None, physical: Optional[dict] = None,
                  cc: Optional[dict] = None, fs8: Optional[dict] = None, solve_mode: int = L.CF_SOLVE_AUTO,
                  bounds=None, gauss: Sequence = (), chi2_gauss: Sequence = (), cpl_wall: bool = False,
-                 device: int = 0, devices=None, probe_limit: float = 0.0, om_mode: int = 0, c_km_s: float = C_KM_S):
+                 device: int = 0, devices=None, probe_limit: float = 0.0, om_mode: int = 0, logl_const: float = 0.0, c_km_s: float = C_KM_S):
         """
         params: {"H0": Param(1), "Om": Param(2), ...} for the slots of include/cosmofit.h (cf_param_slot).
         sn: dict(z_cmb, z_hel, obs, chol[, step | z_turn, fixed_mu, lin_coef, dirs]) — chol is
@@ -60,6 +60,7 @@ class LikelihoodEngine:
             mu_theory for SN i (SH0ES Cepheid hosts, sn/pantheon_and_sh0es.py:63-69); lin_coef[i] multiplies the "lin"
             slot and is added to the offset (bulk-flow magnitude term, bao/desi_cmb_pantheon_H0trgb.py:102-106); dirs
             [N, 3] unit vectors make the peculiar velocity n . (v, v2, v3) x step (sn/pantheon_dipole_xyz.py:50-60).
+        logl_const: constant added to log L (Gaussian normalisations a script keeps in its log-likelihood).
         om_mode: 1 = the "Om" slot holds omega_m = Omega_m h^2 (bao/desi_omh2.py:18-20).
         fs8: dict(z, val, inv_cov, fid, a_init[, steps]) — growth-rate block with the slots "s8" and "fs8err"
             (fs8/fs8.py:64-125); fid[k] = H_fid(z_k) D_M,fid(z_k) of the Alcock-Paczynski correction.
@@ -89,6 +90,7 @@ class LikelihoodEngine:
         d.solve_mode = int(solve_mode)
         d.probe_limit = float(probe_limit)
         d.om_mode = int(om_mode)
+        d.logl_const = float(logl_const)
         dev_arr = None
         if devices is not None:
             if isinstance(devices, str):

@@ -523,3 +523,49 @@ class Cc(_Base):
             params=dict(H0=Param(0), Om=Param(1), fcc=Param(2)),
             cc=dict(z=z_cc, h=H_cc, inv_cov=np.linalg.inv(cov_cc), logdet=np.linalg.slogdet(cov_cc)[1]),
             bounds=self.bounds, device=device, devices=devices)
+
+
+class Fs8Cmb(_Base):
+    """fs8/fs8_cmb.py: theta = (H0, wb, wc, w0, sigma8, f_err); bounds :186-195.  Growth-rate data + Planck/ACT (R, l_A, wb) in the
+    physical-density model with thawing dark energy; the growth ODE starts at a = 1 / 501 (:128-129); log L keeps
+    -0.5 (N ln 2 pi + logdet) + N ln f_err (:19-21,181-183)."""
+    bounds = np.array([(50, 80), (0.01, 0.035), (0.1, 0.35), (-1.0, 0.0), (0.5, 1.0), (0.2, 3.2)], dtype=float)
+    A_INIT = 1.0 / 501.0
+
+    def __init__(self, z, fs8_vals, cov_mat, fid, *, comp=None, device=0, devices=None, bounds=None, steps=0):
+        comp = cmb_data.PLANCK_ACT if comp is None else comp
+        z = np.asarray(z, dtype=np.float64)
+        self.bounds = self.bounds if bounds is None else np.asarray(bounds, float)
+        self.z_max = float(np.max(z) + 0.1)  # :25
+        norm_factor = len(z) * np.log(2 * np.pi) + np.linalg.slogdet(cov_mat)[1]  # :19-20
+        self.engine = LikelihoodEngine(
+            ndim=6, z_max=self.z_max, n_grid=N_GRID, ez_model=L.CF_EZ_PHYSICAL, fde=L.CF_FDE_THAWING,
+            params=dict(H0=Param(0), obh2=Param(1), och2=Param(2), w0=Param(3), s8=Param(4), fs8err=Param(5)),
+            cmb=dict(mode=comp["cmb_mode"], prior=comp["cmb_prior"], inv_cov=comp["cmb_inv_cov"], zstar_fit=comp["zstar_fit"]),
+            fs8=dict(z=z, val=fs8_vals, inv_cov=np.linalg.inv(cov_mat), fid=fid, a_init=self.A_INIT, steps=steps),
+            physical=_physical(comp), logl_const=-0.5 * norm_factor, bounds=self.bounds, device=device, devices=devices)
+
+    def fs8_theory(self, params):
+        return self.engine.parts(params)["fs8_theory"][0]
+
+
+class DesiFsLyaCcFs8(_Base):
+    """bao/desi_fs_lya_cc_fs8.py: theta = (H0, Om, sigma8, f_cc, f_fs8, r_d, w0).  DESI FS+Lya BAO (F_AP, D_H = c / H, free r_d),
+    cosmic chronometers (f_cc) and growth-rate data (f_fs8), late-time flat thawing; the growth ODE starts at a = 1 / 201
+    (:115-116); log L keeps both Gaussian normalisations (:183-192)."""
+    A_INIT = 1.0 / 201.0
+
+    def __init__(self, bao_z, bao_val, bao_qty, bao_inv_cov, z_cc, H_cc, cov_cc, fs8_z, fs8_vals, fs8_cov, fs8_fid, *, device=0,
+                 devices=None, steps=0):
+        self.z_max = float(max(np.max(fs8_z), np.max(z_cc), np.max(bao_z)) + 0.1)  # :28-29
+        norm_fs8 = len(fs8_z) * np.log(2 * np.pi) + np.linalg.slogdet(fs8_cov)[1]
+        self.engine = LikelihoodEngine(
+            ndim=7, z_max=self.z_max, n_grid=N_GRID, fde=L.CF_FDE_THAWING,
+            params=dict(H0=Param(0), Om=Param(1), s8=Param(2), fcc=Param(3), fs8err=Param(4), rd=Param(5), w0=Param(6)),
+            bao=dict(z=bao_z, val=bao_val, qty=bao_qty, inv_cov=bao_inv_cov, dh_exact=True),
+            cc=dict(z=z_cc, h=H_cc, inv_cov=np.linalg.inv(cov_cc), logdet=np.linalg.slogdet(cov_cc)[1]),
+            fs8=dict(z=fs8_z, val=fs8_vals, inv_cov=np.linalg.inv(fs8_cov), fid=fs8_fid, a_init=self.A_INIT, steps=steps),
+            logl_const=-0.5 * norm_fs8, device=device, devices=devices)
+
+    def fs8_theory(self, params):
+        return self.engine.parts(params)["fs8_theory"][0]

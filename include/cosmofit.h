@@ -270,6 +270,8 @@ typedef struct cf_desc {
   const double* fs8_val;    /* [n_fs8] */
   const double* fs8_inv_cov;/* [n_fs8*n_fs8] */
   const double* fs8_fid;    /* [n_fs8] H_fid(z_k) D_M,fid(z_k) in the units H(z) D_M(z) has for this descriptor */
+  double logl_const;        /* constant added to log L (CF_OUT_LOGL / CF_OUT_LOGP): Gaussian normalisations a script keeps in its
+                               log-likelihood, e.g. -0.5 (N ln 2 pi + logdet) of the growth-rate block, fs8/fs8_cmb.py:20,181-183 */
   double fs8_a_init;        /* 10^-2.15 (fs8/fs8.py:79), 10^-2.7 (bao/desi_cmb_union3_fs8.py:168), 1/201 (ohd/cc_fs8.py:86-87) */
 } cf_desc;
 

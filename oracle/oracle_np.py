@@ -212,6 +212,7 @@ class Likelihood:
     gauss: Sequence = ()  # (idx, mean, sigma) on the log-prior
     chi2_gauss: Sequence = ()  # (idx, mean, sigma) added to chi^2
     cpl_wall: bool = False  # w0 + wa >= 0 -> log L = -1e8   (bao/desi_fs_lya_cmb.py:118-121)
+    logl_const: float = 0.0  # constant added to log L (fs8/fs8_cmb.py:20,181-183: -0.5 (N ln 2 pi + logdet))
 
     def __post_init__(self):
         # z_grid / dz exactly as sn/pantheon.py:16-17
@@ -508,7 +509,7 @@ def log_likelihood(lk: Likelihood, theta) -> float:
     theta = np.asarray(theta, dtype=np.float64)
     if lk.cpl_wall and lk.w0.get(theta) + lk.wa.get(theta) >= 0.0:
         return -1e8  # bao/desi_fs_lya_cmb.py:118-121
-    ll = -0.5 * chi_squared(lk, theta)
+    ll = -0.5 * chi_squared(lk, theta) + lk.logl_const
     if lk.fs8_z is not None:  # fs8/fs8.py:123-125: -0.5 (chi2 - 2 N ln f_err)
         ll += len(lk.fs8_z) * np.log(lk.fs8err.get(theta))
     if lk.cc_z is not None:  # bao/desi_union3_cc_theta_star.py:135-139

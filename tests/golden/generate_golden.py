@@ -844,6 +844,50 @@ def case_ohd_cc():
     print("ohd_cc.npz chi2[-2:] =", out["chi2"][-2:])
 
 
+def case_fs8_fs8_cmb():
+    """fs8/fs8_cmb.py: growth-rate data + Planck/ACT compressed CMB in the physical-density model with thawing dark energy;
+    theta = (H0, wb, wc, w0, sigma8, f_err); the ODE starts at a = 1 / 501 (:128-129); log L keeps the Gaussian normalisation
+    N ln 2 pi + logdet - 2 N ln f_err (:19-21,181-183)."""
+    _enter_reference()
+    import fs8.fs8_cmb as m
+
+    rng = np.random.default_rng(71)
+    thetas = theta_batch(m.bounds, 8, rng)[:10]
+    thetas = np.vstack([thetas, [[67.5, 0.0224, 0.119, -0.9, 0.8, 1.5]]])
+    out = dict(_cmb_consts(m.cmb))
+    out.update(fs8_z=m.z_vals, fs8_val=m.fs8_vals, fs8_cov=m.fs8_data.cov_mat, fs8_fid=m.Hz_DMz_fid, a_span=m.a_span,
+               z_max=np.float64(m.z_grid[-1]), bounds=m.bounds, thetas=thetas, norm_factor=np.float64(m.norm_factor),
+               chi2=np.array([m.chi_squared(t) for t in thetas]), logl=np.array([m.log_likelihood(t) for t in thetas]),
+               chi2_parts=np.array([[m.chi2_fs8(t), m.chi2_cmb(t)] for t in thetas]),
+               theory=np.array([m.fs8_theory(m.a_vals, t) for t in thetas[:3]]),
+               theory_tight=np.array([_tight_fs8_theory(m, m.a_vals, m.a_span, t[-2], (t,)) for t in thetas[:3]]))
+    np.savez_compressed(os.path.join(HERE, "fs8_fs8_cmb.npz"), **out)
+    print("fs8_fs8_cmb.npz chi2[-2:] =", out["chi2"][-2:],
+          "reference's own integration error on theory: %.2e" % np.max(np.abs(out["theory"] / out["theory_tight"] - 1)))
+
+
+def case_bao_desi_fs_lya_cc_fs8():
+    """bao/desi_fs_lya_cc_fs8.py: DESI FS+Lya BAO (F_AP, exact D_H, free r_d) + cosmic chronometers (f_cc) + growth-rate data
+    (f_fs8), late-time flat thawing; theta = (H0, Om, sigma8, f_cc, f_fs8, r_d, w0); both Gaussian normalisations in log L
+    (:183-192).  All data real."""
+    _enter_reference()
+    import bao.desi_fs_lya_cc_fs8 as m
+
+    rng = np.random.default_rng(72)
+    box = [(40.0, 100.0), (0.1, 0.6), (0.1, 1.5), (0.03, 3.0), (0.2, 3.0), (110.0, 180.0), (-1.0, 0.0)]  # main() (:204-210)
+    thetas = np.vstack([_uniform(box, 10, rng), [[68.0, 0.3, 0.8, 1.0, 1.0, 147.0, -0.9]]])
+    out = _bao_inputs(m.data, m.bao_cov_matrix, m.desi_qty, m.inv_cov_bao)
+    out.update(cc_z=m.z_cc, cc_h=m.H_values, cc_cov=m.cov_matrix, fs8_z=m.z_fs8, fs8_val=m.fs8_values, fs8_cov=m.fs8.cov_mat,
+               fs8_fid=m.Hz_DMz_fid, a_span=m.a_span, z_max=np.float64(m.z_grid[-1]), thetas=thetas,
+               chi2=np.array([m.chi_squared(t) for t in thetas]), logl=np.array([m.log_likelihood(t) for t in thetas]),
+               chi2_parts=np.array([[m.chi2_cc(t), m.chi2_fs8(t), m.chi2_bao(t)] for t in thetas]),
+               theory=np.array([m.fs8_theory(m.a_fs8, t) for t in thetas[:3]]),
+               theory_tight=np.array([_tight_fs8_theory(m, m.a_fs8, m.a_span, t[2], (t,)) for t in thetas[:3]]))
+    np.savez_compressed(os.path.join(HERE, "bao_desi_fs_lya_cc_fs8.npz"), **out)
+    print("bao_desi_fs_lya_cc_fs8.npz chi2[-2:] =", out["chi2"][-2:],
+          "reference's own integration error on theory: %.2e" % np.max(np.abs(out["theory"] / out["theory_tight"] - 1)))
+
+
 CASES = {
     "interpolator": case_interpolator,
     "sn_pantheon": case_sn_pantheon,
@@ -875,6 +919,8 @@ CASES = {
     "bao_desi_bbn": case_bao_desi_bbn,
     "bao_desi_cc": case_bao_desi_cc,
     "ohd_cc": case_ohd_cc,
+    "fs8_fs8_cmb": case_fs8_fs8_cmb,
+    "bao_desi_fs_lya_cc_fs8": case_bao_desi_fs_lya_cc_fs8,
 }
 
 if __name__ == "__main__":

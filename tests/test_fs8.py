@@ -48,7 +48,27 @@ def lk_cc_fs8(g):
                           fs8_val=g["fs8_val"], fs8_inv_cov=np.linalg.inv(g["fs8_cov"]), fs8_fid=g["fs8_fid"], fs8_a_span=g["a_span"])
 
 
-CASES = {"fs8_fs8": lk_fs8, "bao_desi_cmb_union3_fs8": lk_union3_fs8, "ohd_cc_fs8": lk_cc_fs8}
+def lk_fs8_cmb(g):
+    d = _cmbdata("PLANCK_ACT")
+    return onp.Likelihood(ndim=6, z_max=float(g["z_max"]), ez_model=onp.EZ_PHYSICAL, fde=onp.FDE_THAWING, H0=onp.Slot(0),
+                          obh2=onp.Slot(1), och2=onp.Slot(2), w0=onp.Slot(3), s8=onp.Slot(4), fs8err=onp.Slot(5), cmb_mode=1,
+                          cmb_prior=d["cmb_prior"], cmb_inv_cov=d["cmb_inv_cov"], zstar_fit=d["zstar_fit"], fs8_z=g["fs8_z"],
+                          fs8_val=g["fs8_val"], fs8_inv_cov=np.linalg.inv(g["fs8_cov"]), fs8_fid=g["fs8_fid"], fs8_a_span=g["a_span"],
+                          logl_const=-0.5 * float(g["norm_factor"]), bounds=g["bounds"], **_phys(d))
+
+
+def lk_fs_lya_cc_fs8(g):
+    norm_fs8 = len(g["fs8_z"]) * np.log(2 * np.pi) + np.linalg.slogdet(g["fs8_cov"])[1]
+    return onp.Likelihood(ndim=7, z_max=float(g["z_max"]), fde=onp.FDE_THAWING, H0=onp.Slot(0), Om=onp.Slot(1), s8=onp.Slot(2),
+                          fcc=onp.Slot(3), fs8err=onp.Slot(4), rd=onp.Slot(5), w0=onp.Slot(6), bao_z=g["bao_z"], bao_val=g["bao_val"],
+                          bao_qty=g["bao_qty"], bao_inv_cov=g["bao_inv_cov"], bao_dh_exact=True, cc_z=g["cc_z"], cc_h=g["cc_h"],
+                          cc_inv_cov=np.linalg.inv(g["cc_cov"]), cc_logdet=np.linalg.slogdet(g["cc_cov"])[1], fs8_z=g["fs8_z"],
+                          fs8_val=g["fs8_val"], fs8_inv_cov=np.linalg.inv(g["fs8_cov"]), fs8_fid=g["fs8_fid"], fs8_a_span=g["a_span"],
+                          logl_const=-0.5 * norm_fs8)
+
+
+CASES = {"fs8_fs8": lk_fs8, "bao_desi_cmb_union3_fs8": lk_union3_fs8, "ohd_cc_fs8": lk_cc_fs8, "fs8_fs8_cmb": lk_fs8_cmb,
+         "bao_desi_fs_lya_cc_fs8": lk_fs_lya_cc_fs8}
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -150,4 +170,27 @@ def test_gpu_cc_fs8(gpu):
     np.testing.assert_allclose(parts["chi2_cc"], g["chi2_parts"][:, 0], rtol=1e-10)
     np.testing.assert_allclose(parts["chi2_fs8"], g["chi2_parts"][:, 1], rtol=CHI2_VS_REFERENCE)
     np.testing.assert_allclose(lk.log_likelihood(g["thetas"]), g["logl_vec"], rtol=CHI2_VS_REFERENCE)
+    lk.engine.close()
+
+
+@pytest.mark.gpu
+def test_gpu_fs8_cmb(gpu):
+    g = golden("fs8_fs8_cmb")
+    lk = gpu.likelihoods.Fs8Cmb(g["fs8_z"], g["fs8_val"], g["fs8_cov"], g["fs8_fid"], bounds=g["bounds"])
+    _check_gpu(lk, g)
+    parts = lk.engine.parts(g["thetas"][np.isfinite(g["chi2"])])
+    np.testing.assert_allclose(parts["chi2_blocks"][:, 2], g["chi2_parts"][np.isfinite(g["chi2"]), 1], rtol=1e-10)  # CMB block: 1e-10
+    lk.engine.close()
+
+
+@pytest.mark.gpu
+def test_gpu_desi_fs_lya_cc_fs8(gpu):
+    g = golden("bao_desi_fs_lya_cc_fs8")
+    lk = gpu.likelihoods.DesiFsLyaCcFs8(g["bao_z"], g["bao_val"], g["bao_qty"], g["bao_inv_cov"], g["cc_z"], g["cc_h"], g["cc_cov"],
+                                        g["fs8_z"], g["fs8_val"], g["fs8_cov"], g["fs8_fid"])
+    _check_gpu(lk, g)
+    parts = lk.engine.parts(g["thetas"])
+    np.testing.assert_allclose(parts["chi2_cc"], g["chi2_parts"][:, 0], rtol=1e-10)
+    np.testing.assert_allclose(parts["chi2_blocks"][:, 1], g["chi2_parts"][:, 2], rtol=1e-10)
+    np.testing.assert_allclose(parts["chi2_fs8"], g["chi2_parts"][:, 1], rtol=CHI2_VS_REFERENCE)
     lk.engine.close()
