@@ -10,7 +10,7 @@ from ._lib import CosmofitError, build, lib
 from ._lib import (CF_FDE_CPL, CF_FDE_LCDM, CF_FDE_THAWING, CF_FDE_WCDM, CF_OUT_CHI2, CF_OUT_LOGL, CF_OUT_LOGP,
                    CF_SOLVE_AUTO, CF_SOLVE_BLOCKED_TRSM, CF_SOLVE_INVERSE_GEMM)
 from .engine import C_KM_S, LikelihoodEngine, Param
-from . import cmb_data, interpolator, laplace, likelihoods, solve_triangular, sn_pantheon, synthetic
+from . import cmb_data, interpolator, laplace, likelihoods, scripts, solve_triangular, sn_pantheon, synthetic
 
 
 

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COSMOFIT_LIB") or os.path.join(_HERE, "libcosmofit_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-CF_ABI_VERSION = 5
+CF_ABI_VERSION = 6
 CF_P_NSLOTS = 15
 SLOTS = ("offset", "H0", "Om", "obh2", "och2", "w0", "wa", "v", "rd", "fcc", "lin", "v2", "v3", "s8", "fs8err")
 
@@ -79,6 +79,7 @@ class cf_desc(C.Structure):
         ("n_fs8", C.c_int32), ("fs8_steps", C.c_int32),
         ("fs8_z", C.c_void_p), ("fs8_val", C.c_void_p), ("fs8_inv_cov", C.c_void_p), ("fs8_fid", C.c_void_p),
         ("logl_const", C.c_double), ("fs8_a_init", C.c_double),
+        ("sn_vel_mode", C.c_int32), ("cc_f_mode", C.c_int32), ("prior_norm_mode", C.c_int32), ("_pad6", C.c_int32),
     ]
 
 

@@ -405,6 +405,10 @@ static int validate_desc(const cf_desc* c) {
         return fail(CF_ERR_INVALID, "cf_create: growth-rate data must lie in a_init <= a <= 1");
   }
   if (!std::isfinite(c->logl_const)) return fail(CF_ERR_INVALID, "cf_create: logl_const must be finite");
+  if ((c->sn_vel_mode | 1) != 1 || (c->cc_f_mode | 1) != 1 || (c->prior_norm_mode | 1) != 1)
+    return fail(CF_ERR_INVALID, "cf_create: sn_vel_mode, cc_f_mode and prior_norm_mode must be 0 or 1");
+  if (c->sn_vel_mode == 1 && (c->sn_dir || c->sn_fixed_mu))
+    return fail(CF_ERR_INVALID, "cf_create: sn_vel_mode 1 cannot be combined with sn_dir or sn_fixed_mu");
   if (c->om_mode != 0 && c->om_mode != 1) return fail(CF_ERR_INVALID, "cf_create: om_mode must be 0 or 1");
   if (c->rd_wm_mode != 0 && c->rd_wm_mode != 1) return fail(CF_ERR_INVALID, "cf_create: rd_wm_mode must be 0 or 1");
   if (c->n_devices < -1 || c->n_devices > 64 || (c->n_devices > 0 && !c->devices))
@@ -510,6 +514,8 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
   d.n_aux = c->n_bao + c->n_fs8;
   d.cpl_wall = c->cpl_wall;
   d.logl_const = c->logl_const;
+  d.sn_vel_mult = c->sn_vel_mode == 1;
+  d.cc_f_inverse = c->cc_f_mode == 1;
   d.has_bounds = c->bounds != nullptr;
   d.log_norm = 0.0;
   if (c->bounds) {
@@ -520,7 +526,7 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
       if (!(d.hi[k] > d.lo[k])) return bail(fail(CF_ERR_INVALID, "cf_create: bounds must satisfy lo < hi"));
       s += std::log(d.hi[k] - d.lo[k]);  // normalization = -sum(log(hi-lo)), sn/pantheon.py:77
     }
-    d.log_norm = -s;
+    d.log_norm = c->prior_norm_mode == 1 ? 0.0 : -s;  // ohd/cc_cmb.py:70-73 returns 0.0 inside the box
   }
   d.n_gauss = c->n_gauss;
   for (int g = 0; g < c->n_gauss; ++g) {

@@ -119,6 +119,7 @@ struct cf_dev_desc {
   // priors
   int32_t has_bounds, n_gauss, n_chi2_gauss, cpl_wall;
   double log_norm;  // -sum(log(hi-lo))
+  int32_t sn_vel_mult, cc_f_inverse;  // cf_desc.sn_vel_mode / cc_f_mode == 1
   double logl_const;  // constant added to log L (Gaussian normalisations kept in a script's log-likelihood)
   double lo[CF_MAX_NDIM], hi[CF_MAX_NDIM];
   int32_t gauss_idx[CF_MAX_GAUSS];

@@ -661,7 +661,7 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
     const double v100 = 100 * slot_get(d, CF_P_V_D, th);
     const double lin = d.sn_lin ? slot_get(d, CF_P_LIN_D, th) : 0.0;
     const bool parts = dm_out != nullptr || mucorr_out != nullptr;
-    if (!parts && !d.sn_fixed_mu && !d.sn_dir && (!d.sn_lin || d.lin_in_rec)) {
+    if (!parts && !d.sn_fixed_mu && !d.sn_dir && !d.sn_vel_mult && (!d.sn_lin || d.lin_in_rec)) {
       if (d.lin_in_rec) sn_fast_loop<false, true>(d, T, log_tab, out, off, v100, tid, lin);
       else if (d.step_pm1) sn_fast_loop<true>(d, T, log_tab, out, off, v100, tid);
       else sn_fast_loop<false>(d, T, log_tab, out, off, v100, tid);
@@ -679,6 +679,7 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
                                            : v100 * d.sn_step[i];
             const double z_pec = v_km_s / d.c;
             z_cosmo = -1.0 + (1.0 + zc) / (1.0 + z_pec);
+            if (d.sn_vel_mult) z_cosmo = fmax((1.0 + zc) * (1.0 + z_pec) - 1.0, 1e-8);  // bao/desi_pantheon_cc.py:84-87
           }
           const double DMc = hermite_tab(T, z_cosmo);
           const double fixed = d.sn_fixed_mu ? d.sn_fixed_mu[i] : __longlong_as_double(0x7ff8000000000000ll);
@@ -834,7 +835,7 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
     __syncthreads();
     c_cc = group_quadratic_form(dl, d.cc_inv_cov, d.n_cc, sl);
     const double f = slot_get(d, CF_P_FCC_D, th);
-    c_cc *= f * f;
+    c_cc = d.cc_f_inverse ? c_cc * pow(f, -2.0) : c_cc * (f * f);  // ohd/cc_pantheon.py:64 / bao/desi_union3_cc_theta_star.py:130
     __syncthreads();  // dl is reused by the BAO block
   }
 
@@ -1039,7 +1040,8 @@ __device__ double finalize_value(const cf_dev_desc& d, const double* __restrict_
   if (d.n_fs8 > 0)  // -0.5 (chi2 - 2 N ln f_err), fs8/fs8.py:123-125 (f_err fixed to 1 where a script has none)
     ll += d.n_fs8 * log(slot_get(d, CF_P_FS8ERR_D, th));
   if (d.n_cc > 0)  // Gaussian normalisation with rescaled errors, bao/desi_union3_cc_theta_star.py:135-139
-    ll -= 0.5 * (d.n_cc * 1.8378770664093453 + d.cc_logdet - 2 * d.n_cc * log(slot_get(d, CF_P_FCC_D, th)));
+    ll -= 0.5 * (d.n_cc * 1.8378770664093453 + d.cc_logdet +
+                 (d.cc_f_inverse ? 2 : -2) * d.n_cc * log(slot_get(d, CF_P_FCC_D, th)));  // ohd/cc_pantheon.py:92
   return lp + ll;
 }
 

@@ -52,7 +52,7 @@ class LikelihoodEngine:
                  bao: Optional[dict] = None, cmb: Optional[dict] = None, physical: Optional[dict] = None,
                  cc: Optional[dict] = None, fs8: Optional[dict] = None, solve_mode: int = L.CF_SOLVE_AUTO,
                  bounds=None, gauss: Sequence = (), chi2_gauss: Sequence = (), cpl_wall: bool = False,
-                 device: int = 0, devices=None, probe_limit: float = 0.0, om_mode: int = 0, logl_const: float = 0.0, c_km_s: float = C_KM_S):
+                 device: int = 0, devices=None, probe_limit: float = 0.0, om_mode: int = 0, logl_const: float = 0.0, prior_normalised: bool = True, c_km_s: float = C_KM_S):
         """
         params: {"H0": Param(1), "Om": Param(2), ...} for the slots of include/cosmofit.h (cf_param_slot).
         sn: dict(z_cmb, z_hel, obs, chol[, step | z_turn, fixed_mu, lin_coef, dirs]) — chol is
@@ -91,6 +91,7 @@ class LikelihoodEngine:
         d.probe_limit = float(probe_limit)
         d.om_mode = int(om_mode)
         d.logl_const = float(logl_const)
+        d.prior_norm_mode = 0 if prior_normalised else 1
         dev_arr = None
         if devices is not None:
             if isinstance(devices, str):
@@ -119,6 +120,7 @@ class LikelihoodEngine:
             d.n_sn = z_cmb.size
             d.sn_z_cmb, d.sn_z_hel, d.sn_obs, d.sn_step = _ptr(z_cmb), _ptr(z_hel), _ptr(obs), _ptr(step)
             d.sn_z_turn = float(sn.get("z_turn", 0.15))
+            d.sn_vel_mode = 1 if sn.get("vel_mult", False) else 0
             d.sn_chol, d.sn_chol_ld = _ptr(chol), chol.shape[1]
             if sn.get("fixed_mu") is not None:
                 fm = _f64(sn["fixed_mu"])
@@ -163,6 +165,7 @@ class LikelihoodEngine:
                 raise ValueError("cc: z, h must have n entries and inv_cov must be (n, n)")
             keep += [cz, ch, cinv]
             d.n_cc, d.cc_z, d.cc_h, d.cc_inv_cov, d.cc_logdet = cz.size, _ptr(cz), _ptr(ch), _ptr(cinv), float(cc["logdet"])
+            d.cc_f_mode = 1 if cc.get("f_inverse", False) else 0
         self.n_fs8 = 0
         if fs8 is not None:
             fz, fv, finv, ffid = _f64(fs8["z"]), _f64(fs8["val"]), _f64(fs8["inv_cov"]), _f64(fs8["fid"])

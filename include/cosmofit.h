@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 5
+#define CF_ABI_VERSION 6
 
 typedef struct cf_handle cf_handle;
 
@@ -273,6 +273,14 @@ typedef struct cf_desc {
   double logl_const;        /* constant added to log L (CF_OUT_LOGL / CF_OUT_LOGP): Gaussian normalisations a script keeps in its
                                log-likelihood, e.g. -0.5 (N ln 2 pi + logdet) of the growth-rate block, fs8/fs8_cmb.py:20,181-183 */
   double fs8_a_init;        /* 10^-2.15 (fs8/fs8.py:79), 10^-2.7 (bao/desi_cmb_union3_fs8.py:168), 1/201 (ohd/cc_fs8.py:86-87) */
+
+  /* ---- further per-script conventions ---- */
+  int32_t sn_vel_mode;      /* 0: z_cosmo = -1 + (1 + z_cmb) / (1 + z_pec)                         sn/pantheon.py:43-48
+                               1: z_cosmo = max((1 + z_cmb) (1 + z_pec) - 1, 1e-8)                 bao/desi_pantheon_cc.py:84-90 */
+  int32_t cc_f_mode;        /* 0: chi2_cc * f_cc^2, log L += n_cc ln f_cc  (f_cc divides the errors, bao/desi_union3_cc_theta_star.py:129-139)
+                               1: chi2_cc * f_cc^-2, log L -= n_cc ln f_cc (f_cc multiplies them)   ohd/cc_pantheon.py:64,92 */
+  int32_t prior_norm_mode;  /* 0: log prior inside the box = -sum log(hi - lo) (sn/pantheon.py:77); 1: 0.0 (ohd/cc_cmb.py:70-73) */
+  int32_t _pad6;
 } cf_desc;
 
 typedef struct cf_info {

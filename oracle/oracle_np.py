@@ -212,6 +212,9 @@ class Likelihood:
     gauss: Sequence = ()  # (idx, mean, sigma) on the log-prior
     chi2_gauss: Sequence = ()  # (idx, mean, sigma) added to chi^2
     cpl_wall: bool = False  # w0 + wa >= 0 -> log L = -1e8   (bao/desi_fs_lya_cmb.py:118-121)
+    sn_vel_mult: bool = False  # z_cosmo = max((1 + z_cmb)(1 + z_pec) - 1, 1e-8), bao/desi_pantheon_cc.py:84-87
+    cc_f_inverse: bool = False  # chi2_cc * f^-2 and + 2 N ln f in the normalisation, ohd/cc_pantheon.py:64,92
+    prior_normalised: bool = True  # False: log prior = 0.0 inside the box, ohd/cc_cmb.py:70-73
     logl_const: float = 0.0  # constant added to log L (fs8/fs8_cmb.py:20,181-183: -0.5 (N ln 2 pi + logdet))
 
     def __post_init__(self):
@@ -386,6 +389,8 @@ def sn_parts(lk: Likelihood, theta, tables=None):
             v_km_s = 100 * lk.v.get(theta) * lk.step
         z_pec = v_km_s / lk.c
         z_cosmo = -1.0 + (1.0 + lk.z_cmb) / (1.0 + z_pec)
+        if lk.sn_vel_mult:
+            z_cosmo = np.maximum((1.0 + lk.z_cmb) * (1.0 + z_pec) - 1.0, 1e-8)
         mu_corr = 5.0 * np.log10(interp_hermite(z_cosmo, lk.z_grid, cum_dm, dh_grid) / DM)
     else:  # bao/desi_des5y_bbn_theta_star.py:94-97: no step term at all
         mu_corr = np.zeros_like(DM)
@@ -402,7 +407,8 @@ def sn_parts(lk: Likelihood, theta, tables=None):
 def chi2_cc(lk: Likelihood, theta) -> float:
     """bao/desi_union3_cc_theta_star.py:129-130."""
     delta = lk.cc_h - H_z(lk, lk.cc_z, theta)
-    return float(delta @ lk.cc_inv_cov @ delta * lk.fcc.get(theta) ** 2)
+    f = lk.fcc.get(theta)
+    return float(delta @ lk.cc_inv_cov @ delta * (f**-2 if lk.cc_f_inverse else f**2))
 
 
 # ---- growth rate f sigma_8: fs8/fs8.py:26-120, bao/desi_cmb_union3_fs8.py:27-207 ----------------------------------------
@@ -514,7 +520,8 @@ def log_likelihood(lk: Likelihood, theta) -> float:
         ll += len(lk.fs8_z) * np.log(lk.fs8err.get(theta))
     if lk.cc_z is not None:  # bao/desi_union3_cc_theta_star.py:135-139
         n_cc = len(lk.cc_z)
-        ll -= 0.5 * (n_cc * np.log(2 * np.pi) + lk.cc_logdet - 2 * n_cc * np.log(lk.fcc.get(theta)))
+        sign = 2 if lk.cc_f_inverse else -2  # ohd/cc_pantheon.py:92
+        ll -= 0.5 * (n_cc * np.log(2 * np.pi) + lk.cc_logdet + sign * n_cc * np.log(lk.fcc.get(theta)))
     return ll
 
 
@@ -525,7 +532,7 @@ def log_prior(lk: Likelihood, theta) -> float:
     if b is not None:
         if not np.all((b[:, 0] < theta) & (theta < b[:, 1])):
             return -np.inf
-        lp = -np.sum(np.log(b[:, 1] - b[:, 0]))
+        lp = -np.sum(np.log(b[:, 1] - b[:, 0])) if lk.prior_normalised else 0.0
     else:
         lp = 0.0
     for idx, mean, sigma in lk.gauss:

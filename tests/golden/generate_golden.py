@@ -888,6 +888,119 @@ def case_bao_desi_fs_lya_cc_fs8():
           "reference's own integration error on theory: %.2e" % np.max(np.abs(out["theory"] / out["theory_tight"] - 1)))
 
 
+# ---- scripts that are plain combinations of the blocks above: one generic case, data-driven ---------------------------------------
+def _qty_codes(bao):
+    return np.array([{"DV_over_rs": 0, "DM_over_rs": 1, "DH_over_rs": 2, "F_AP": 3}[str(q)] for q in bao["quantity"]], dtype=np.int32)
+
+
+def _cat_bao(m, *pairs):
+    """Several (data, covariance) attribute pairs of the module as ONE block-diagonal BAO block (what the scripts that
+    keep them apart sum: bao/desi_cmb_union3_H0trgb.py:122-131)."""
+    from scipy.linalg import block_diag
+
+    data = np.concatenate([getattr(m, a) for a, _ in pairs])
+    return data, block_diag(*[getattr(m, c) for _, c in pairs])
+
+
+# fixture name -> (module, SN injection, SN attribute names (z_cmb, z_hel, obs, cov), BAO (data, cov) getter, CC attribute names,
+#                  sampling box (the script's bounds / nautilus prior), fiducial row)
+GENERIC = {
+    "bao_desi_cmb_union3": ("bao.desi_cmb_union3", None, ("z_cmb", "z_hel", "mu_vals", "cov_matrix_sn"),
+                            lambda m: (m.bao, m.bao_cov_mat), None,
+                            [(-1, 1), (60, 75), (0.01, 0.03), (0.01, 0.25), (-8, 8)], [0.0, 67.5, 0.0224, 0.119, 0.5]),
+    "bao_desi_cmb_union3_H0trgb": ("bao.desi_cmb_union3_H0trgb", None, ("z_cmb", "z_hel", "mu_vals", "cov_matrix_sn"),
+                                   lambda m: _cat_bao(m, ("bao_data", "bao_cov_matrix"), ("sixdF_bao_data", "sixdF_bao_cov_matrix")), None,
+                                   [(-1, 1), (60, 75), (0.01, 0.03), (0.01, 0.25), (-9.5, 3.5)], [0.0, 68.5, 0.0224, 0.118, -1.0]),
+    "bao_desi_des5y_H0trgb": ("bao.desi_des5y_H0trgb", "dovekie", ("z_cmb", "z_hel", "mu_values", "cov_matrix_sn"),
+                              lambda m: (m.bao_data, m.cov_matrix_bao), None, "bounds", [0.0, 69.0, 145.0, 0.31, -0.85]),
+    "bao_desi_des5y_bbn": ("bao.desi_des5y_bbn", "dovekie", ("z_cmb", "z_hel", "mu_values", "cov_matrix_sn"),
+                           lambda m: (m.bao_data, m.bao_cov_matrix), None,
+                           [(55, 80), (0.10, 0.65), (0.020, 0.024), (-1.0, -1 / 3), (-0.5, 0.5)], [68.0, 0.31, 0.02218, -0.85, 0.0]),
+    "bao_desi_union3_bbn": ("bao.desi_union3_bbn", None, ("z_cmb", "z_hel", "mu_values", "cov_matrix_sn"),
+                            lambda m: (m.bao_data, m.bao_cov_mat), None,
+                            [(55, 80), (0.10, 0.65), (0.020, 0.024), (-12.0, 5.0), (-1.0, 1.0)], [68.0, 0.31, 0.02218, -1.0, 0.0]),
+    "bao_desi_bbn_theta_star": ("bao.desi_bbn_theta_star", None, None, lambda m: (m.bao_data, m.bao_cov_matrix), None,
+                                [(50, 90), (0.020, 0.024), (0.05, 0.30), (-1.0, 0.0)], [67.5, 0.02218, 0.119, -0.9]),
+    "bao_desi_union3_bbn_theta_star": ("bao.desi_union3_bbn_theta_star", None, ("z_cmb", "z_hel", "mu_values", "cov_matrix_sn"),
+                                       lambda m: (m.bao, m.cov_mat_bao), None,
+                                       [(-1, 1), (50, 90), (0.020, 0.024), (0.05, 0.30), (-8.5, 8.5)], [0.0, 67.5, 0.02218, 0.119, -1.0]),
+    "bao_desi_des5y_cc": ("bao.desi_des5y_cc", "dovekie", ("z_cmb", "z_hel", "mu_values", "cov_matrix_sn"),
+                          lambda m: (m.bao_data, m.cov_matrix_bao), ("z_cc_vals", "H_cc_vals", "cov_matrix_cc"), "bounds",
+                          [1.0, 0.0, 68.0, 147.0, 0.31, 0.5]),
+    "bao_desi_des5y_cc_theta_star": ("bao.desi_des5y_cc_theta_star", "dovekie", ("z_sn_vals", "z_sn_hel_vals", "mu_values", "cov_matrix_sn"),
+                                     lambda m: (m.bao_data, m.cov_matrix_bao), ("z_cc_vals", "H_cc_vals", "cov_matrix_cc"), "bounds",
+                                     [1.0, 0.0, 67.5, 0.0224, 0.119, -0.9]),
+    "bao_desi_fs_lya": ("bao.desi_fs_lya", None, None, lambda m: (m.data, m.cov_matrix), None,
+                        [(0.5, 0.8), (0.1, 0.8), (-1.0, 0.0)], [0.68, 0.3, -0.9]),
+    "bao_desi_fs_lya_union3_cc": ("bao.desi_fs_lya_union3_cc", None, ("z_cmb", "z_hel", "mu_vals", "cov_matrix_sn"),
+                                  lambda m: (m.bao_data, m.cov_matrix_bao), ("z_cc_vals", "H_cc_vals", "cov_matrix_cc"),
+                                  [(0.01, 3.0), (-1, 1), (45, 90), (100, 200), (0.2, 0.5), (-8.5, 8.5)], [1.0, 0.0, 68.0, 147.0, 0.31, -1.0]),
+    "bao_desi_pantheon_cc": ("bao.desi_pantheon_cc", "pantheon", ("z_cmb", "z_hel", "apparent_mag_values", "cov_matrix_sn"),
+                             lambda m: (m.bao_data, m.cov_matrix_bao), ("z_cc_vals", "H_cc_vals", "cov_matrix_cc"), "bounds",
+                             [68.0, -19.4, 147.0, 0.31, 0.5, 1.0]),
+    "bao_desi_des5y_obh2_theta_star": ("bao.desi_des5y_obh2_theta_star", "dovekie", ("z_cmb", "z_hel", "mu_values", "cov_matrix_sn"),
+                                       lambda m: (m.bao_data, m.cov_matrix_bao), None, "bounds", [0.0, 67.5, 0.0224, 0.119, -0.9]),
+    "bao_desi_pantheon_obh2_theta_star": ("bao.desi_pantheon_obh2_theta_star", "pantheon", ("z_cmb", "z_hel", "mag_values", "cov_matrix_sn"),
+                                          lambda m: (m.bao_data, m.cov_matrix_bao), None, "bounds", [-19.4, 67.5, 0.0224, 0.119, -0.9]),
+    "bao_desi_union3_obh2_theta_star": ("bao.desi_union3_obh2_theta_star", None, ("z_cmb", "z_hel", "mu_vals", "cov_matrix_sn"),
+                                        lambda m: (m.bao_data, m.cov_matrix_bao), None,
+                                        [(-1, 1), (50, 90), (0.01, 0.03), (0.05, 0.3), (-12, 5)], [0.0, 67.5, 0.0224, 0.119, -1.0]),
+    "ohd_cc_cmb": ("ohd.cc_cmb", None, None, None, ("z_values", "H_values", "cov_matrix_cc"), "bounds", [67.5, 0.0224, 0.119, 1.0]),
+    "ohd_cc_pantheon": ("ohd.cc_pantheon", "pantheon", ("z_cmb", "z_hel", "mB_vals", "cov_matrix_sn"), None,
+                        ("z_cc_vals", "H_cc_vals", "cov_matrix_cc"), "bounds", [1.0, 68.0, -19.4, 0.31, -0.85]),
+    "ohd_cc_union3": ("ohd.cc_union3", None, ("z_cmb", "z_hel", "mu_vals", "cov_matrix_sn"), None,
+                      ("z_cc_vals", "H_cc_vals", "cov_matrix_cc"),
+                      [(0.05, 3.35), (-1.0, 1.0), (40.0, 95.0), (0.1, 0.7), (-900, 900)], [1.0, 0.0, 68.0, 0.31, -100.0]),
+    "sn_union3_1_cmb": ("sn.union3_1_cmb", None, ("z_cmb", "z_hel", "mu_vals", "cov_matrix_sn"), None, None,
+                        [(-1, 1), (60, 75), (0.01, 0.03), (0.01, 0.25), (-9, 9)], [0.0, 67.5, 0.0224, 0.119, 0.5]),
+}
+
+
+def case_generic(name):
+    """One of the GENERIC scripts: the data its loaders return (the injected SN sets with their seeded covariance recipe),
+    a seeded theta batch from the script's own prior box, and chi_squared / log_likelihood / log_probability per row."""
+    import importlib
+
+    module, inject, sn, bao, cc, box, fid = GENERIC[name]
+    _enter_reference()
+    injected = {"dovekie": _inject_dovekie, "pantheon": _inject_pantheon, None: lambda: None}[inject]()
+    m = importlib.import_module(module)
+    rng = np.random.default_rng(sum(name.encode()))
+    has_bounds = isinstance(box, str)
+    thetas = theta_batch(np.asarray(getattr(m, box), float), 10, rng) if has_bounds else _uniform(box, 14, rng)
+    thetas = np.vstack([thetas, [fid]])
+    out = dict(thetas=thetas)
+    if has_bounds:
+        out["bounds"] = np.asarray(getattr(m, box), float)
+    if sn is not None:
+        out.update(z_cmb=getattr(m, sn[0]), z_hel=getattr(m, sn[1]), obs=getattr(m, sn[2]))
+        if injected is not None:
+            out["sigma"] = injected[3]  # covariance = synthetic_cov(sigma), regenerated by the tests
+        else:
+            out["cov_sn"] = getattr(m, sn[3])
+    if bao is not None:
+        data, cov = bao(m)
+        out.update(_bao_inputs(data, cov, _qty_codes(data), np.linalg.inv(cov)))
+    if cc is not None:
+        out.update(cc_z=getattr(m, cc[0]), cc_h=getattr(m, cc[1]), cc_cov=getattr(m, cc[2]))
+    grid = getattr(m, "z_grid", None)
+    if grid is not None:
+        out["z_max"] = np.float64(grid[-1])
+    with np.errstate(all="ignore"):
+        out["chi2"] = np.array([m.chi_squared(t) for t in thetas])
+        out["logl"] = np.array([m.log_likelihood(t) for t in thetas])
+        if hasattr(m, "log_probability"):
+            out["logp"] = np.array([m.log_probability(t) for t in thetas])
+        if hasattr(m, "bao_theory") and bao is not None:
+            data, _ = bao(m)
+            try:
+                out["theory"] = np.array([m.bao_theory(data["z"], _qty_codes(data), t) for t in thetas[-3:]])
+            except TypeError:  # (z, qty, params, DM_interp) signature
+                out["theory"] = np.array([m.bao_theory(data["z"], _qty_codes(data), t, m.DM_grid(t)) for t in thetas[-3:]])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name + ".npz chi2[-3:] =", out["chi2"][-3:], "logl[-1] =", out["logl"][-1])
+
+
 CASES = {
     "interpolator": case_interpolator,
     "sn_pantheon": case_sn_pantheon,
@@ -922,6 +1035,7 @@ CASES = {
     "fs8_fs8_cmb": case_fs8_fs8_cmb,
     "bao_desi_fs_lya_cc_fs8": case_bao_desi_fs_lya_cc_fs8,
 }
+CASES.update({name: (lambda name=name: case_generic(name)) for name in GENERIC})
 
 if __name__ == "__main__":
     if len(sys.argv) == 3 and sys.argv[1] == "--one":

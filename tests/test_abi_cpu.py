@@ -35,7 +35,7 @@ def test_desc_layout_matches_c(pkg, tmp_path):
     """sizeof / offsetof of cf_desc and cf_info as gcc sees them == the ctypes mirror."""
     fields = ["ndim", "z_max", "param", "n_sn", "sn_chol_ld", "n_bao", "rd_fit", "cmb_mode", "cmb_inv_cov", "nu_ws",
               "bounds", "gauss", "chi2_gauss", "sn_fixed_mu", "n_cc", "cc_logdet", "solve_mode", "probe_limit", "n_devices", "devices", "om_mode", "rd_wm_mode", "sn_lin_coef", "sn_dir", "n_fs8", "fs8_fid", "logl_const",
-              "fs8_a_init"]
+              "fs8_a_init", "sn_vel_mode", "cc_f_mode", "prior_norm_mode"]
     prog = '#include <stdio.h>\n#include <stddef.h>\n#include "cosmofit.h"\nint main(){printf("%zu %zu", sizeof(cf_desc), sizeof(cf_info));' + \
         "".join(f'printf(" %zu", offsetof(cf_desc, {f}));' for f in fields) + "return 0;}"
     src = tmp_path / "sz.c"
