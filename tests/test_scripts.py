@@ -137,6 +137,13 @@ def test_every_recipe_has_a_fixture_and_cites_a_script():
         scripts.build("bao/not_a_script.py")
 
 
+@pytest.fixture(scope="module")
+def gpu(pkg):
+    if pkg.lib().cf_device_count() < 1:
+        pytest.fail("GPU tests need an MI355X; no HIP device visible (there is no fallback path)")
+    return pkg
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("script", sorted(FIXTURE_OF))
 def test_gpu_script(gpu, script):
