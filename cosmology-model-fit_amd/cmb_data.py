@@ -78,3 +78,20 @@ PLANCK = _compression(
     94.07, (0.73491615, 1.00820929, 1.01709662, 1.17030559), (1.00078696, 1.00128548), 1, n_eff=3.046)
 
 BBN_SCHONEBERG = (0.02218, 0.00055)  # omega_b mean, sigma: y2024BBN/prior_lcdm_schoneberg.py:2-3
+
+
+# Derived parameters of the post-fit blocks (gd_samples.addDerived(cmb.z_star(...)), bao/desi_cmb_union3.py:181-192): the
+# fitting formulae with this compression's constants, vectorised over the posterior samples on the host.
+def z_star(comp, wb, wm):
+    """Redshift of photon decoupling, arXiv:2106.00428 eq. A-4 (cmb/data_planck_act_compression.py:86-99)."""
+    s1, s2, b, m = comp["zstar_fit"]
+    e0, a1, e1, e2, a2, e3, e4 = ZSTAR_CONSTS
+    wb, wm = np.asarray(wb, float) ** b, np.asarray(wm, float) ** m
+    return wm**e0 + s1 * a1 * wb**e1 * wm**e2 + s2 * a2 * wm**e3 * wb**e4
+
+
+def r_drag(comp, wb, wm):
+    """Sound horizon at the drag epoch in Mpc, arXiv:2106.00428 eq. 8 (cmb/data_planck_act_compression.py:102-124)."""
+    b, m, a1, a2, a3, a4, a5, a6, a7, a8, a9 = comp["rd_fit"]
+    wb, wm = np.asarray(wb, float) ** b, np.asarray(wm, float) ** m
+    return 1.0 / (a1 * wb**a2 + a3 * wb**a4 * wm**a5 + a6 * wm**a7) - a8 / wm**a9

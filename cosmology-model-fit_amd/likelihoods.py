@@ -569,3 +569,38 @@ class DesiFsLyaCcFs8(_Base):
 
     def fs8_theory(self, params):
         return self.engine.parts(params)["fs8_theory"][0]
+
+
+class CmbOnly(_Base):
+    """cmb/cmb.py: theta = (H0, wb, wc); bounds :29-35.  The Planck+ACT (R, l_A, wb) compression alone.  ``log_likelihood`` and
+    ``log_probability`` return (value, blobs) like the script (:45-70), blobs = (100 theta*, r_s(z*) in Mpc, D_M(z*) in Gpc, z*):
+    the first three follow from the (R, l_A) the device computed (D_M* = R c / (100 sqrt(wm)), r* = pi D_M* / l_A), z* from its
+    fitting formula."""
+    bounds = np.array([(60.0, 75.0), (0.020, 0.025), (0.05, 0.25)])
+
+    def __init__(self, *, comp=None, device=0, devices=None, bounds=None):
+        self.comp = comp = cmb_data.PLANCK_ACT if comp is None else comp
+        self.bounds = self.bounds if bounds is None else np.asarray(bounds, float)
+        self.z_max = 1.0  # no datum needs the distance table
+        self.engine = LikelihoodEngine(
+            ndim=3, z_max=self.z_max, n_grid=N_GRID, ez_model=L.CF_EZ_PHYSICAL, fde=L.CF_FDE_LCDM,
+            params=dict(H0=Param(0), obh2=Param(1), och2=Param(2)),
+            cmb=dict(mode=comp["cmb_mode"], prior=comp["cmb_prior"], inv_cov=comp["cmb_inv_cov"], zstar_fit=comp["zstar_fit"]),
+            physical=_physical(comp), bounds=self.bounds, device=device, devices=devices)
+
+    def blobs(self, params):
+        th = np.atleast_2d(np.asarray(params, float))
+        vec = self.engine.parts(th)["cmb_vector"]
+        wm = th[:, 1] + th[:, 2] + self.comp["omnu_h2"]
+        dm_star = vec[:, 0] * C_KM_S / (100 * np.sqrt(wm))
+        out = np.stack([100 * np.pi / vec[:, 1], np.pi * dm_star / vec[:, 1], dm_star / 1000, cmb_data.z_star(self.comp, th[:, 1], wm)], axis=1)
+        return out[0] if np.ndim(params) == 1 else out
+
+    def log_likelihood(self, params):
+        return self.engine.log_likelihood(params), self.blobs(params)
+
+    def log_probability(self, params):
+        """(log P, blobs); rows outside the box carry NaN blobs (the script returns np.empty(4) there, :66-67)."""
+        lp = self.engine.log_probability(params)
+        blobs = self.blobs(params)
+        return lp, np.where(np.isfinite(np.asarray(lp))[..., None], blobs, np.nan)

@@ -1001,6 +1001,22 @@ def case_generic(name):
     print(name + ".npz chi2[-3:] =", out["chi2"][-3:], "logl[-1] =", out["logl"][-1])
 
 
+def case_cmb_cmb():
+    """cmb/cmb.py: the Planck+ACT compression alone, theta = (H0, wb, wc); log_probability returns (log P, blobs) with
+    blobs = (100 theta*, r*, D_M* / 1000, z*) (:45-70)."""
+    _enter_reference()
+    import cmb.cmb as m
+
+    rng = np.random.default_rng(81)
+    thetas = np.vstack([theta_batch(m.bounds, 12, rng), [[67.5, 0.0224, 0.119]]])
+    lp = [m.log_probability(t) for t in thetas]
+    ll = [m.log_likelihood(t) for t in thetas]
+    logp = np.array([v[0] for v in lp])
+    out = dict(bounds=m.bounds, thetas=thetas, logp=logp, logl=np.array([v[0] for v in ll]), blobs=np.array([v[1] for v in ll]))
+    np.savez_compressed(os.path.join(HERE, "cmb_cmb.npz"), **out)
+    print("cmb_cmb.npz logp[-2:] =", logp[-2:], "blobs[-1] =", out["blobs"][-1])
+
+
 CASES = {
     "interpolator": case_interpolator,
     "sn_pantheon": case_sn_pantheon,
@@ -1035,6 +1051,7 @@ CASES = {
     "fs8_fs8_cmb": case_fs8_fs8_cmb,
     "bao_desi_fs_lya_cc_fs8": case_bao_desi_fs_lya_cc_fs8,
 }
+CASES["cmb_cmb"] = case_cmb_cmb
 CASES.update({name: (lambda name=name: case_generic(name)) for name in GENERIC})
 
 if __name__ == "__main__":

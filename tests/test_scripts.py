@@ -164,3 +164,43 @@ def test_gpu_script(gpu, script):
     if "theory" in g:
         np.testing.assert_allclose(lk.engine.parts(th[-3:])["bao_theory"], g["theory"], rtol=1e-11)
     lk.engine.close()
+
+
+# ---- cmb/cmb.py: the compression alone, with blobs ---------------------------------------------------------------------------------
+def _cmb_only_oracle(g):
+    d = load_pkg().cmb_data.PLANCK_ACT
+    return onp.Likelihood(ndim=3, z_max=1.0, ez_model=onp.EZ_PHYSICAL, H0=onp.Slot(0), obh2=onp.Slot(1), och2=onp.Slot(2), cmb_mode=1,
+                          cmb_prior=d["cmb_prior"], cmb_inv_cov=d["cmb_inv_cov"], zstar_fit=d["zstar_fit"], bounds=g["bounds"],
+                          **{k: d[k] for k in ("or_h2", "omnu_h2", "o_gamma_h2", "nu_m0", "nu_rho0", "nu_qs_sq", "nu_ws")})
+
+
+def test_oracle_cmb_only_and_host_fitting_formulae():
+    g = golden("cmb_cmb")
+    cmb_data = load_pkg().cmb_data
+    lk = _cmb_only_oracle(g)
+    for th, lp, ll, blob in zip(g["thetas"], g["logp"], g["logl"], g["blobs"]):
+        got = onp.log_probability(lk, th)
+        assert (got == lp) if not np.isfinite(lp) else got == pytest.approx(lp, rel=RTOL)
+        assert onp.log_likelihood(lk, th) == pytest.approx(ll, rel=RTOL)
+        wm = th[1] + th[2] + cmb_data.PLANCK_ACT["omnu_h2"]
+        assert cmb_data.z_star(cmb_data.PLANCK_ACT, th[1], wm) == pytest.approx(blob[3], rel=1e-14)  # blob z*: the reference's cmb.z_star
+    ref = golden("bao_desi_fs_lya_cmb")  # spot values of the reference's own cmb.z_star / cmb.r_drag
+    np.testing.assert_allclose(cmb_data.z_star(cmb_data.PLANCK_ACT, ref["fit_wb"], ref["fit_wm"]), ref["zstar_vals"], rtol=1e-14)
+    np.testing.assert_allclose(cmb_data.r_drag(cmb_data.PLANCK_ACT, ref["fit_wb"], ref["fit_wm"]), ref["rdrag_vals"], rtol=1e-14)
+
+
+@pytest.mark.gpu
+def test_gpu_cmb_only_with_blobs(gpu):
+    g = golden("cmb_cmb")
+    lk = gpu.likelihoods.CmbOnly()
+    np.testing.assert_array_equal(lk.bounds, g["bounds"])
+    lp, blobs = lk.log_probability(g["thetas"])
+    fin = np.isfinite(g["logp"])
+    assert np.array_equal(np.isfinite(lp), fin) and np.all(np.isnan(blobs[~fin]))
+    np.testing.assert_allclose(lp[fin], g["logp"][fin], rtol=RTOL)
+    ll, blobs_all = lk.log_likelihood(g["thetas"])  # the script evaluates log_likelihood (and its blobs) for any theta
+    np.testing.assert_allclose(ll, g["logl"], rtol=RTOL)
+    np.testing.assert_allclose(blobs_all, g["blobs"], rtol=1e-11)
+    one_lp, one_blob = lk.log_probability(g["thetas"][-1])
+    assert one_lp == pytest.approx(g["logp"][-1], rel=RTOL) and one_blob.shape == (4,)
+    lk.engine.close()
