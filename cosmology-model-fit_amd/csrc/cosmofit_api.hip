@@ -36,15 +36,16 @@ __global__ void walker_kernel(cf_dev_desc d, const double* theta, int64_t W, dou
 template <int MODEL, int FDE>
 __global__ void small_blocks_kernel(cf_dev_desc d, const double* theta, int64_t W, const d2* bao_nodes, double* chi2_extra,
                                     double* blocks_out, double* bao_out);
-template <int MODEL, int FDE>
-__global__ void growth_kernel(cf_dev_desc d, const double* theta, int64_t W, const d2* aux_nodes, double* scratch, double* chi2_extra,
-                              int accumulate, double* blocks_out, double* theory_out);
+template <int MODEL, int FDE, int C>
+__global__ void growth_kernel(cf_dev_desc d, const double* theta, int64_t W, const d2* aux_nodes, double* chi2_extra, int accumulate,
+                              double* blocks_out, double* theory_out);
+#define CF_DECLARE_GROWTH(M, F, C) \
+  extern template __global__ void growth_kernel<M, F, C>(cf_dev_desc, const double*, int64_t, const d2*, double*, int, double*, double*);
 #define CF_DECLARE_WALKER(M, F)                                                                                            \
   extern template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*, d2*); \
   extern template __global__ void small_blocks_kernel<M, F>(cf_dev_desc, const double*, int64_t, const d2*, double*,       \
                                                             double*, double*);                                            \
-  extern template __global__ void growth_kernel<M, F>(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, int, \
-                                                      double*, double*);
+  CF_DECLARE_GROWTH(M, F, 1) CF_DECLARE_GROWTH(M, F, 2) CF_DECLARE_GROWTH(M, F, 4) CF_DECLARE_GROWTH(M, F, 8)
 CF_DECLARE_WALKER(0, 0) CF_DECLARE_WALKER(0, 1) CF_DECLARE_WALKER(0, 2) CF_DECLARE_WALKER(0, 3)
 CF_DECLARE_WALKER(1, 0) CF_DECLARE_WALKER(1, 1) CF_DECLARE_WALKER(1, 2) CF_DECLARE_WALKER(1, 3)
 
@@ -62,11 +63,13 @@ static small_blocks_fn pick_small_blocks(int model, int fde) {
       {small_blocks_kernel<1, 0>, small_blocks_kernel<1, 1>, small_blocks_kernel<1, 2>, small_blocks_kernel<1, 3>}};
   return table[model][fde];
 }
-typedef void (*growth_fn)(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, int, double*, double*);
-static growth_fn pick_growth(int model, int fde) {
-  static const growth_fn table[2][4] = {{growth_kernel<0, 0>, growth_kernel<0, 1>, growth_kernel<0, 2>, growth_kernel<0, 3>},
-                                        {growth_kernel<1, 0>, growth_kernel<1, 1>, growth_kernel<1, 2>, growth_kernel<1, 3>}};
-  return table[model][fde];
+typedef void (*growth_fn)(cf_dev_desc, const double*, int64_t, const d2*, double*, int, double*, double*);
+#define CF_GROWTH_ROW(M, C) {growth_kernel<M, 0, C>, growth_kernel<M, 1, C>, growth_kernel<M, 2, C>, growth_kernel<M, 3, C>}
+static growth_fn pick_growth(int model, int fde, int steps) {  // steps = 256 C, C in {1, 2, 4, 8}
+  static const growth_fn table[4][2][4] = {{CF_GROWTH_ROW(0, 1), CF_GROWTH_ROW(1, 1)}, {CF_GROWTH_ROW(0, 2), CF_GROWTH_ROW(1, 2)},
+                                           {CF_GROWTH_ROW(0, 4), CF_GROWTH_ROW(1, 4)}, {CF_GROWTH_ROW(0, 8), CF_GROWTH_ROW(1, 8)}};
+  const int c = steps / 256;
+  return table[c == 1 ? 0 : c == 2 ? 1 : c == 4 ? 2 : 3][model][fde];
 }
 template <int KS, int TC>
 __global__ void trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* theta, int64_t W, const double* delta,
@@ -267,7 +270,7 @@ struct cf_handle {
   DevBuf z_cmb, z_hel, obs, sn_step, sn_rec, log10_tab;
   DevBuf bao_z, bao_val, bao_inv_cov, bao_qty, gl_x, gl_w, fixed_mu, cc_z, cc_h, cc_inv_cov, nu_grid, ln_grid, sn_lin, sn_dir;
   DevBuf theta, out, delta, ypk, chi2_extra, nonfinite;
-  DevBuf fs8_z, fs8_val, fs8_inv_cov, fs8_fid, fs8_step_of, fs8_order, fs8_scratch;
+  DevBuf fs8_z, fs8_val, fs8_inv_cov, fs8_fid, fs8_step_of, fs8_order, fs8_tab, fs8_pts;
   DevBuf bao_nodes, bao_base;  // [max_walkers][n_bao][CF_BAO_NODES] table nodes for small_blocks_kernel; first node per datum
   bool has_small_blocks = false;  // BAO and / or CMB block present
   bool has_growth = false;        // growth-rate block present
@@ -324,7 +327,6 @@ static int ensure_workspace(cf_handle* h, int64_t W) {
   if (h->stage_out.ensure((size_t)w_pad * 8)) return CF_ERR_HIP;
   if (h->chi2_extra.ensure((size_t)w_pad * 8)) return CF_ERR_HIP;
   if (h->d.n_aux > 0 && h->bao_nodes.ensure((size_t)w_pad * h->d.n_aux * CF_BAO_NODES * sizeof(d2))) return CF_ERR_HIP;
-  if (h->d.n_fs8 > 0 && h->fs8_scratch.ensure((size_t)w_pad * h->d.n_fs8 * 8)) return CF_ERR_HIP;
   if (h->d.n_sn > 0 && h->solve_mode == CF_SOLVE_INVERSE_GEMM) {
     if (h->partial.ensure((size_t)w_pad * h->ipack.dev.n_rowblocks * 8)) return CF_ERR_HIP;
     if (h->arrivals.ensure((size_t)(w_pad / 16) * 4)) return CF_ERR_HIP;
@@ -398,7 +400,7 @@ static int validate_desc(const cf_desc* c) {
   if (c->n_fs8 > 0) {
     if (!c->fs8_z || !c->fs8_val || !c->fs8_inv_cov || !c->fs8_fid) return fail(CF_ERR_INVALID, "cf_create: growth-rate arrays must not be null");
     if (!(c->fs8_a_init > 0.0 && c->fs8_a_init < 1.0)) return fail(CF_ERR_INVALID, "cf_create: fs8_a_init must be in (0, 1)");
-    if (c->fs8_steps < 0 || c->fs8_steps > 65536) return fail(CF_ERR_INVALID, "cf_create: fs8_steps must be in 0..65536");
+    if (c->fs8_steps < 0 || c->fs8_steps > 2048) return fail(CF_ERR_INVALID, "cf_create: fs8_steps must be in 0..2048");
     if (c->n_grid < CF_BAO_NODES) return fail(CF_ERR_INVALID, "cf_create: a growth-rate block needs n_grid >= 6");
     for (int k = 0; k < c->n_fs8; ++k)
       if (!(1.0 / (1.0 + c->fs8_z[k]) >= c->fs8_a_init) || c->fs8_z[k] < 0.0)
@@ -509,7 +511,8 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
   h->has_small_blocks = c->n_bao > 0 || c->cmb_mode != CF_CMB_NONE || c->n_cc > 0;
   h->has_growth = c->n_fs8 > 0;
   d.n_fs8 = c->n_fs8;
-  d.fs8_steps = c->fs8_steps > 0 ? c->fs8_steps : 512;
+  d.fs8_steps = 256;  // 256 lanes per walker, 1 / 2 / 4 / 8 steps per lane: the request rounded up to 256, 512 (default), 1024, 2048
+  while (d.fs8_steps < (c->fs8_steps > 0 ? c->fs8_steps : 512)) d.fs8_steps *= 2;
   d.fs8_a_init = c->fs8_a_init;
   d.n_aux = c->n_bao + c->n_fs8;
   d.cpl_wall = c->cpl_wall;
@@ -682,6 +685,52 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
       return bail(fail(CF_ERR_HIP, "hipMemcpy(fs8 order) failed"));
     d.fs8_step_of = h->fs8_step_of.as<const int32_t>();
     d.fs8_order = h->fs8_order.as<const int32_t>();
+    // what the ODE's coefficients need that does not depend on theta, at the 2 S + 1 boundaries and midpoints of the steps:
+    // a = exp(x), 1 + z, the massive-neutrino density ratio and nu 3 (1 + w_nu) / (1 + z)   cmb/data_planck_act_compression.py:53-83
+    const int npts = 2 * d.fs8_steps + 1;
+    std::vector<double> tab((size_t)npts * 4);
+    for (int m = 0; m < npts; ++m) {
+      const double a = m == npts - 1 ? 1.0 : std::exp(x0 + m * (0.5 * hstep)), zp1 = 1.0 / a;
+      double nu = 0.0, dnu = 0.0;
+      if (c->ez_model == CF_EZ_PHYSICAL) {
+        const double r = c->nu_m0 / zp1, mz_sq = r * r;
+        double ws = 0.0, num = 0.0, den = 0.0;
+        for (int i = 0; i < 5; ++i) {
+          const double f = std::sqrt(c->nu_qs_sq[i] + mz_sq);
+          ws += f * c->nu_ws[i];
+          num += c->nu_ws[i] / f;
+          den += c->nu_ws[i] * f;
+        }
+        nu = zp1 * zp1 * zp1 * zp1 * ws / c->nu_rho0;
+        const double w_nu = (1.0 / 3) - (1.0 / 3) * mz_sq * num / den;
+        dnu = nu * 3 * (1.0 + w_nu) / zp1;
+      }
+      tab[4 * m] = a; tab[4 * m + 1] = zp1; tab[4 * m + 2] = nu; tab[4 * m + 3] = dnu;
+    }
+    if ((rc = upload_vec(h->fs8_tab, tab.data(), (int64_t)tab.size()))) return bail(rc);
+    d.fs8_tab = h->fs8_tab.as<const double>();
+    // per datum (in step order): the cubic-Hermite weights of ln a_k inside its step, a_k and the neutrino density at z_k
+    auto nu_of = [&](double zp1) {
+      const double r = c->nu_m0 / zp1, mz_sq = r * r;
+      double ws = 0.0;
+      for (int i = 0; i < 5; ++i) ws += std::sqrt(c->nu_qs_sq[i] + mz_sq) * c->nu_ws[i];
+      return zp1 * zp1 * zp1 * zp1 * ws / c->nu_rho0;
+    };
+    std::vector<double> pts((size_t)n * 8, 0.0);
+    for (int s = 0; s < n; ++s) {
+      const int k = order[s], i = step_of[s];
+      const double a = 1.0 / (1.0 + c->fs8_z[k]);
+      const double t = (std::log(a) - (x0 + i * hstep)) / hstep, t2 = t * t, t3 = t2 * t;
+      double* p = &pts[(size_t)s * 8];
+      p[0] = 2 * t3 - 3 * t2 + 1;
+      p[1] = (t3 - 2 * t2 + t) * hstep;
+      p[2] = -2 * t3 + 3 * t2;
+      p[3] = (t3 - t2) * hstep;
+      p[4] = a;
+      p[5] = c->ez_model == CF_EZ_PHYSICAL ? nu_of(1.0 + c->fs8_z[k]) : 0.0;
+    }
+    if ((rc = upload_vec(h->fs8_pts, pts.data(), (int64_t)pts.size()))) return bail(rc);
+    d.fs8_pts = h->fs8_pts.as<const double>();
   }
   if (c->ez_model == CF_EZ_PHYSICAL) {
     // massive-neutrino density at the grid nodes, cmb/data_planck_act_compression.py:53-66 -- independent of theta
@@ -1015,10 +1064,10 @@ static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_
     if (h->has_small_blocks)  // sixteen lanes per walker, sixteen walkers per workgroup
       hipLaunchKernelGGL(pick_small_blocks(d.ez_model, d.fde), dim3((unsigned)((Wc + 15) / 16)), dim3(256), 0, st, d, th, Wc,
                          (const d2*)bao_nodes, extra, blocks_out, bao_out);
-    if (h->has_growth)  // one lane per walker: the growth ODE and the f sigma_8 quadratic form, added to chi2_extra
-      hipLaunchKernelGGL(pick_growth(d.ez_model, d.fde), dim3((unsigned)((Wc + 63) / 64)), dim3(64), 0, st, d, th, Wc,
-                         (const d2*)bao_nodes, h->fs8_scratch.as<double>() + off * d.n_fs8, extra, h->has_small_blocks ? 1 : 0,
-                         fs8_block_out, fs8_theory_out);
+    if (h->has_growth)  // 256 lanes per walker: the growth ODE as a scan of 2 x 2 step matrices, the f sigma_8 quadratic form
+      hipLaunchKernelGGL(pick_growth(d.ez_model, d.fde, d.fs8_steps), dim3((unsigned)Wc), dim3(256),
+                         (size_t)(2 * (d.fs8_steps + 1) + 16 + CF_MAX_FS8 + 2 + 256) * 8, st, d, th, Wc, (const d2*)bao_nodes, extra,
+                         h->has_small_blocks ? 1 : 0, fs8_block_out, fs8_theory_out);
   }
   if (ev_walker_done) HIP_TRY(hipEventRecord(ev_walker_done, st));
   if (ev) HIP_TRY(hipEventRecord(ev[1], st));

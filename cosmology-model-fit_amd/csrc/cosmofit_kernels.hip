@@ -926,84 +926,182 @@ __device__ __forceinline__ void e2_and_slope(const cf_dev_desc& d, const WalkerC
   }
 }
 
-template <int MODEL, int FDE>
-__device__ __forceinline__ void growth_rhs(const cf_dev_desc& d, const WalkerCosmo& wc, double om, double x, double y1, double y2,
-                                           double& f1, double& f2) {
-  const double a = exp(x), z = 1.0 / a - 1.0;
-  double e2, de2;
-  e2_and_slope<MODEL, FDE>(d, wc, z, e2, de2);
-  const double a2 = a * a;
-  const double ea_over_e = -de2 / (2 * a2 * e2);
-  const double source = 1.5 * om * y1 / (a2 * a2 * a * e2);
-  f1 = a * y2;
-  f2 = a * (-(3 / a + ea_over_e) * y2 + source);
+// The ODE is LINEAR in y = (delta, delta'):  dy/dx = A(x) y,  A = [[0, a], [s, -p]],  s = (3/2) Om / (a^4 E^2),
+// p = 3 - (dE^2/dz) / (2 a E^2)  (x = ln a).  One classical RK4 step is therefore a 2 x 2 matrix,
+//   M = I + (h/6) (K1 + 2 K2 + 2 K3 + K4),  K1 = A0,  K2 = Ah (I + h/2 K1),  K3 = Ah (I + h/2 K2),  K4 = A1 (I + h K3),
+// the same arithmetic as the vector form up to the association of the products, and the 2048 dependent right-hand sides of
+// the step-by-step integration become: the coefficients at all 2 S + 1 points in parallel (C steps per lane, 256 lanes per
+// walker), the C step matrices of a lane multiplied together, ONE scan of 2 x 2 products over the 256 lanes, and a C-step
+// re-walk from the lane's own start value that leaves (delta', d delta'/dx) at every step boundary in LDS for the Hermite
+// read-out at the data points.  Everything that does not depend on theta -- a = exp(x), 1 + z, the massive-neutrino density and
+// its slope -- is tabulated at cf_create (fs8_tab).
+struct M22 {
+  double a, b, c, d;  // [[a, b], [c, d]]
+};
+__device__ __forceinline__ M22 mm(const M22& L, const M22& R) {
+  return {L.a * R.a + L.b * R.c, L.a * R.b + L.b * R.d, L.c * R.a + L.d * R.c, L.c * R.b + L.d * R.d};
+}
+__device__ __forceinline__ M22 shfl_up_m(const M22& m, int delta) {
+  return {__shfl_up(m.a, delta), __shfl_up(m.b, delta), __shfl_up(m.c, delta), __shfl_up(m.d, delta)};
 }
 
+// A(x) at table point m (boundary i = m / 2 for even m, the midpoint of step (m - 1) / 2 for odd m)
 template <int MODEL, int FDE>
-__global__ void __launch_bounds__(64)
+__device__ __forceinline__ void growth_coef(const cf_dev_desc& d, const WalkerCosmo& wc, double om, int m, double lnzp1, double& a,
+                                            double& s, double& p) {
+  const d4 t = reinterpret_cast<const d4*>(d.fs8_tab)[m];  // {a, 1 + z, nu(z), nu 3 (1 + w_nu) / (1 + z)}
+  a = t[0];
+  const double zp1 = t[1], z = zp1 - 1.0, sq = zp1 * zp1, cubed = sq * zp1;
+  // dark-energy density ratio f and df/dz = f 3 (1 + w(z)) / (1 + z), with 1 / (1 + z) = a and one reciprocal shared
+  // (fs8/fs8.py:26-41; the forms of f_de / dfde_dz above)
+  double f = 1.0, df = 0.0;
+  if (FDE == CF_FDE_WCDM_D) {
+    f = exp(3 * (1 + wc.w0) * lnzp1);
+    df = f * 3 * (1.0 + wc.w0) * a;
+  } else if (FDE == CF_FDE_THAWING_D) {
+    const double inv = 1.0 / ((1.0 + wc.w0) + (1.0 - wc.w0) * cubed), r = 2 * cubed * inv;
+    f = r * r;
+    df = f * 3 * (2 * (1.0 + wc.w0) * inv) * a;  // 1 + w(z) = 2 (1 + w0) / ((1 + w0) + (1 - w0) (1 + z)^3)
+  } else if (FDE == CF_FDE_CPL_D) {
+    const double za = z * a;
+    f = exp(fma(3 * (1 + wc.w0 + wc.wa), lnzp1, -3 * wc.wa * za));
+    df = f * 3 * (1.0 + wc.w0 + wc.wa * za) * a;
+  }
+  double e2, de2;
+  if (MODEL == CF_EZ_LATE_FLAT_D) {  // fs8/fs8.py:44-56
+    e2 = wc.Om * cubed + (1.0 - wc.Om) * f;
+    de2 = 3 * wc.Om * sq + (1.0 - wc.Om) * df;
+  } else {  // bao/desi_cmb_union3_fs8.py:46-66,127-140
+    e2 = wc.Or * (cubed * zp1) + wc.Obc * cubed + wc.Ode * f + wc.Onu * t[2];
+    de2 = 3 * wc.Obc * sq + 4 * wc.Or * cubed + wc.Onu * t[3] + wc.Ode * df;
+  }
+  const double r = zp1 / e2;  // 1 / (a E^2)
+  s = 1.5 * om * r * cubed;   // (3/2) Om / (a^4 E^2)
+  p = 3.0 - 0.5 * de2 * r;
+}
+
+#define CF_GROWTH_TPB 256
+template <int MODEL, int FDE, int C>
+__global__ void __launch_bounds__(CF_GROWTH_TPB)
 growth_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, const d2* __restrict__ aux_nodes,
-              double* __restrict__ scratch, double* __restrict__ chi2_extra, int accumulate, double* __restrict__ blocks_out,
-              double* __restrict__ theory_out) {
-  const int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (w >= W) return;
+              double* __restrict__ chi2_extra, int accumulate, double* __restrict__ blocks_out, double* __restrict__ theory_out) {
+  extern __shared__ double growth_lds[];
+  constexpr int S = C * CF_GROWTH_TPB;
+  d2* bnd = reinterpret_cast<d2*>(growth_lds);                   // [S + 1] {delta', d delta'/dx} at the step boundaries
+  M22* wave_tot = reinterpret_cast<M22*>(growth_lds + 2 * (S + 1));  // [4] product of each wave's lanes
+  double* resid = growth_lds + 2 * (S + 1) + 16;                  // [CF_MAX_FS8] residuals; [CF_MAX_FS8] = delta(a = 1)
+  double* part = resid + CF_MAX_FS8 + 2;                          // [4][64] partial column sums of the quadratic form
+  const int64_t w = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const double* th = theta + w * d.ndim;
   const WalkerCosmo wc = make_cosmo(d, th);
   const double om = MODEL == CF_EZ_LATE_FLAT_D ? wc.Om : wc.Obc;
-  const int n = d.n_fs8, steps = d.fs8_steps;
-  double* dprime = scratch + w * n;  // delta'(a_k), in the data's own order
-  const double x0 = log(d.fs8_a_init), h = -x0 / steps;
-  double y1 = d.fs8_a_init, y2 = 1.0, k1a, k1b;
-  growth_rhs<MODEL, FDE>(d, wc, om, x0, y1, y2, k1a, k1b);
-  int next = 0;
-  for (int i = 0; i < steps; ++i) {
-    const double x = x0 + i * h;
-    double k2a, k2b, k3a, k3b, k4a, k4b;
-    growth_rhs<MODEL, FDE>(d, wc, om, x + 0.5 * h, y1 + 0.5 * h * k1a, y2 + 0.5 * h * k1b, k2a, k2b);
-    growth_rhs<MODEL, FDE>(d, wc, om, x + 0.5 * h, y1 + 0.5 * h * k2a, y2 + 0.5 * h * k2b, k3a, k3b);
-    growth_rhs<MODEL, FDE>(d, wc, om, x + h, y1 + h * k3a, y2 + h * k3b, k4a, k4b);
-    const double n1 = y1 + (h / 6) * (k1a + 2 * k2a + 2 * k3a + k4a);
-    const double n2 = y2 + (h / 6) * (k1b + 2 * k2b + 2 * k3b + k4b);
-    double e1a, e1b;  // first stage of the next step = slopes at the end of this one
-    growth_rhs<MODEL, FDE>(d, wc, om, i + 1 == steps ? 0.0 : x + h, n1, n2, e1a, e1b);
-    while (next < n && d.fs8_step_of[next] == i) {  // the data points whose ln a lies in this step: cubic Hermite of delta'
-      const int k = d.fs8_order[next];
-      const double t = (log(1.0 / (1.0 + d.fs8_z[k])) - x) / h;
-      const double t2 = t * t, t3 = t2 * t;
-      dprime[k] = (2 * t3 - 3 * t2 + 1) * y2 + (t3 - 2 * t2 + t) * h * k1b + (-2 * t3 + 3 * t2) * n2 + (t3 - t2) * h * e1b;
-      ++next;
-    }
-    y1 = n1; y2 = n2; k1a = e1a; k1b = e1b;
+  const int n = d.n_fs8;
+  const double x0 = log(d.fs8_a_init), h = -x0 / S, hh = 0.5 * h;
+
+  // ---- the C step matrices of this lane and their product ----
+  M22 M[C];
+  double s_at[C], p_at[C];  // A at the start boundary of each step: d delta'/dx = s delta - p delta'
+  double a0, s0, p0, s_end, p_end;
+  growth_coef<MODEL, FDE>(d, wc, om, 2 * C * tid, -(x0 + (2 * C * tid) * hh), a0, s0, p0);
+  M22 Q{1.0, 0.0, 0.0, 1.0};
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    const int m = 2 * (C * tid + j);
+    double am, sm, pm, a1, s1, p1;
+    growth_coef<MODEL, FDE>(d, wc, om, m + 1, -(x0 + (m + 1) * hh), am, sm, pm);
+    growth_coef<MODEL, FDE>(d, wc, om, m + 2, m + 2 == 2 * S ? 0.0 : -(x0 + (m + 2) * hh), a1, s1, p1);
+    const M22 A0{0.0, a0, s0, -p0}, Ah{0.0, am, sm, -pm}, A1{0.0, a1, s1, -p1};
+    const M22 K2 = mm(Ah, M22{1.0, hh * A0.b, hh * A0.c, 1.0 + hh * A0.d});
+    const M22 K3 = mm(Ah, M22{1.0 + hh * K2.a, hh * K2.b, hh * K2.c, 1.0 + hh * K2.d});
+    const M22 K4 = mm(A1, M22{1.0 + h * K3.a, h * K3.b, h * K3.c, 1.0 + h * K3.d});
+    const double h6 = h / 6;
+    M[j] = M22{1.0 + h6 * (2 * K2.a + 2 * K3.a + K4.a), h6 * (A0.b + 2 * K2.b + 2 * K3.b + K4.b),
+               h6 * (A0.c + 2 * K2.c + 2 * K3.c + K4.c), 1.0 + h6 * (A0.d + 2 * K2.d + 2 * K3.d + K4.d)};
+    s_at[j] = s0;
+    p_at[j] = p0;
+    Q = mm(M[j], Q);
+    a0 = a1; s0 = s1; p0 = p1;
   }
-  const double delta0 = y1, s8 = slot_get(d, CF_P_S8_D, th), ferr = slot_get(d, CF_P_FS8ERR_D, th);
-  // residuals with the Alcock-Paczynski factor; they overwrite delta' in the scratch row
-  for (int k = 0; k < n; ++k) {
+  s_end = s0;
+  p_end = p0;
+
+  // ---- inclusive scan of the lane products (later steps on the left), over the wave, then over the four waves ----
+  M22 P = Q;
+#pragma unroll
+  for (int dlt = 1; dlt < 64; dlt <<= 1) {
+    const M22 R = shfl_up_m(P, dlt);
+    if (lane >= dlt) P = mm(P, R);
+  }
+  if (lane == 63) wave_tot[wave] = P;
+  __syncthreads();
+  M22 E = shfl_up_m(P, 1);  // exclusive prefix inside the wave
+  if (lane == 0) E = M22{1.0, 0.0, 0.0, 1.0};
+  for (int v = wave - 1; v >= 0; --v) E = mm(E, wave_tot[v]);  // E (this wave's earlier lanes) x waves wave-1 ... 0
+
+  // ---- re-walk the lane's own steps from its start value: boundary values into LDS ----
+  double y1 = E.a * d.fs8_a_init + E.b, y2 = E.c * d.fs8_a_init + E.d;  // y(0) = (a_init, 1), fs8/fs8.py:79-82
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    bnd[C * tid + j] = d2{y2, s_at[j] * y1 - p_at[j] * y2};
+    const double n1 = M[j].a * y1 + M[j].b * y2, n2 = M[j].c * y1 + M[j].d * y2;
+    y1 = n1;
+    y2 = n2;
+  }
+  if (tid == CF_GROWTH_TPB - 1) {
+    bnd[S] = d2{y2, s_end * y1 - p_end * y2};
+    resid[CF_MAX_FS8] = y1;  // delta(a = 1)
+  }
+  __syncthreads();
+
+  // ---- data points, one lane each (wave 0): delta'(a_k) by cubic Hermite inside its step (weights tabulated at cf_create),
+  //      theory, Alcock-Paczynski factor, residual ----
+  const double delta0 = resid[CF_MAX_FS8], s8 = slot_get(d, CF_P_S8_D, th), ferr = slot_get(d, CF_P_FS8ERR_D, th);
+  if (wave == 0 && lane < n) {
+    const int k = d.fs8_order[lane], i = d.fs8_step_of[lane];
+    const d4* pt = reinterpret_cast<const d4*>(d.fs8_pts) + 2 * lane;
+    const d4 hw = pt[0], aux = pt[1];  // Hermite weights {h00, h h10, h01, h h11}; {a_k, nu(z_k), -, -}
+    const d2 b0 = bnd[i], b1 = bnd[i + 1];
+    const double dprime = hw[0] * b0[0] + hw[1] * b0[1] + hw[2] * b1[0] + hw[3] * b1[1];
     NodeView T;
     T.p = aux_nodes + (w * d.n_aux + d.n_bao + k) * CF_BAO_NODES;
     T.base = d.bao_base[d.n_bao + k];
     T.G = d.n_grid; T.step = d.step; T.inv_step = d.inv_step; T.inv_last = d.inv_last; T.z_max = d.z_max;
-    const double z = d.fs8_z[k], a = 1.0 / (1.0 + z);
-    const double theory = (s8 / delta0) * a * dprime[k];
-    const double q = H_of_z<MODEL, FDE>(d, wc, z) * hermite_tab(T, z) / d.fs8_fid[k];
+    const double z = d.fs8_z[k];
+    const double theory = (s8 / delta0) * aux[0] * dprime;
+    const double Hz = wc.H0 * sqrt(e2_of_z<MODEL, FDE>(d, wc, z, MODEL == CF_EZ_PHYSICAL_D ? aux[1] : -1.0));
+    const double q = Hz * hermite_tab(T, z) / d.fs8_fid[k];
     if (theory_out) theory_out[w * n + k] = theory;
-    dprime[k] = d.fs8_val[k] - theory / q;
+    resid[k] = d.fs8_val[k] - theory / q;
   }
-  double c = 0.0;
-  for (int j = 0; j < n; ++j) {  // delta @ inv_cov @ delta in the reference's order (column by column)
-    double t = 0.0;
-    for (int i = 0; i < n; ++i) t += dprime[i] * d.fs8_inv_cov[i * n + j];
-    c += t * dprime[j];
+  __syncthreads();
+  // ---- delta @ inv_cov @ delta: thread (j = lane, quarter = wave) sums the rows i = wave (mod 4) of column j ----
+  double tj = 0.0;
+  if (lane < n) {
+    const double* col = d.fs8_inv_cov + lane;
+#pragma unroll 4
+    for (int i = wave; i < n; i += 4) tj += resid[i] * col[i * n];
   }
-  c *= ferr * ferr;
-  chi2_extra[w] = accumulate ? chi2_extra[w] + c : c;
-  if (blocks_out) blocks_out[w] = c;
+  part[wave * 64 + lane] = tj;
+  __syncthreads();
+  if (wave != 0) return;
+  double r_own = lane < n ? (((part[lane] + part[64 + lane]) + part[128 + lane]) + part[192 + lane]) * resid[lane] : 0.0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) r_own += __shfl_xor(r_own, off);
+  if (lane == 0) {
+    const double c = r_own * (ferr * ferr);
+    chi2_extra[w] = accumulate ? chi2_extra[w] + c : c;
+    if (blocks_out) blocks_out[w] = c;
+  }
 }
 
+#define CF_INSTANTIATE_GROWTH(M, F, C) \
+  template __global__ void growth_kernel<M, F, C>(cf_dev_desc, const double*, int64_t, const d2*, double*, int, double*, double*);
 #define CF_INSTANTIATE_WALKER(M, F)                                                                              \
   template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*, d2*); \
   template __global__ void small_blocks_kernel<M, F>(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, \
                                                      double*);                                                      \
-  template __global__ void growth_kernel<M, F>(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, int, double*, \
-                                               double*);
+  CF_INSTANTIATE_GROWTH(M, F, 1) CF_INSTANTIATE_GROWTH(M, F, 2) CF_INSTANTIATE_GROWTH(M, F, 4) CF_INSTANTIATE_GROWTH(M, F, 8)
 CF_INSTANTIATE_WALKER(0, 0) CF_INSTANTIATE_WALKER(0, 1) CF_INSTANTIATE_WALKER(0, 2) CF_INSTANTIATE_WALKER(0, 3)
 CF_INSTANTIATE_WALKER(1, 0) CF_INSTANTIATE_WALKER(1, 1) CF_INSTANTIATE_WALKER(1, 2) CF_INSTANTIATE_WALKER(1, 3)
 

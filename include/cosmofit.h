@@ -262,8 +262,9 @@ typedef struct cf_desc {
    * Omega_m = slot OM (CF_EZ_LATE_FLAT) or (omega_b + omega_c)/h^2 (CF_EZ_PHYSICAL);
    * theory_k = (sigma_8 / delta(1)) a_k delta'(a_k) / q_k,  q_k = H(z_k) D_M(z_k) / fs8_fid[k]  (Alcock-Paczynski);
    * chi2_fs8 = f_err^2 (val - theory)^T inv_cov (val - theory)  and  log L += n_fs8 ln f_err.
-   * The reference integrates with scipy's adaptive RK45 at rtol = 1e-6; here a fixed-step RK4 in ln a (fs8_steps steps,
-   * 0 = default 512): the two agree to the reference's own integration error (~1e-6 relative on theory). */
+   * The reference integrates with scipy's adaptive RK45 at rtol = 1e-6; here a fixed-step RK4 in ln a: fs8_steps steps, rounded
+   * up to 256, 512 (0 = default), 1024 or 2048 (256 lanes per walker, 1-8 steps per lane; the ODE is linear, so the steps are
+   * 2 x 2 matrices combined by a parallel scan): the two agree to the reference's own integration error (~1e-6 relative on theory). */
   int32_t n_fs8;
   int32_t fs8_steps;
   const double* fs8_z;      /* [n_fs8] */
