@@ -295,6 +295,18 @@ extern "C" int cf_device_count(void) {
   return n;
 }
 
+// First of the CF_BAO_NODES table nodes copied out for a datum at redshift xi: its interval on the grid by the arithmetic of
+// hermite_tab (cosmofit_kernels.hip), two nodes below.
+static int32_t aux_node_base(const cf_dev_desc& d, double xi) {
+  const int G = d.n_grid;
+  int i = xi * d.inv_step >= (double)G ? G : (xi > 0.0 ? (int)(xi * d.inv_step) : 0);
+  i = i > G - 2 ? G - 2 : (i < 0 ? 0 : i);
+  if (i > 0 && (double)i * d.step >= xi) --i;
+  if (i < G - 2 && (double)(i + 1) * d.step < xi) ++i;
+  int b = i - 2;
+  return b < 0 ? 0 : (b > G - CF_BAO_NODES ? G - CF_BAO_NODES : b);
+}
+
 static int upload_vec(DevBuf& b, const double* src, int64_t n) {
   if (b.ensure((size_t)n * 8)) return CF_ERR_HIP;
   HIP_TRY(hipMemcpy(b.p, src, (size_t)n * 8, hipMemcpyHostToDevice));
@@ -638,17 +650,7 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
     // copy of CF_BAO_NODES nodes starts two nodes below it, so that the kernel's own interval search, the Hermite pair
     // and the two 3-point PCHIP stencils all stay inside the copy
     std::vector<int32_t> base((size_t)d.n_aux);
-    const int G = d.n_grid;
-    for (int k = 0; k < d.n_aux; ++k) {
-      const double xi = k < c->n_bao ? c->bao_z[k] : c->fs8_z[k - c->n_bao];
-      int i = (int)(xi * d.inv_step);
-      i = i > G - 2 ? G - 2 : (i < 0 ? 0 : i);
-      if (i > 0 && (double)i * d.step >= xi) --i;
-      if (i < G - 2 && (double)(i + 1) * d.step < xi) ++i;
-      int b = i - 2;
-      b = b < 0 ? 0 : (b > G - CF_BAO_NODES ? G - CF_BAO_NODES : b);
-      base[k] = b;
-    }
+    for (int k = 0; k < d.n_aux; ++k) base[k] = aux_node_base(d, k < c->n_bao ? c->bao_z[k] : c->fs8_z[k - c->n_bao]);
     if (h->bao_base.ensure(base.size() * 4)) return bail(CF_ERR_HIP);
     if (hipMemcpy(h->bao_base.p, base.data(), base.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
       return bail(fail(CF_ERR_HIP, "hipMemcpy(bao_base) failed"));
@@ -1333,6 +1335,53 @@ extern "C" int cf_eval_table(cf_handle* h, const double* theta, int64_t W, doubl
   for (size_t i = 0; i < host.size(); ++i) {
     cum_dm[i] = host[i].x;
     dh[i] = host[i].y;
+  }
+  return CF_OK;
+}
+
+extern "C" int cf_eval_bao_at(cf_handle* h, const double* theta, const double* z, const int32_t* qty, int64_t n, double* out) {
+  if (!h || !theta || (n > 0 && (!z || !qty || !out))) return fail(CF_ERR_INVALID, "cf_eval_bao_at: null argument");
+  if (n < 0) return fail(CF_ERR_INVALID, "cf_eval_bao_at: n must be >= 0");
+  for (int64_t k = 0; k < n; ++k) {
+    if (!std::isfinite(z[k])) return fail(CF_ERR_INVALID, "cf_eval_bao_at: z must be finite");
+    if (qty[k] < 0 || qty[k] > 3) return fail(CF_ERR_INVALID, "cf_eval_bao_at: qty must be 0 (D_V), 1 (D_M), 2 (D_H) or 3 (F_AP)");
+  }
+  if (n == 0) return CF_OK;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIP_TRY(hipSetDevice(h->device));
+  int rc;
+  if ((rc = ensure_workspace(h, 1))) return rc;
+  if (h->has_last && h->last_stream != h->stream) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_last, 0));
+  HIP_TRY(hipMemcpyAsync(h->theta.p, theta, (size_t)h->d.ndim * 8, hipMemcpyHostToDevice, h->stream));
+  DevBuf dz, dq, dbase, dval, dinv, nodes, dout, extra;
+  const int B = CF_MAX_BAO;
+  if (dz.ensure(B * 8) || dq.ensure(B * 4) || dbase.ensure(B * 4) || dval.ensure(B * 8) || dinv.ensure((size_t)B * B * 8) ||
+      nodes.ensure((size_t)B * CF_BAO_NODES * sizeof(d2)) || dout.ensure(B * 8) || extra.ensure(64))
+    return CF_ERR_HIP;
+  HIP_TRY(hipMemsetAsync(dval.p, 0, B * 8, h->stream));
+  HIP_TRY(hipMemsetAsync(dinv.p, 0, (size_t)B * B * 8, h->stream));
+  for (int64_t k0 = 0; k0 < n; k0 += B) {
+    const int m = (int)(n - k0 < B ? n - k0 : B);
+    // a copy of the descriptor whose only block is a BAO block at the requested points (data value 0, inverse covariance 0:
+    // the quadratic form is not used); the E(z) model, the D_H convention and the sound horizon stay the handle's
+    cf_dev_desc d = h->d;
+    d.n_sn = 0; d.n_ld = 0; d.n_fs8 = 0; d.n_cc = 0; d.cmb_mode = 0;
+    d.n_bao = m; d.n_aux = m;
+    std::vector<int32_t> base((size_t)m);
+    for (int k = 0; k < m; ++k) base[k] = aux_node_base(d, z[k0 + k]);
+    HIP_TRY(hipMemcpyAsync(dz.p, z + k0, (size_t)m * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(dq.p, qty + k0, (size_t)m * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(dbase.p, base.data(), (size_t)m * 4, hipMemcpyHostToDevice, h->stream));
+    d.bao_z = dz.as<const double>(); d.bao_qty = dq.as<const int32_t>(); d.bao_base = dbase.as<const int32_t>();
+    d.bao_val = dval.as<const double>(); d.bao_inv_cov = dinv.as<const double>();
+    const size_t lds = ((size_t)d.n_grid + (d.n_grid >> d.chunk_shift) + 2) * 16;
+    hipLaunchKernelGGL(pick_walker(d.ez_model, d.fde), dim3(1), dim3(512), lds, h->stream, d, h->theta.as<const double>(), (int64_t)1,
+                       (double*)nullptr, (double*)nullptr, (double*)nullptr, nodes.as<d2>(), (d2*)nullptr);
+    hipLaunchKernelGGL(pick_small_blocks(d.ez_model, d.fde), dim3(1), dim3(256), 0, h->stream, d, h->theta.as<const double>(), (int64_t)1,
+                       (const d2*)nodes.as<d2>(), extra.as<double>(), (double*)nullptr, dout.as<double>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out + k0, dout.p, (size_t)m * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));  // `base` and the staging buffers are reused by the next chunk
   }
   return CF_OK;
 }

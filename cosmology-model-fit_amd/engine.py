@@ -297,6 +297,18 @@ class LikelihoodEngine:
         z_grid, cum, dh = self.distance_table(np.asarray(theta, dtype=np.float64).reshape(1, -1))
         return interp_hermite(np.atleast_1d(_f64(z)), z_grid, cum[0], dh[0])
 
+    def bao_theory_at(self, theta, z, qty):
+        """``bao_theory(z, qty, params)`` of the scripts at arbitrary redshifts for one theta (bao/desi.py:38-56): the smooth curves
+        of the post-fit plots (bao/plot_predictions.py:24-45).  qty: 0 D_V / r_d, 1 D_M / r_d, 2 D_H / r_d, 3 F_AP."""
+        th = _f64(theta).reshape(-1)
+        if th.size != self.ndim:
+            raise ValueError(f"theta must have {self.ndim} entries")
+        z = np.atleast_1d(_f64(z))
+        q = np.ascontiguousarray(np.broadcast_to(np.asarray(qty), z.shape), dtype=np.int32)
+        out = np.empty(z.size)
+        L.check(L.lib().cf_eval_bao_at(self._h, _ptr(th), _ptr(z), _ptr(q), z.size, _ptr(out)))
+        return out
+
     def enable_timing(self, slots=1, stride=1):
         """Keep HIP-event timings of the last `slots` timed evaluations (0 = off); only every `stride`-th evaluation is timed."""
         L.check(L.lib().cf_enable_timing(self._h, int(slots)))

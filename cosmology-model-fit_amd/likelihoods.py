@@ -51,8 +51,17 @@ class _Base:
 
     log_probability_vect = log_probs_vectorized  # bao/desi_cmb.py:137
 
-    def bao_theory(self, params):
-        return self.engine.parts(params)["bao_theory"][0]
+    def bao_theory(self, *args):
+        """``bao_theory(params)``: the theory vector at the data points.  With the scripts' own signatures
+        ``bao_theory(z, qty, params)`` (bao/desi.py:38) / ``bao_theory(z, qty, params, DM_interp)`` (bao/desi_cmb_des5y.py:82):
+        the same quantities at ARBITRARY redshifts -- what the post-fit block passes to ``plot_bao_predictions`` as
+        ``lambda z, qty: bao_theory(z, qty, best_fit)`` (bao/desi.py:204-211; DM_interp is implied by params and ignored)."""
+        if len(args) == 1:
+            return self.engine.parts(args[0])["bao_theory"][0]
+        if len(args) in (3, 4):
+            z, qty, params = args[:3]
+            return self.engine.bao_theory_at(params, z, qty)
+        raise TypeError("bao_theory(params) or bao_theory(z, qty, params[, DM_interp])")
 
     def cmb_distances(self, params):
         return self.engine.parts(params)["cmb_vector"][0]

@@ -16,6 +16,7 @@
  *   cf_eval_parts        DM_z / mu_theory / mu_corr accessors used by the post-fit plots
  *                                                        sn/pantheon.py:34-54,152-155
  *   cf_eval_table        the (cum_dm, dh_grid) pair inside DM_z / DM_grid  sn/pantheon.py:35-39, bao/desi_cmb_des5y.py:60-66
+ *   cf_eval_bao_at       bao_theory(z, qty, params) at ARBITRARY redshifts (post-fit plots)  bao/desi.py:38-56, bao/plot_predictions.py:24-45
  *   cf_interp_hermite    interp_hermite                   interpolator.py:117-119
  *   cf_interp_pchip      interp_pchip                     interpolator.py:111-114
  *   cf_solve_triangular  solve_triangular (returns y.y)   solve_triangular.py:5-14
@@ -344,6 +345,12 @@ int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, double* dm_obs, 
  * scripts hands to interp_hermite (sn/pantheon.py:34-40, bao/desi_cmb_des5y.py:60-66), for the post-fit plots that
  * evaluate distances at arbitrary redshifts (sn/pantheon.py:152-155). */
 int cf_eval_table(cf_handle* h, const double* theta, int64_t W, double* cum_dm, double* dh);
+
+/* bao_theory(z, qty, params) of the scripts for ONE theta at n arbitrary (redshift, quantity code) pairs -- what the post-fit
+ * block hands to plot_bao_predictions as a smooth curve (bao/plot_predictions.py:24-45, bao/desi.py:38-56, :204-211): the
+ * handle's own E(z) model, D_H convention (PCHIP or c / H) and sound horizon (slot, fixed or fitted), evaluated by the same
+ * kernels as the BAO block of the likelihood.  qty: 0 D_V / r_d, 1 D_M / r_d, 2 D_H / r_d, 3 F_AP.  Host buffers. */
+int cf_eval_bao_at(cf_handle* h, const double* theta, const double* z, const int32_t* qty, int64_t n, double* out);
 
 /* Per-kernel timing with HIP events recorded on the stream the kernels are launched on.
  * cf_enable_timing(h, slots): keep events for the last `slots` evaluation calls (0 = off, the

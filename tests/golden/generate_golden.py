@@ -1017,6 +1017,35 @@ def case_cmb_cmb():
     print("cmb_cmb.npz logp[-2:] =", logp[-2:], "blobs[-1] =", out["blobs"][-1])
 
 
+def case_bao_plot_curves():
+    """What the post-fit blocks plot: bao_theory at the 200 redshifts of plot_bao_predictions (bao/plot_predictions.py:24-45:
+    z_smooth = linspace(0, max z, 200), one curve per quantity code present in the data), through the scripts' own
+    ``bao_theory(z, qty, params[, DM_interp])`` -- bao/desi.py (PCHIP D_H, fixed r_d), bao/desi_cc.py (exact D_H, free r_d),
+    bao/desi_cmb_des5y.py (physical densities, fitted r_drag, F_AP; four-argument form)."""
+    _enter_reference()
+    _inject_dovekie()
+    import bao.desi as m1
+    import bao.desi_cc as m2
+    import bao.desi_cmb_des5y as m3
+
+    out = {}
+    for tag, m, data, theta, four in (("desi", m1, m1.data, np.array([0.68, 0.31, -0.85]), False),
+                                      ("desi_cc", m2, m2.data, np.array([1.0, 68.0, 147.0, 0.31, -0.9]), False),
+                                      ("desi_cmb_des5y", m3, m3.bao, np.array([0.0, 67.5, 0.0224, 0.119, 0.5]), True)):
+        z_smooth = np.linspace(0, max(data["z"]), 200)
+        codes = sorted({int(c) for c in _qty_codes(data)})
+        curves = []
+        for c in codes:
+            q = np.full_like(z_smooth, c, dtype=np.int32)
+            with np.errstate(all="ignore"):
+                fn = getattr(m, "bao_theory", None) or m.theory_bao  # bao/desi_cc.py:67 names it theory_bao
+                curves.append(fn(z_smooth, q, theta, m.DM_grid(theta)) if four else fn(z_smooth, q, theta))
+        out.update({tag + "_z": z_smooth, tag + "_codes": np.array(codes, dtype=np.int32), tag + "_theta": theta,
+                    tag + "_curves": np.array(curves)})
+    np.savez_compressed(os.path.join(HERE, "bao_plot_curves.npz"), **out)
+    print("bao_plot_curves.npz", {k: v.shape for k, v in out.items() if k.endswith("curves")})
+
+
 CASES = {
     "interpolator": case_interpolator,
     "sn_pantheon": case_sn_pantheon,
@@ -1052,6 +1081,7 @@ CASES = {
     "bao_desi_fs_lya_cc_fs8": case_bao_desi_fs_lya_cc_fs8,
 }
 CASES["cmb_cmb"] = case_cmb_cmb
+CASES["bao_plot_curves"] = case_bao_plot_curves
 CASES.update({name: (lambda name=name: case_generic(name)) for name in GENERIC})
 
 if __name__ == "__main__":
