@@ -39,12 +39,15 @@ __global__ void small_blocks_kernel(cf_dev_desc d, const double* theta, int64_t 
 template <int MODEL, int FDE, int C>
 __global__ void growth_kernel(cf_dev_desc d, const double* theta, int64_t W, const d2* aux_nodes, double* chi2_extra, int accumulate,
                               double* blocks_out, double* theory_out);
+template <int MODEL, int FDE>
+__global__ void hz_kernel(cf_dev_desc d, const double* theta, const double* z, int64_t n, double* out);
 #define CF_DECLARE_GROWTH(M, F, C) \
   extern template __global__ void growth_kernel<M, F, C>(cf_dev_desc, const double*, int64_t, const d2*, double*, int, double*, double*);
 #define CF_DECLARE_WALKER(M, F)                                                                                            \
   extern template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*, d2*); \
   extern template __global__ void small_blocks_kernel<M, F>(cf_dev_desc, const double*, int64_t, const d2*, double*,       \
                                                             double*, double*);                                            \
+  extern template __global__ void hz_kernel<M, F>(cf_dev_desc, const double*, const double*, int64_t, double*);             \
   CF_DECLARE_GROWTH(M, F, 1) CF_DECLARE_GROWTH(M, F, 2) CF_DECLARE_GROWTH(M, F, 4) CF_DECLARE_GROWTH(M, F, 8)
 CF_DECLARE_WALKER(0, 0) CF_DECLARE_WALKER(0, 1) CF_DECLARE_WALKER(0, 2) CF_DECLARE_WALKER(0, 3)
 CF_DECLARE_WALKER(1, 0) CF_DECLARE_WALKER(1, 1) CF_DECLARE_WALKER(1, 2) CF_DECLARE_WALKER(1, 3)
@@ -61,6 +64,12 @@ static small_blocks_fn pick_small_blocks(int model, int fde) {
   static const small_blocks_fn table[2][4] = {
       {small_blocks_kernel<0, 0>, small_blocks_kernel<0, 1>, small_blocks_kernel<0, 2>, small_blocks_kernel<0, 3>},
       {small_blocks_kernel<1, 0>, small_blocks_kernel<1, 1>, small_blocks_kernel<1, 2>, small_blocks_kernel<1, 3>}};
+  return table[model][fde];
+}
+typedef void (*hz_fn)(cf_dev_desc, const double*, const double*, int64_t, double*);
+static hz_fn pick_hz(int model, int fde) {
+  static const hz_fn table[2][4] = {{hz_kernel<0, 0>, hz_kernel<0, 1>, hz_kernel<0, 2>, hz_kernel<0, 3>},
+                                    {hz_kernel<1, 0>, hz_kernel<1, 1>, hz_kernel<1, 2>, hz_kernel<1, 3>}};
   return table[model][fde];
 }
 typedef void (*growth_fn)(cf_dev_desc, const double*, int64_t, const d2*, double*, int, double*, double*);
@@ -1336,6 +1345,27 @@ extern "C" int cf_eval_table(cf_handle* h, const double* theta, int64_t W, doubl
     cum_dm[i] = host[i].x;
     dh[i] = host[i].y;
   }
+  return CF_OK;
+}
+
+extern "C" int cf_eval_hz(cf_handle* h, const double* theta, const double* z, int64_t n, double* out) {
+  if (!h || !theta || (n > 0 && (!z || !out))) return fail(CF_ERR_INVALID, "cf_eval_hz: null argument");
+  if (n < 0) return fail(CF_ERR_INVALID, "cf_eval_hz: n must be >= 0");
+  if (n == 0) return CF_OK;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIP_TRY(hipSetDevice(h->device));
+  int rc;
+  if ((rc = ensure_workspace(h, 1))) return rc;
+  if (h->has_last && h->last_stream != h->stream) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_last, 0));
+  DevBuf dz, dout;
+  if (dz.ensure((size_t)n * 8) || dout.ensure((size_t)n * 8)) return CF_ERR_HIP;
+  HIP_TRY(hipMemcpyAsync(h->theta.p, theta, (size_t)h->d.ndim * 8, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(dz.p, z, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(pick_hz(h->d.ez_model, h->d.fde), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d,
+                     h->theta.as<const double>(), dz.as<const double>(), n, dout.as<double>());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, dout.p, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   return CF_OK;
 }
 

@@ -1095,12 +1095,23 @@ growth_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, const 
   }
 }
 
+// H(z) of one theta at arbitrary redshifts: the H_z(z, params) the post-fit blocks plot (ohd/cc.py:95-96, ohd/plot_predictions.py:7-21)
+template <int MODEL, int FDE>
+__global__ void hz_kernel(cf_dev_desc d, const double* __restrict__ theta, const double* __restrict__ z, int64_t n,
+                          double* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const WalkerCosmo wc = make_cosmo(d, theta);
+  out[i] = H_of_z<MODEL, FDE>(d, wc, z[i]);
+}
+
 #define CF_INSTANTIATE_GROWTH(M, F, C) \
   template __global__ void growth_kernel<M, F, C>(cf_dev_desc, const double*, int64_t, const d2*, double*, int, double*, double*);
 #define CF_INSTANTIATE_WALKER(M, F)                                                                              \
   template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*, d2*); \
   template __global__ void small_blocks_kernel<M, F>(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, \
                                                      double*);                                                      \
+  template __global__ void hz_kernel<M, F>(cf_dev_desc, const double*, const double*, int64_t, double*);                     \
   CF_INSTANTIATE_GROWTH(M, F, 1) CF_INSTANTIATE_GROWTH(M, F, 2) CF_INSTANTIATE_GROWTH(M, F, 4) CF_INSTANTIATE_GROWTH(M, F, 8)
 CF_INSTANTIATE_WALKER(0, 0) CF_INSTANTIATE_WALKER(0, 1) CF_INSTANTIATE_WALKER(0, 2) CF_INSTANTIATE_WALKER(0, 3)
 CF_INSTANTIATE_WALKER(1, 0) CF_INSTANTIATE_WALKER(1, 1) CF_INSTANTIATE_WALKER(1, 2) CF_INSTANTIATE_WALKER(1, 3)

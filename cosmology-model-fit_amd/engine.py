@@ -309,6 +309,16 @@ class LikelihoodEngine:
         L.check(L.lib().cf_eval_bao_at(self._h, _ptr(th), _ptr(z), _ptr(q), z.size, _ptr(out)))
         return out
 
+    def H_z(self, theta, z):
+        """``H_z(z, params)`` of the scripts in km/s/Mpc at arbitrary redshifts for one theta (ohd/cc.py:95-96)."""
+        th = _f64(theta).reshape(-1)
+        if th.size != self.ndim:
+            raise ValueError(f"theta must have {self.ndim} entries")
+        z = np.atleast_1d(_f64(z))
+        out = np.empty(z.size)
+        L.check(L.lib().cf_eval_hz(self._h, _ptr(th), _ptr(z), z.size, _ptr(out)))
+        return out
+
     def enable_timing(self, slots=1, stride=1):
         """Keep HIP-event timings of the last `slots` timed evaluations (0 = off); only every `stride`-th evaluation is timed."""
         L.check(L.lib().cf_enable_timing(self._h, int(slots)))

@@ -63,6 +63,11 @@ class _Base:
             return self.engine.bao_theory_at(params, z, qty)
         raise TypeError("bao_theory(params) or bao_theory(z, qty, params[, DM_interp])")
 
+    def H_z(self, z, params):
+        """``H_z(z, params)`` of the scripts (km/s/Mpc) at arbitrary redshifts: the curve of ``plot_cc_predictions``
+        (``lambda z: H_z(z, best_fit)``, ohd/cc.py:95-96, bao/desi_cc.py:193-194)."""
+        return self.engine.H_z(params, z)
+
     def cmb_distances(self, params):
         return self.engine.parts(params)["cmb_vector"][0]
 

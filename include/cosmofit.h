@@ -17,6 +17,7 @@
  *                                                        sn/pantheon.py:34-54,152-155
  *   cf_eval_table        the (cum_dm, dh_grid) pair inside DM_z / DM_grid  sn/pantheon.py:35-39, bao/desi_cmb_des5y.py:60-66
  *   cf_eval_bao_at       bao_theory(z, qty, params) at ARBITRARY redshifts (post-fit plots)  bao/desi.py:38-56, bao/plot_predictions.py:24-45
+ *   cf_eval_hz           H_z(z, params) at arbitrary redshifts (post-fit plots)             ohd/cc.py:95-96, ohd/plot_predictions.py:7-32
  *   cf_interp_hermite    interp_hermite                   interpolator.py:117-119
  *   cf_interp_pchip      interp_pchip                     interpolator.py:111-114
  *   cf_solve_triangular  solve_triangular (returns y.y)   solve_triangular.py:5-14
@@ -351,6 +352,10 @@ int cf_eval_table(cf_handle* h, const double* theta, int64_t W, double* cum_dm, 
  * handle's own E(z) model, D_H convention (PCHIP or c / H) and sound horizon (slot, fixed or fitted), evaluated by the same
  * kernels as the BAO block of the likelihood.  qty: 0 D_V / r_d, 1 D_M / r_d, 2 D_H / r_d, 3 F_AP.  Host buffers. */
 int cf_eval_bao_at(cf_handle* h, const double* theta, const double* z, const int32_t* qty, int64_t n, double* out);
+
+/* H_z(z, params) of the scripts in km/s/Mpc for ONE theta at n arbitrary redshifts: the curve and the residuals of
+ * plot_cc_predictions (ohd/plot_predictions.py:7-32, ohd/cc.py:95-101, bao/desi_cc.py:193-199).  Host buffers. */
+int cf_eval_hz(cf_handle* h, const double* theta, const double* z, int64_t n, double* out);
 
 /* Per-kernel timing with HIP events recorded on the stream the kernels are launched on.
  * cf_enable_timing(h, slots): keep events for the last `slots` evaluation calls (0 = off, the

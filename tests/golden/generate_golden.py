@@ -1042,6 +1042,9 @@ def case_bao_plot_curves():
                 curves.append(fn(z_smooth, q, theta, m.DM_grid(theta)) if four else fn(z_smooth, q, theta))
         out.update({tag + "_z": z_smooth, tag + "_codes": np.array(codes, dtype=np.int32), tag + "_theta": theta,
                     tag + "_curves": np.array(curves)})
+        # H_z(z, params) as plot_cc_predictions evaluates it (ohd/plot_predictions.py:8,21), plus redshifts far beyond the data
+        z_h = np.concatenate([np.linspace(0, max(data["z"]), 100), [5.0, 50.0, 1089.0]])
+        out.update({tag + "_hz_z": z_h, tag + "_hz": m.H_z(z_h, theta)})
     np.savez_compressed(os.path.join(HERE, "bao_plot_curves.npz"), **out)
     print("bao_plot_curves.npz", {k: v.shape for k, v in out.items() if k.endswith("curves")})
 

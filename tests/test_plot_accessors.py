@@ -5,7 +5,10 @@ SURVEY 8(b) lists ``bao_theory`` among the accessors a drop-in must keep.  Fixtu
 (tests/golden/generate_golden.py::case_bao_plot_curves) for bao/desi.py (PCHIP D_H, fixed r_d), bao/desi_cc.py (exact D_H, free
 r_d) and bao/desi_cmb_des5y.py (physical densities, fitted r_drag, F_AP, four-argument form).
 
-CPU: the numpy oracle evaluated at the plot's redshifts.  GPU (-m gpu): ``cf_eval_bao_at`` through the mirrors, bar 1e-10.
+The same fixture holds ``H_z(z, params)`` at the redshifts of ``plot_cc_predictions`` (ohd/plot_predictions.py:7-32) and far beyond.
+
+CPU: the numpy oracle evaluated at the plot's redshifts.  GPU (-m gpu): ``cf_eval_bao_at`` / ``cf_eval_hz`` through the mirrors,
+bar 1e-10.
 """
 import dataclasses
 
@@ -35,6 +38,12 @@ def test_oracle_reproduces_the_plotted_curves(tag):
         at = dataclasses.replace(lk, bao_z=z, bao_qty=np.full(z.size, code, dtype=np.int32), bao_val=np.zeros(z.size),
                                  bao_inv_cov=np.zeros((z.size, z.size)))
         np.testing.assert_allclose(onp.bao_theory(at, c[tag + "_theta"]), curve, rtol=RTOL, atol=1e-300)
+
+
+@pytest.mark.parametrize("tag", sorted(CASES))
+def test_oracle_reproduces_the_plotted_hubble_curve(tag):
+    c = golden("bao_plot_curves")
+    np.testing.assert_allclose(onp.H_z(_oracle(tag), c[tag + "_hz_z"], c[tag + "_theta"]), c[tag + "_hz"], rtol=1e-13)
 
 
 @pytest.fixture(scope="module")
@@ -68,6 +77,8 @@ def test_gpu_bao_theory_with_the_scripts_signature(gpu, tag):
     # four-argument form (DM_interp is implied by params), a scalar quantity code, and the data points themselves
     np.testing.assert_array_equal(lk.bao_theory(z[:70], 1, theta, None), lk.bao_theory(z[:70], np.ones(70, dtype=np.int32), theta))
     np.testing.assert_allclose(lk.bao_theory(g["bao_z"], g["bao_qty"], theta), lk.bao_theory(theta), rtol=1e-13)
+    # H_z(z, params): the lambda of plot_cc_predictions (ohd/cc.py:95-96), also far beyond the data
+    np.testing.assert_allclose(lk.H_z(c[tag + "_hz_z"], theta), c[tag + "_hz"], rtol=RTOL)
     with pytest.raises(gpu.CosmofitError):
         lk.bao_theory(z[:3], 7, theta)
     with pytest.raises(TypeError):
