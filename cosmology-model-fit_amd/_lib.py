@@ -109,6 +109,7 @@ EXPORTS = {
     "cf_eval_table": (C.c_int, [_VP, _VP, _I64, _VP, _VP]),
     "cf_eval_bao_at": (C.c_int, [_VP, _VP, _VP, _VP, _I64, _VP]),
     "cf_eval_hz": (C.c_int, [_VP, _VP, _VP, _I64, _VP]),
+    "cf_eval_fs8_at": (C.c_int, [_VP, _VP, _VP, _I64, _VP]),
     "cf_last_kernel_ms": (C.c_int, [_VP, C.POINTER(C.c_float * 2)]),
     "cf_enable_timing": (C.c_int, [_VP, C.c_int]),
     "cf_set_timing_stride": (C.c_int, [_VP, C.c_int]),

@@ -450,6 +450,40 @@ struct HostPrep {
   cf_host_pack hp;
 };
 
+// Growth-rate data points for growth_kernel: the RK4 step that contains ln a_k, the data in step order (ascending a), and per
+// datum in that order the cubic-Hermite weights of ln a_k inside its step, a_k and the massive-neutrino density at z_k.
+static void fs8_points(const cf_dev_desc& d, const double* zs, int n, std::vector<int32_t>& step_of, std::vector<int32_t>& order,
+                       std::vector<double>& pts) {
+  const double x0 = std::log(d.fs8_a_init), hstep = -x0 / d.fs8_steps;
+  std::vector<std::pair<int32_t, int32_t>> so;
+  for (int k = 0; k < n; ++k) {
+    int i = (int)((std::log(1.0 / (1.0 + zs[k])) - x0) / hstep);
+    i = i < 0 ? 0 : (i > d.fs8_steps - 1 ? d.fs8_steps - 1 : i);
+    so.emplace_back(i, k);
+  }
+  std::sort(so.begin(), so.end());
+  step_of.resize((size_t)n);
+  order.resize((size_t)n);
+  pts.assign((size_t)n * 8, 0.0);
+  for (int s = 0; s < n; ++s) {
+    const int i = step_of[s] = so[s].first, k = order[s] = so[s].second;
+    const double zp1 = 1.0 + zs[k], a = 1.0 / zp1;
+    const double t = (std::log(a) - (x0 + i * hstep)) / hstep, t2 = t * t, t3 = t2 * t;
+    double* p = &pts[(size_t)s * 8];
+    p[0] = 2 * t3 - 3 * t2 + 1;
+    p[1] = (t3 - 2 * t2 + t) * hstep;
+    p[2] = -2 * t3 + 3 * t2;
+    p[3] = (t3 - t2) * hstep;
+    p[4] = a;
+    if (d.ez_model == CF_EZ_PHYSICAL) {  // cmb/data_planck_act_compression.py:53-66
+      const double r = d.nu_m0 / zp1, mz_sq = r * r;
+      double ws = 0.0;
+      for (int q = 0; q < 5; ++q) ws += std::sqrt(d.nu_qs_sq[q] + mz_sq) * d.nu_ws[q];
+      p[5] = zp1 * zp1 * zp1 * zp1 * ws / d.nu_rho0;
+    }
+  }
+}
+
 static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** out) {
   cf_handle* h = new cf_handle();
   auto bail = [&](int code) { cf_destroy(h); return code; };
@@ -676,20 +710,11 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
     d.fs8_val = h->fs8_val.as<const double>();
     d.fs8_inv_cov = h->fs8_inv_cov.as<const double>();
     d.fs8_fid = h->fs8_fid.as<const double>();
-    // RK4 step that contains ln a_k, and the data in step order (ascending a)
+    // RK4 step that contains ln a_k, the data in step order (ascending a), their Hermite weights
     const double x0 = std::log(c->fs8_a_init), hstep = -x0 / d.fs8_steps;
-    std::vector<int32_t> step_of((size_t)n), order((size_t)n);
-    std::vector<std::pair<int32_t, int32_t>> so;
-    for (int k = 0; k < n; ++k) {
-      int i = (int)((std::log(1.0 / (1.0 + c->fs8_z[k])) - x0) / hstep);
-      i = i < 0 ? 0 : (i > d.fs8_steps - 1 ? d.fs8_steps - 1 : i);
-      so.emplace_back(i, k);
-    }
-    std::sort(so.begin(), so.end());
-    for (int k = 0; k < n; ++k) {
-      step_of[k] = so[k].first;
-      order[k] = so[k].second;
-    }
+    std::vector<int32_t> step_of, order;
+    std::vector<double> pts;
+    fs8_points(d, c->fs8_z, n, step_of, order, pts);
     if (h->fs8_step_of.ensure((size_t)n * 4) || h->fs8_order.ensure((size_t)n * 4)) return bail(CF_ERR_HIP);
     if (hipMemcpy(h->fs8_step_of.p, step_of.data(), (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->fs8_order.p, order.data(), (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess)
@@ -720,26 +745,6 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
     }
     if ((rc = upload_vec(h->fs8_tab, tab.data(), (int64_t)tab.size()))) return bail(rc);
     d.fs8_tab = h->fs8_tab.as<const double>();
-    // per datum (in step order): the cubic-Hermite weights of ln a_k inside its step, a_k and the neutrino density at z_k
-    auto nu_of = [&](double zp1) {
-      const double r = c->nu_m0 / zp1, mz_sq = r * r;
-      double ws = 0.0;
-      for (int i = 0; i < 5; ++i) ws += std::sqrt(c->nu_qs_sq[i] + mz_sq) * c->nu_ws[i];
-      return zp1 * zp1 * zp1 * zp1 * ws / c->nu_rho0;
-    };
-    std::vector<double> pts((size_t)n * 8, 0.0);
-    for (int s = 0; s < n; ++s) {
-      const int k = order[s], i = step_of[s];
-      const double a = 1.0 / (1.0 + c->fs8_z[k]);
-      const double t = (std::log(a) - (x0 + i * hstep)) / hstep, t2 = t * t, t3 = t2 * t;
-      double* p = &pts[(size_t)s * 8];
-      p[0] = 2 * t3 - 3 * t2 + 1;
-      p[1] = (t3 - 2 * t2 + t) * hstep;
-      p[2] = -2 * t3 + 3 * t2;
-      p[3] = (t3 - t2) * hstep;
-      p[4] = a;
-      p[5] = c->ez_model == CF_EZ_PHYSICAL ? nu_of(1.0 + c->fs8_z[k]) : 0.0;
-    }
     if ((rc = upload_vec(h->fs8_pts, pts.data(), (int64_t)pts.size()))) return bail(rc);
     d.fs8_pts = h->fs8_pts.as<const double>();
   }
@@ -1344,6 +1349,62 @@ extern "C" int cf_eval_table(cf_handle* h, const double* theta, int64_t W, doubl
   for (size_t i = 0; i < host.size(); ++i) {
     cum_dm[i] = host[i].x;
     dh[i] = host[i].y;
+  }
+  return CF_OK;
+}
+
+extern "C" int cf_eval_fs8_at(cf_handle* h, const double* theta, const double* z, int64_t n, double* out) {
+  if (!h || !theta || (n > 0 && (!z || !out))) return fail(CF_ERR_INVALID, "cf_eval_fs8_at: null argument");
+  if (n < 0) return fail(CF_ERR_INVALID, "cf_eval_fs8_at: n must be >= 0");
+  if (!h->has_growth) return fail(CF_ERR_INVALID, "cf_eval_fs8_at: the handle has no growth-rate block");
+  for (int64_t k = 0; k < n; ++k)
+    if (!(z[k] >= 0.0) || !(1.0 / (1.0 + z[k]) >= h->d.fs8_a_init))
+      return fail(CF_ERR_INVALID, "cf_eval_fs8_at: redshifts must lie in a_init <= a <= 1");
+  if (n == 0) return CF_OK;
+  std::lock_guard<std::mutex> lk(h->mu);
+  HIP_TRY(hipSetDevice(h->device));
+  int rc;
+  if ((rc = ensure_workspace(h, 1))) return rc;
+  if (h->has_last && h->last_stream != h->stream) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_last, 0));
+  HIP_TRY(hipMemcpyAsync(h->theta.p, theta, (size_t)h->d.ndim * 8, hipMemcpyHostToDevice, h->stream));
+  const int B = CF_MAX_FS8;
+  DevBuf dz, dbase, dstep, dorder, dpts, dval, dinv, dfid, nodes, dout, extra;
+  if (dz.ensure(B * 8) || dbase.ensure(B * 4) || dstep.ensure(B * 4) || dorder.ensure(B * 4) || dpts.ensure(B * 64) ||
+      dval.ensure(B * 8) || dinv.ensure((size_t)B * B * 8) || dfid.ensure(B * 8) ||
+      nodes.ensure((size_t)B * CF_BAO_NODES * sizeof(d2)) || dout.ensure(B * 8) || extra.ensure(64))
+    return CF_ERR_HIP;
+  HIP_TRY(hipMemsetAsync(dval.p, 0, B * 8, h->stream));
+  HIP_TRY(hipMemsetAsync(dinv.p, 0, (size_t)B * B * 8, h->stream));
+  const std::vector<double> ones((size_t)B, 1.0);  // the Alcock-Paczynski factor divides the residual only, not theory_out
+  HIP_TRY(hipMemcpyAsync(dfid.p, ones.data(), B * 8, hipMemcpyHostToDevice, h->stream));
+  for (int64_t k0 = 0; k0 < n; k0 += B) {
+    const int m = (int)(n - k0 < B ? n - k0 : B);
+    // a copy of the descriptor whose only block is a growth-rate block at the requested redshifts (data 0, inverse
+    // covariance 0: only theory_out is used); E(z), sigma_8 and a_init stay the handle's
+    cf_dev_desc d = h->d;
+    d.n_sn = 0; d.n_ld = 0; d.n_bao = 0; d.n_cc = 0; d.cmb_mode = 0;
+    d.n_fs8 = m; d.n_aux = m;
+    std::vector<int32_t> step_of, order, base((size_t)m);
+    std::vector<double> pts;
+    fs8_points(d, z + k0, m, step_of, order, pts);
+    for (int k = 0; k < m; ++k) base[k] = aux_node_base(d, z[k0 + k]);
+    HIP_TRY(hipMemcpyAsync(dz.p, z + k0, (size_t)m * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(dbase.p, base.data(), (size_t)m * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(dstep.p, step_of.data(), (size_t)m * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(dorder.p, order.data(), (size_t)m * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(dpts.p, pts.data(), (size_t)m * 64, hipMemcpyHostToDevice, h->stream));
+    d.fs8_z = dz.as<const double>(); d.bao_base = dbase.as<const int32_t>(); d.fs8_step_of = dstep.as<const int32_t>();
+    d.fs8_order = dorder.as<const int32_t>(); d.fs8_pts = dpts.as<const double>(); d.fs8_val = dval.as<const double>();
+    d.fs8_inv_cov = dinv.as<const double>(); d.fs8_fid = dfid.as<const double>();
+    const size_t lds = ((size_t)d.n_grid + (d.n_grid >> d.chunk_shift) + 2) * 16;
+    hipLaunchKernelGGL(pick_walker(d.ez_model, d.fde), dim3(1), dim3(512), lds, h->stream, d, h->theta.as<const double>(), (int64_t)1,
+                       (double*)nullptr, (double*)nullptr, (double*)nullptr, nodes.as<d2>(), (d2*)nullptr);
+    hipLaunchKernelGGL(pick_growth(d.ez_model, d.fde, d.fs8_steps), dim3(1), dim3(256),
+                       (size_t)(2 * (d.fs8_steps + 1) + 16 + CF_MAX_FS8 + 2 + 256) * 8, h->stream, d, h->theta.as<const double>(),
+                       (int64_t)1, (const d2*)nodes.as<d2>(), extra.as<double>(), 0, (double*)nullptr, dout.as<double>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out + k0, dout.p, (size_t)m * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));  // the host vectors and the staging buffers are reused by the next chunk
   }
   return CF_OK;
 }

@@ -319,6 +319,17 @@ class LikelihoodEngine:
         L.check(L.lib().cf_eval_hz(self._h, _ptr(th), _ptr(z), z.size, _ptr(out)))
         return out
 
+    def fs8_theory_at(self, theta, z):
+        """f sigma_8 (before the Alcock-Paczynski division) at arbitrary redshifts for one theta: ``fs8_theory(1 / (1 + z), params)``
+        of the growth-rate scripts (fs8/fs8.py:84-98,221-226)."""
+        th = _f64(theta).reshape(-1)
+        if th.size != self.ndim:
+            raise ValueError(f"theta must have {self.ndim} entries")
+        z = np.atleast_1d(_f64(z))
+        out = np.empty(z.size)
+        L.check(L.lib().cf_eval_fs8_at(self._h, _ptr(th), _ptr(z), z.size, _ptr(out)))
+        return out
+
     def enable_timing(self, slots=1, stride=1):
         """Keep HIP-event timings of the last `slots` timed evaluations (0 = off); only every `stride`-th evaluation is timed."""
         L.check(L.lib().cf_enable_timing(self._h, int(slots)))

@@ -68,6 +68,16 @@ class _Base:
         (``lambda z: H_z(z, best_fit)``, ohd/cc.py:95-96, bao/desi_cc.py:193-194)."""
         return self.engine.H_z(params, z)
 
+    def fs8_theory(self, *args):
+        """``fs8_theory(params)``: f sigma_8 at the data points.  ``fs8_theory(a, params)`` -- the scripts' own signature
+        (fs8/fs8_cmb.py:132, bao/desi_cmb_union3_fs8.py:172, ohd/cc_fs8.py:90) -- at ARBITRARY scale factors: the smooth curve of
+        the post-fit block (``lambda z: fs8_theory(1 / (1 + z), best_fit)``, fs8/plot_predictions.py:7-32)."""
+        if len(args) == 1:
+            return self.engine.parts(args[0])["fs8_theory"][0]
+        if len(args) == 2:
+            return self.engine.fs8_theory_at(args[1], 1.0 / np.asarray(args[0], dtype=np.float64) - 1.0)
+        raise TypeError("fs8_theory(params) or fs8_theory(a, params)")
+
     def cmb_distances(self, params):
         return self.engine.parts(params)["cmb_vector"][0]
 
@@ -418,8 +428,13 @@ class Fs8(_Base):
             fs8=dict(z=z, val=fs8_vals, inv_cov=np.linalg.inv(cov_mat), fid=self.fid, a_init=self.A_INIT, steps=steps),
             bounds=self.bounds, device=device, devices=devices)
 
-    def fs8_theory(self, params):
-        return self.engine.parts(params)["fs8_theory"][0]
+    def fs8_theory(self, *args):
+        """``fs8_theory(params)`` at the data points, or the script's own ``fs8_theory(a, Om, sigma8_0, w0)`` (fs8/fs8.py:84) at
+        arbitrary scale factors."""
+        if len(args) == 4:
+            a, Om, s8, w0 = args
+            return super().fs8_theory(a, np.array([Om, s8, w0, 1.0]))
+        return super().fs8_theory(*args)
 
 
 class DesiCmbUnion3Fs8(_Base):
@@ -441,9 +456,6 @@ class DesiCmbUnion3Fs8(_Base):
             fs8=dict(z=fs8_z, val=fs8_vals, inv_cov=np.linalg.inv(fs8_cov), fid=fs8_fid, a_init=self.A_INIT, steps=steps),
             physical=_physical(comp), device=device, devices=devices)
 
-    def fs8_theory(self, params):
-        return self.engine.parts(params)["fs8_theory"][0]
-
 
 class CcFs8(_Base):
     """ohd/cc_fs8.py: theta = (H0, Om, sigma8, f_cc, f_fs8, w0).  Cosmic chronometers and growth-rate data, each with its own
@@ -462,9 +474,6 @@ class CcFs8(_Base):
             cc=dict(z=z_cc, h=H_cc, inv_cov=np.linalg.inv(cov_cc), logdet=-len(z_cc) * np.log(2 * np.pi)),
             fs8=dict(z=fs8_z, val=fs8_vals, inv_cov=np.linalg.inv(fs8_cov), fid=fs8_fid, a_init=self.A_INIT, steps=steps),
             device=device, devices=devices)
-
-    def fs8_theory(self, params):
-        return self.engine.parts(params)["fs8_theory"][0]
 
 
 class DesiUnion3ThetaStarSubset(_Base):
@@ -559,9 +568,6 @@ class Fs8Cmb(_Base):
             fs8=dict(z=z, val=fs8_vals, inv_cov=np.linalg.inv(cov_mat), fid=fid, a_init=self.A_INIT, steps=steps),
             physical=_physical(comp), logl_const=-0.5 * norm_factor, bounds=self.bounds, device=device, devices=devices)
 
-    def fs8_theory(self, params):
-        return self.engine.parts(params)["fs8_theory"][0]
-
 
 class DesiFsLyaCcFs8(_Base):
     """bao/desi_fs_lya_cc_fs8.py: theta = (H0, Om, sigma8, f_cc, f_fs8, r_d, w0).  DESI FS+Lya BAO (F_AP, D_H = c / H, free r_d),
@@ -580,9 +586,6 @@ class DesiFsLyaCcFs8(_Base):
             cc=dict(z=z_cc, h=H_cc, inv_cov=np.linalg.inv(cov_cc), logdet=np.linalg.slogdet(cov_cc)[1]),
             fs8=dict(z=fs8_z, val=fs8_vals, inv_cov=np.linalg.inv(fs8_cov), fid=fs8_fid, a_init=self.A_INIT, steps=steps),
             logl_const=-0.5 * norm_fs8, device=device, devices=devices)
-
-    def fs8_theory(self, params):
-        return self.engine.parts(params)["fs8_theory"][0]
 
 
 class CmbOnly(_Base):

@@ -18,6 +18,7 @@
  *   cf_eval_table        the (cum_dm, dh_grid) pair inside DM_z / DM_grid  sn/pantheon.py:35-39, bao/desi_cmb_des5y.py:60-66
  *   cf_eval_bao_at       bao_theory(z, qty, params) at ARBITRARY redshifts (post-fit plots)  bao/desi.py:38-56, bao/plot_predictions.py:24-45
  *   cf_eval_hz           H_z(z, params) at arbitrary redshifts (post-fit plots)             ohd/cc.py:95-96, ohd/plot_predictions.py:7-32
+ *   cf_eval_fs8_at       fs8_theory(a, params) at arbitrary scale factors (post-fit plots) fs8/fs8.py:84-98,221-226
  *   cf_interp_hermite    interp_hermite                   interpolator.py:117-119
  *   cf_interp_pchip      interp_pchip                     interpolator.py:111-114
  *   cf_solve_triangular  solve_triangular (returns y.y)   solve_triangular.py:5-14
@@ -356,6 +357,11 @@ int cf_eval_bao_at(cf_handle* h, const double* theta, const double* z, const int
 /* H_z(z, params) of the scripts in km/s/Mpc for ONE theta at n arbitrary redshifts: the curve and the residuals of
  * plot_cc_predictions (ohd/plot_predictions.py:7-32, ohd/cc.py:95-101, bao/desi_cc.py:193-199).  Host buffers. */
 int cf_eval_hz(cf_handle* h, const double* theta, const double* z, int64_t n, double* out);
+
+/* fs8_theory(a, params) of the growth-rate scripts -- f sigma_8 before the Alcock-Paczynski division -- for ONE theta at n
+ * arbitrary redshifts z = 1 / a - 1 with a_init <= a <= 1: the smooth curve of fs8/plot_predictions.py:7-32
+ * (fs8/fs8.py:221-226).  The handle must have a growth-rate block (its a_init, E(z) model and sigma_8 slot are used). */
+int cf_eval_fs8_at(cf_handle* h, const double* theta, const double* z, int64_t n, double* out);
 
 /* Per-kernel timing with HIP events recorded on the stream the kernels are launched on.
  * cf_enable_timing(h, slots): keep events for the last `slots` evaluation calls (0 = off, the

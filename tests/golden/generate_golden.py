@@ -1049,6 +1049,28 @@ def case_bao_plot_curves():
     print("bao_plot_curves.npz", {k: v.shape for k, v in out.items() if k.endswith("curves")})
 
 
+def case_fs8_plot_curves():
+    """The smooth f sigma_8 curve of the post-fit blocks (fs8/plot_predictions.py:7-11: z_plot = linspace(0, max z + 0.5, 200),
+    ``fs8_theory(1 / (1 + z_plot), ...)``) through the scripts' own functions: fs8/fs8.py (scalar signature, :84, :221-223) and
+    ohd/cc_fs8.py (``fs8_theory(a, params)``, :90); with the converged solution of the script's own ODE beside it."""
+    _enter_reference()
+    import fs8.fs8 as m1
+    import ohd.cc_fs8 as m2
+
+    out = {}
+    z1 = np.linspace(0, np.max(m1.data["z"]) + 0.5, 200)
+    t1 = np.array([0.3, 0.8, -0.9, 1.0])
+    out.update(fs8_z=z1, fs8_theta=t1, fs8_curve=m1.fs8_theory(1 / (1 + z1), t1[0], t1[1], t1[2]),
+               fs8_curve_tight=_tight_fs8_theory(m1, 1 / (1 + z1[::-1]), m1.a_span, t1[1], (t1[0], t1[2]))[::-1])
+    z2 = np.linspace(0, np.max(m2.z_fs8) + 0.5, 200)
+    t2 = np.array([68.0, 0.3, 0.8, 1.0, 1.0, -0.9])
+    out.update(cc_fs8_z=z2, cc_fs8_theta=t2, cc_fs8_curve=m2.fs8_theory(1 / (1 + z2), t2),
+               cc_fs8_curve_tight=_tight_fs8_theory(m2, 1 / (1 + z2[::-1]), m2.a_span, t2[2], (t2,))[::-1])
+    np.savez_compressed(os.path.join(HERE, "fs8_plot_curves.npz"), **out)
+    for tag in ("fs8", "cc_fs8"):
+        print(tag, "curve: reference vs converged %.2e" % np.max(np.abs(out[tag + "_curve"] / out[tag + "_curve_tight"] - 1)))
+
+
 CASES = {
     "interpolator": case_interpolator,
     "sn_pantheon": case_sn_pantheon,
@@ -1085,6 +1107,7 @@ CASES = {
 }
 CASES["cmb_cmb"] = case_cmb_cmb
 CASES["bao_plot_curves"] = case_bao_plot_curves
+CASES["fs8_plot_curves"] = case_fs8_plot_curves
 CASES.update({name: (lambda name=name: case_generic(name)) for name in GENERIC})
 
 if __name__ == "__main__":

@@ -194,3 +194,39 @@ def test_gpu_desi_fs_lya_cc_fs8(gpu):
     np.testing.assert_allclose(parts["chi2_blocks"][:, 1], g["chi2_parts"][:, 2], rtol=1e-10)
     np.testing.assert_allclose(parts["chi2_fs8"], g["chi2_parts"][:, 1], rtol=CHI2_VS_REFERENCE)
     lk.engine.close()
+
+
+# ---- the smooth curve of the post-fit blocks: fs8_theory at arbitrary scale factors, with the scripts' own signatures ----------------
+def test_oracle_reproduces_the_plotted_growth_curves():
+    c = golden("fs8_plot_curves")
+    import dataclasses
+    for tag, make in (("fs8", lambda: lk_fs8(golden("fs8_fs8"))), ("cc_fs8", lambda: lk_cc_fs8(golden("ohd_cc_fs8")))):
+        z = c[tag + "_z"][::8]
+        at = dataclasses.replace(make(), fs8_z=z, fs8_val=np.zeros(z.size), fs8_inv_cov=np.zeros((z.size, z.size)), fs8_fid=np.ones(z.size))
+        np.testing.assert_allclose(onp.fs8_theory(at, c[tag + "_theta"]), c[tag + "_curve"][::8], rtol=THEORY_VS_REFERENCE)
+
+
+@pytest.mark.gpu
+def test_gpu_fs8_theory_with_the_scripts_signatures(gpu):
+    c = golden("fs8_plot_curves")
+    g = golden("fs8_fs8")
+    lk = gpu.likelihoods.Fs8(g["fs8_z"], g["fs8_val"], g["fs8_cov"], None, fid=g["fs8_fid"], bounds=g["bounds"])
+    z, t = c["fs8_z"], c["fs8_theta"]
+    curve = (lambda zz: lk.fs8_theory(1 / (1 + zz), t[0], t[1], t[2]))(z)  # the lambda of fs8/fs8.py:221-223, 200 points
+    np.testing.assert_allclose(curve, c["fs8_curve_tight"], rtol=THEORY_VS_TIGHT)
+    np.testing.assert_allclose(curve, c["fs8_curve"], rtol=THEORY_VS_REFERENCE)
+    np.testing.assert_allclose(lk.fs8_theory(1 / (1 + g["fs8_z"]), t), lk.fs8_theory(t), rtol=1e-12)  # the data points themselves
+    with pytest.raises(gpu.CosmofitError):
+        lk.fs8_theory(np.array([1e-4]), t)  # a < a_init
+    lk.engine.close()
+    g = golden("ohd_cc_fs8")
+    lk = gpu.likelihoods.CcFs8(g["cc_z"], g["cc_h"], g["cc_cov"], g["fs8_z"], g["fs8_val"], g["fs8_cov"], g["fs8_fid"])
+    curve = lk.fs8_theory(1 / (1 + c["cc_fs8_z"]), c["cc_fs8_theta"])  # ohd/cc_fs8.py:90: fs8_theory(a, params)
+    np.testing.assert_allclose(curve, c["cc_fs8_curve_tight"], rtol=THEORY_VS_TIGHT)
+    np.testing.assert_allclose(curve, c["cc_fs8_curve"], rtol=THEORY_VS_REFERENCE)
+    lk.engine.close()
+    sn = golden("bao_desi")
+    no_growth = gpu.likelihoods.DesiBao(sn["bao_z"], sn["bao_val"], sn["bao_qty"], sn["bao_inv_cov"], rd=float(sn["rd"]))
+    with pytest.raises(gpu.CosmofitError):
+        no_growth.fs8_theory(np.array([0.5]), np.array([0.68, 0.3, -0.9]))
+    no_growth.engine.close()
