@@ -240,6 +240,9 @@ struct PinnedBuf {
   }
 };
 
+#ifndef CF_ZEROCOPY_DEFAULT
+#define CF_ZEROCOPY_DEFAULT 16384
+#endif
 #define CF_MAX_CHUNKS 8  // sub-batches of one evaluation (walker kernel of chunk c + 1 beside the solve of chunk c)
 
 // A host thread that evaluates one replica's slice of a multi-device cf_eval (one per replica beyond the first).
@@ -1206,11 +1209,21 @@ static int eval_host_single(cf_handle* h, const double* theta, int64_t W, double
   HIP_TRY(hipSetDevice(h->device));
   if ((rc = ensure_workspace(h, W))) return rc;
   memcpy(h->stage_in.p, theta, (size_t)W * h->d.ndim * 8);
-  HIP_TRY(hipMemcpyAsync(h->theta.p, h->stage_in.p, (size_t)W * h->d.ndim * 8, hipMemcpyHostToDevice, h->stream));
-  if ((rc = launch_path(h, h->theta.as<const double>(), W, h->out.as<double>(), out_kind, h->stream, nullptr, nullptr,
-                        nullptr, nullptr)))
-    return rc;
-  HIP_TRY(hipMemcpyAsync(h->stage_out.p, h->out.p, (size_t)W * 8, hipMemcpyDeviceToHost, h->stream));
+  // Small batches are latency-bound: the kernels then read theta from, and write the results to, the pinned (device-visible,
+  // coherent) staging block in place -- a few cache lines over the host link instead of two copy commands on the critical
+  // path.  CF_ZEROCOPY_MAX = largest such batch (walkers; 0 = always copy).
+  static const int64_t zc_max = [] { const char* e = getenv("CF_ZEROCOPY_MAX"); return e ? atoll(e) : (long long)CF_ZEROCOPY_DEFAULT; }();
+  if (W <= zc_max) {
+    if ((rc = launch_path(h, (const double*)h->stage_in.p, W, (double*)h->stage_out.p, out_kind, h->stream, nullptr, nullptr,
+                          nullptr, nullptr)))
+      return rc;
+  } else {
+    HIP_TRY(hipMemcpyAsync(h->theta.p, h->stage_in.p, (size_t)W * h->d.ndim * 8, hipMemcpyHostToDevice, h->stream));
+    if ((rc = launch_path(h, h->theta.as<const double>(), W, h->out.as<double>(), out_kind, h->stream, nullptr, nullptr,
+                          nullptr, nullptr)))
+      return rc;
+    HIP_TRY(hipMemcpyAsync(h->stage_out.p, h->out.p, (size_t)W * 8, hipMemcpyDeviceToHost, h->stream));
+  }
   if ((rc = wait_stream(h->stream))) return rc;
   memcpy(out, h->stage_out.p, (size_t)W * 8);
   return CF_OK;
