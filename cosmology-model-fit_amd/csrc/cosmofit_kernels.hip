@@ -1564,11 +1564,30 @@ tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict_
   if (arrived_before != (unsigned)pk.n_rowblocks - 1u) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   if (tid == 0) __hip_atomic_store(&arrivals[px], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (tid < 16 * NP && w0 + tid < W) {
+  // The shares come back through LDS: 256 threads fetch the (row block, walker) entries side by side, then thread w adds its
+  // walker's shares in row-block order -- the same additions as a loop of dependent loads, without its n_rowblocks round
+  // trips to memory (27 x ~0.7 us: two thirds of a one-panel solve; profiles/r02_epilogue_loads_ab.txt).
+  constexpr int PW = 16 * NP;
+  double* sh = reinterpret_cast<double*>(part);  // 4096 doubles; the K-quarter exchange is over
+  const int n_sh = pk.n_rowblocks * PW;
+#ifdef CF_EPILOGUE_SERIAL  // A/B build: the loop of dependent loads
+  const bool via_lds = false;
+#else
+  const bool via_lds = n_sh <= 4096;
+#endif
+  if (via_lds) {
+    for (int idx = tid; idx < n_sh; idx += 256)
+      sh[idx] = __hip_atomic_load(&partial[(int64_t)(idx / PW) * w_pad + w0 + idx % PW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    lds_barrier();
+  }
+  if (tid < PW && w0 + tid < W) {
     const int64_t w = w0 + tid;
     double c2 = 0.0;
-    for (int r = 0; r < pk.n_rowblocks; ++r)
-      c2 += __hip_atomic_load(&partial[(int64_t)r * w_pad + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (via_lds)
+      for (int r = 0; r < pk.n_rowblocks; ++r) c2 += sh[r * PW + tid];
+    else
+      for (int r = 0; r < pk.n_rowblocks; ++r)
+        c2 += __hip_atomic_load(&partial[(int64_t)r * w_pad + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (chi2_sn_out) chi2_sn_out[w] = c2;  // the SN block alone (cf_eval_parts)
     if (chi2_extra) c2 += chi2_extra[w];
     out[w] = finalize_value(d, theta + w * d.ndim, c2, out_kind, nonfinite);
