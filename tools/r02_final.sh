@@ -11,6 +11,8 @@ d=json.load(open('$1')); print('$1', '%.4e'%d['value'], '%.4f'%d['ms_per_step'],
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }; show $O/bench.json
 python3 bench.py --no-cpu-baseline > $O/bench_default.json 2>/dev/null && show $O/bench_default.json
 python3 bench.py --walkers-per-gpu 8192 --no-cpu-baseline > $O/bench_w8192.json 2>/dev/null && show $O/bench_w8192.json
+python3 bench.py --scaling strong --no-cpu-baseline --steps 10 > $O/bench_strong_w65536.json 2>/dev/null && show $O/bench_strong_w65536.json
+python3 bench.py --solve blocked --no-cpu-baseline > $O/bench_blocked_solve.json 2>/dev/null && show $O/bench_blocked_solve.json
 python3 bench.py --workload desi_cmb_des5y --no-cpu-baseline > $O/bench_config3_lcdm.json 2>/dev/null && show $O/bench_config3_lcdm.json
 python3 bench.py --workload desi_cmb_des5y --fde cpl --no-cpu-baseline > $O/bench_config3_cpl.json 2>/dev/null && show $O/bench_config3_cpl.json
 python3 bench.py --workload desi_des5y_bbn_theta_star --no-cpu-baseline > $O/bench_config5.json 2>/dev/null && show $O/bench_config5.json
