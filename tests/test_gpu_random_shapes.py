@@ -1,6 +1,8 @@
 """GPU (-m gpu): seeded random likelihood shapes against the numpy oracle -- block combinations, sizes at and around the tile /
 panel / grid boundaries (N = 1 .. 700, G = 6 .. 4500 incl. the LDS chunk path above 4096 nodes, W ragged), both solve kernels.
 Edge cases the reference's own scripts never reach but the C-ABI accepts."""
+import os
+
 import numpy as np
 import pytest
 
@@ -28,7 +30,8 @@ def _sn(rng, n, z_hi):
     return z, zh, obs, np.linalg.cholesky(cov)
 
 
-@pytest.mark.parametrize("seed", range(24))
+# CF_TEST_RANDOM_SHAPES=<n>: soak with more seeds (the default 24 keep the suite short)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CF_TEST_RANDOM_SHAPES", "24"))))
 def test_random_shape(gpu, seed):
     rng = np.random.default_rng(1000 + seed)
     P, S = gpu.Param, onp.Slot
