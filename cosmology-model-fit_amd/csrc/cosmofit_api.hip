@@ -106,6 +106,7 @@ CF_DECLARE_TRIGEMM(1, 4)
 CF_DECLARE_TRIGEMM(2, 2)
 CF_DECLARE_TRIGEMM(2, 3)
 CF_DECLARE_TRIGEMM(2, 4)
+CF_DECLARE_TRIGEMM(4, 2)
 extern "C" __global__ void finalize_kernel(cf_dev_desc d, const double* theta, int64_t W, const double* chi2_extra,
                                            double* out, int out_kind, unsigned long long* nonfinite);
 extern "C" __global__ void interp_kernel(const double* xq, int64_t nq, const double* x, const double* y,
@@ -1054,6 +1055,7 @@ static int launch_tri_gemm(const TriGemmArgs& a, hipStream_t st) {
     case 2 * 16 + 2: return launch_tri_gemm_t<2, 2>(a, st);
     case 2 * 16 + 3: return launch_tri_gemm_t<2, 3>(a, st);
     case 2 * 16 + 4: return launch_tri_gemm_t<2, 4>(a, st);
+    case 4 * 16 + 2: return launch_tri_gemm_t<4, 2>(a, st);
   }
   return fail(CF_ERR_INVALID, "bad CF_GEMM_SHAPE");
 }

@@ -1603,6 +1603,7 @@ CF_INSTANTIATE_TRIGEMM(1, 4)
 CF_INSTANTIATE_TRIGEMM(2, 2)
 CF_INSTANTIATE_TRIGEMM(2, 3)
 CF_INSTANTIATE_TRIGEMM(2, 4)
+CF_INSTANTIATE_TRIGEMM(4, 2)
 
 // ------------------------------------------------------------------------------------------------
 // Likelihoods without an SN block: only the epilogue.
