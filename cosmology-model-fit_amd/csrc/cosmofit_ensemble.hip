@@ -54,6 +54,111 @@ __device__ __forceinline__ const double* comp_row(const double* all_pos, int ndi
   return all_pos + (2 * c + ((1 - half) ^ ens_flip(split_key, c))) * ndim;
 }
 
+// KDE preparation for a compile-time dimension D <= 8 (one 256-thread workgroup): ONE pass over the complementary set for the first
+// and second moments of x - x_ref (x_ref = its first row, inside the cloud, so the subtraction in the covariance cancels nothing it
+// needs), every row loaded once with unconditional loads; covariance, Cholesky factor and inverse by thread 0 in registers; the
+// whitened set in a second pass.  The run-time-dimension form in the kernel below reads the rows D + D (D + 1) / 2 times with a block
+// reduction each, branches around every element load and does its linear algebra through LDS: 57 us at nc = 2048, D = 4
+// (profiles/r02_kde_kernels_ab.txt).
+template <int D>
+__device__ __forceinline__ void kde_prepare_small(const double* __restrict__ all_pos, int64_t nc, int half, uint64_t split_key, double h,
+                                                  double* __restrict__ params, double* __restrict__ wc) {
+  constexpr int NM = D + D * (D + 1) / 2;
+  __shared__ double wsum[4][NM], tot[NM], inv_s[D * D];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double x0[D], mom[NM];
+  {
+    const double* r0 = comp_row(all_pos, D, half, split_key, 0);
+#pragma unroll
+    for (int k = 0; k < D; ++k) x0[k] = r0[k];
+  }
+#pragma unroll
+  for (int k = 0; k < NM; ++k) mom[k] = 0.0;
+  for (int64_t c = tid; c < nc; c += 256) {
+    const double* r = comp_row(all_pos, D, half, split_key, c);
+    double dd[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) dd[k] = r[k] - x0[k];
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      mom[a] += dd[a];
+#pragma unroll
+      for (int b = 0; b <= a; ++b) mom[D + a * (a + 1) / 2 + b] += dd[a] * dd[b];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NM; ++k) {
+    double v = mom[k];
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) wsum[wave][k] = v;
+  }
+  __syncthreads();
+  if (tid < NM) tot[tid] = ((wsum[0][tid] + wsum[1][tid]) + wsum[2][tid]) + wsum[3][tid];
+  __syncthreads();
+  if (tid == 0) {
+    double Lm[D][D], It[D][D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {  // Cholesky (lower) of the covariance h^2 (S2 - S1 S1^T / n) / (n - 1)
+      auto cov = [&](int a, int b) {
+        const int hi = a > b ? a : b, lo = a > b ? b : a;
+        return (tot[D + hi * (hi + 1) / 2 + lo] - tot[hi] * tot[lo] / (double)nc) / (double)(nc - 1) * (h * h);
+      };
+      double sj = cov(j, j);
+#pragma unroll
+      for (int k = 0; k < j; ++k) sj -= Lm[j][k] * Lm[j][k];
+      Lm[j][j] = sqrt(sj);
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        if (i < j) Lm[i][j] = 0.0;
+        if (i > j) {
+          double t = cov(i, j);
+#pragma unroll
+          for (int k = 0; k < j; ++k) t -= Lm[i][k] * Lm[j][k];
+          Lm[i][j] = t / Lm[j][j];
+        }
+      }
+    }
+    double log_det = 0.0;
+#pragma unroll
+    for (int col = 0; col < D; ++col) {  // inv(chol) by forward substitution, stored transposed: It[k][m] = inv[m][k]
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        double t = i == col ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = col; k < i; ++k) t -= Lm[i][k] * It[col][k];
+        It[col][i] = i < col ? 0.0 : t / Lm[i][i];
+      }
+      log_det += log(Lm[col][col]);
+    }
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = 0; b < D; ++b) {
+        params[a * D + b] = Lm[a][b];
+        params[D * D + a * D + b] = It[a][b];
+        inv_s[a * D + b] = It[a][b];
+      }
+    params[2 * D * D] = -log((double)nc) - 0.5 * D * log(2.0 * 3.14159265358979323846) - log_det;
+  }
+  __syncthreads();
+  double inv[D * D];
+#pragma unroll
+  for (int k = 0; k < D * D; ++k) inv[k] = inv_s[k];
+  for (int64_t c = tid; c < nc; c += 256) {  // whitened complementary set: wc = comp @ inv_t
+    const double* r = comp_row(all_pos, D, half, split_key, c);
+    double x[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) x[k] = r[k];
+#pragma unroll
+    for (int m = 0; m < D; ++m) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) t += x[k] * inv[k * D + m];
+      wc[c * D + m] = t;
+    }
+  }
+}
+
 // ---- KDE (scipy.stats.gaussian_kde, bw_method="silverman", as emcee's KDEMove uses it) -----------------
 // params = { chol[d*d] (lower), chol_inv_t[d*d], log_norm }, wc = comp @ chol_inv_t  [nc * d]
 extern "C" __global__ void __launch_bounds__(256)
@@ -74,24 +179,38 @@ ens_kde_prepare_kernel(const double* __restrict__ all_pos, int64_t nc, int ndim,
     __syncthreads();
     return r;
   };
-  for (int k = 0; k < d; ++k) {
-    double s = 0.0;
-    for (int64_t c = tid; c < nc; c += 256) s += comp_row(all_pos, d, half, split_key, c)[k];
-    const double tot = block_sum(s);
-    if (tid == 0) mean[k] = tot / (double)nc;
-  }
-  __syncthreads();
   const double h = pow((double)nc * (d + 2) / 4.0, -1.0 / (d + 4));  // silverman_factor
-  for (int a = 0; a < d; ++a)
-    for (int b = 0; b <= a; ++b) {
-      double s = 0.0;
-      for (int64_t c = tid; c < nc; c += 256) {
-        const double* r = comp_row(all_pos, d, half, split_key, c);
-        s += (r[a] - mean[a]) * (r[b] - mean[b]);
-      }
-      const double tot = block_sum(s);
-      if (tid == 0) cov[a * d + b] = cov[b * d + a] = tot / (double)(nc - 1) * (h * h);
+  if (d <= 8) {  // compile-time dimension: everything in registers, every load unconditional (see kde_prepare_small)
+    switch (d) {
+      case 1: kde_prepare_small<1>(all_pos, nc, half, split_key, h, params, wc); break;
+      case 2: kde_prepare_small<2>(all_pos, nc, half, split_key, h, params, wc); break;
+      case 3: kde_prepare_small<3>(all_pos, nc, half, split_key, h, params, wc); break;
+      case 4: kde_prepare_small<4>(all_pos, nc, half, split_key, h, params, wc); break;
+      case 5: kde_prepare_small<5>(all_pos, nc, half, split_key, h, params, wc); break;
+      case 6: kde_prepare_small<6>(all_pos, nc, half, split_key, h, params, wc); break;
+      case 7: kde_prepare_small<7>(all_pos, nc, half, split_key, h, params, wc); break;
+      default: kde_prepare_small<8>(all_pos, nc, half, split_key, h, params, wc); break;
     }
+    return;
+  } else {
+    for (int k = 0; k < d; ++k) {
+      double s = 0.0;
+      for (int64_t c = tid; c < nc; c += 256) s += comp_row(all_pos, d, half, split_key, c)[k];
+      const double tot = block_sum(s);
+      if (tid == 0) mean[k] = tot / (double)nc;
+    }
+    __syncthreads();
+    for (int a = 0; a < d; ++a)
+      for (int b = 0; b <= a; ++b) {
+        double s = 0.0;
+        for (int64_t c = tid; c < nc; c += 256) {
+          const double* r = comp_row(all_pos, d, half, split_key, c);
+          s += (r[a] - mean[a]) * (r[b] - mean[b]);
+        }
+        const double tot = block_sum(s);
+        if (tid == 0) cov[a * d + b] = cov[b * d + a] = tot / (double)(nc - 1) * (h * h);
+      }
+  }
   __syncthreads();
   if (tid == 0) {
     for (int i = 0; i < d * d; ++i) chol[i] = 0.0;
@@ -132,16 +251,18 @@ ens_kde_prepare_kernel(const double* __restrict__ all_pos, int64_t nc, int ndim,
   }
 }
 
-// log Hastings factor of the KDE move, log kde(x) - log kde(q): one WAVE per active walker, lane l takes the
-// complementary walkers l, l + 64, ...; log-sum-exp in two passes over registers (maximum, then the sum).
-#define CF_ENS_KDE_CHUNK 32  // complementary walkers per lane held in registers at a time
+// log Hastings factor of the KDE move, log kde(x) - log kde(q): one 256-thread WORKGROUP per active walker, thread t takes
+// the complementary walkers t, t + 256, ...; log-sum-exp in two passes over registers (maximum, then the sum), both reduced
+// over the workgroup (wave shuffles + four LDS slots).  One WAVE per walker left the chip with 2 waves per SIMD on chains of
+// dependent exp evaluations: 44 us per half-step of 2048 walkers against 28 us (profiles/r02_kde_kernels_ab.txt).
+#define CF_ENS_KDE_CHUNK 8  // complementary walkers per thread held in registers at a time
 extern "C" __global__ void __launch_bounds__(256)
 ens_kde_logfactor_kernel(const double* __restrict__ all_pos, int64_t nc, int ndim, const int64_t* __restrict__ ids,
                          int64_t n_active, const double* __restrict__ kde_params, const double* __restrict__ wc,
                          const double* __restrict__ y, double* __restrict__ log_factor) {
-  const int lane = threadIdx.x & 63;
-  const int64_t i = blockIdx.x * (int64_t)(blockDim.x / 64) + (threadIdx.x >> 6);
-  if (i >= n_active) return;  // wave-uniform
+  __shared__ double xch[4][4];  // per wave {max a, max q, sum a, sum q}
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t i = blockIdx.x;
   const int d = ndim;
   const double* inv_t = kde_params + d * d;
   const double log_norm = kde_params[2 * d * d];
@@ -165,14 +286,14 @@ ens_kde_logfactor_kernel(const double* __restrict__ all_pos, int64_t nc, int ndi
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
   };
-  // running (maximum, scaled sum) per point over chunks of 64 * CF_ENS_KDE_CHUNK complementary walkers
+  // running (maximum, scaled sum) per point over chunks of 256 * CF_ENS_KDE_CHUNK complementary walkers
   double mxa = -INFINITY, mxq = -INFINITY, sa = 0.0, sq = 0.0;
-  for (int64_t c0 = 0; c0 < nc; c0 += 64 * CF_ENS_KDE_CHUNK) {
+  for (int64_t c0 = 0; c0 < nc; c0 += 256 * CF_ENS_KDE_CHUNK) {
     double ea[CF_ENS_KDE_CHUNK], eq[CF_ENS_KDE_CHUNK];
     double la = -INFINITY, lq = -INFINITY;
 #pragma unroll
     for (int t = 0; t < CF_ENS_KDE_CHUNK; ++t) {
-      const int64_t c = c0 + lane + 64 * t;
+      const int64_t c = c0 + tid + 256 * t;
       ea[t] = eq[t] = -INFINITY;
       if (c < nc) {
         double da = 0.0, dq = 0.0;
@@ -187,19 +308,35 @@ ens_kde_logfactor_kernel(const double* __restrict__ all_pos, int64_t nc, int ndi
       la = fmax(la, ea[t]);
       lq = fmax(lq, eq[t]);
     }
-    const double na = fmax(mxa, wave_max(la)), nq = fmax(mxq, wave_max(lq));
+    la = wave_max(la);
+    lq = wave_max(lq);
+    if (lane == 0) {
+      xch[wave][0] = la;
+      xch[wave][1] = lq;
+    }
+    __syncthreads();
+    const double na = fmax(mxa, fmax(fmax(xch[0][0], xch[1][0]), fmax(xch[2][0], xch[3][0])));
+    const double nq = fmax(mxq, fmax(fmax(xch[0][1], xch[1][1]), fmax(xch[2][1], xch[3][1])));
     double pa = 0.0, pq = 0.0;
 #pragma unroll
     for (int t = 0; t < CF_ENS_KDE_CHUNK; ++t) {
       pa += exp(ea[t] - na);  // exp(-inf) = 0 for the slots past nc
       pq += exp(eq[t] - nq);
     }
-    sa = sa * exp(mxa - na) + wave_add(pa);
-    sq = sq * exp(mxq - nq) + wave_add(pq);
+    pa = wave_add(pa);
+    pq = wave_add(pq);
+    if (lane == 0) {
+      xch[wave][2] = pa;
+      xch[wave][3] = pq;
+    }
+    __syncthreads();
+    sa = sa * exp(mxa - na) + (((xch[0][2] + xch[1][2]) + xch[2][2]) + xch[3][2]);
+    sq = sq * exp(mxq - nq) + (((xch[0][3] + xch[1][3]) + xch[2][3]) + xch[3][3]);
     mxa = na;
     mxq = nq;
+    __syncthreads();  // xch is rewritten by the next chunk
   }
-  if (lane == 0) log_factor[i] = ((mxa + log(sa)) + log_norm) - ((mxq + log(sq)) + log_norm);
+  if (tid == 0) log_factor[i] = ((mxa + log(sa)) + log_norm) - ((mxq + log(sq)) + log_norm);
 }
 
 // kind 0 stretch (emcee StretchMove, a), 1 DE (emcee DEMove, gamma0 = 2.38 / sqrt(2 ndim), sigma), 2 KDE (independence
@@ -309,7 +446,7 @@ extern "C" int cf_ens_propose(int32_t kind, const double* d_all_pos, int64_t w_t
                      d_all_pos, w_total / 2, (int)ndim, (int)half, split_key, d_ids, n_active, key0, a, de_sigma, d_kde_params, d_kde_wc,
                      d_y, d_log_factor);
   if (kind == 2)
-    hipLaunchKernelGGL(ens_kde_logfactor_kernel, dim3((unsigned)((n_active + 3) / 4)), dim3(256), 0, (hipStream_t)hip_stream,
+    hipLaunchKernelGGL(ens_kde_logfactor_kernel, dim3((unsigned)n_active), dim3(256), 0, (hipStream_t)hip_stream,
                        d_all_pos, w_total / 2, (int)ndim, d_ids, n_active, d_kde_params, d_kde_wc, (const double*)d_y, d_log_factor);
   return hipGetLastError() == hipSuccess ? CF_OK : cf_set_error(CF_ERR_HIP, "cf_ens_propose: launch failed");
 }
