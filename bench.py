@@ -112,11 +112,24 @@ def main():
     use_dist = "RANK" in os.environ
     if use_dist:
         import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend=backend)
-        dist.barrier()  # rank 0 may have been building the library: nobody loads it before this point
+        # RCCL and gloo print banners ("RCCL version : ...", "[Gloo] Rank 0 is connected ...") on the process's stdout when the
+        # communicator comes up; stdout carries ONE JSON line, so fd 1 points at stderr until the first collective has run
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend=backend)
+            dist.barrier()  # rank 0 may have been building the library: nobody loads it before this point
+            warm = torch.zeros(1, device=dev)
+            dist.all_reduce(warm)  # the first device collective creates the communicator
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     sn = pkg.sn_pantheon
     if args.scaling == "strong":
         if args.walkers_total % (32 * world):

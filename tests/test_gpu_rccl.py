@@ -28,8 +28,9 @@ def test_bench_under_torchrun_runs_rccl_with_one_rank(pkg):
            "--no-cpu-baseline", "--precondition-ms", "0", "--walkers-per-gpu", "1024", "--n-sn", "300"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    d = json.loads(line)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, "stdout must carry ONE JSON line (RCCL's banner goes to stderr):\n" + r.stdout[:800]
+    d = json.loads(lines[0])
     assert d["backend"] == "rccl (torch.distributed nccl)" and d["world_size"] == 1 and d["n_gpus"] == 1
     assert "RCCL all-gather of positions per step" in d["config"]["parallelism"]
     assert d["distinct_devices"] == 1 and len(d["device_ids"]) == 1 and d["value"] > 0
