@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COSMOFIT_LIB") or os.path.join(_HERE, "libcosmofit_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-CF_ABI_VERSION = 6
+CF_ABI_VERSION = 7
 CF_P_NSLOTS = 15
 SLOTS = ("offset", "H0", "Om", "obh2", "och2", "w0", "wa", "v", "rd", "fcc", "lin", "v2", "v3", "s8", "fs8err")
 

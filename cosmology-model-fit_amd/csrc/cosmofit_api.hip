@@ -1297,8 +1297,8 @@ extern "C" int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, doubl
   // the SN accessor path (reference-order mu_corr / mu_theory) is selected by a non-null dm / mu_corr buffer
   if (n > 0 && dm.ensure((size_t)W * n * 8)) return CF_ERR_HIP;
   if (n > 0 && mu_corr && mc.ensure((size_t)W * n * 8)) return CF_ERR_HIP;
-  if (blk.ensure((size_t)W * 6 * 8)) return CF_ERR_HIP;
-  HIP_TRY(hipMemsetAsync(blk.p, 0, (size_t)W * 6 * 8, h->stream));
+  if (blk.ensure((size_t)W * 8 * 8)) return CF_ERR_HIP;
+  HIP_TRY(hipMemsetAsync(blk.p, 0, (size_t)W * 8 * 8, h->stream));
   if (nb > 0 && bt.ensure((size_t)W * nb * 8)) return CF_ERR_HIP;
   if (nf > 0 && ft.ensure((size_t)W * nf * 8)) return CF_ERR_HIP;
   HIP_TRY(hipMemcpyAsync(h->theta.p, theta, (size_t)W * h->d.ndim * 8, hipMemcpyHostToDevice, h->stream));
@@ -1315,20 +1315,19 @@ extern "C" int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, doubl
   if (bao_theory) HIP_TRY(hipMemcpy(bao_theory, bt.p, (size_t)W * nb * 8, hipMemcpyDeviceToHost));
   if (fs8_theory) HIP_TRY(hipMemcpy(fs8_theory, ft.p, (size_t)W * nf * 8, hipMemcpyDeviceToHost));
   if (chi2_blocks) {
-    std::vector<double> sn((size_t)W), b6((size_t)W * 6), fs((size_t)W);
+    std::vector<double> sn((size_t)W), b8((size_t)W * 8), fs((size_t)W);
     HIP_TRY(hipMemcpy(sn.data(), snb.p, (size_t)W * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(b6.data(), blk.p, (size_t)W * 6 * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(b8.data(), blk.p, (size_t)W * 8 * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(fs.data(), fsb.p, (size_t)W * 8, hipMemcpyDeviceToHost));
     for (int64_t w = 0; w < W; ++w) {
-      // sn (written by the solve kernel before the other blocks are added), bao, cmb, the CMB distance vector, cc, fs8
-      chi2_blocks[8 * w + 0] = sn[w];
-      chi2_blocks[8 * w + 1] = b6[6 * w + 0];
-      chi2_blocks[8 * w + 2] = b6[6 * w + 1];
-      chi2_blocks[8 * w + 3] = b6[6 * w + 2];
-      chi2_blocks[8 * w + 4] = b6[6 * w + 3];
-      chi2_blocks[8 * w + 5] = b6[6 * w + 4];
-      chi2_blocks[8 * w + 6] = b6[6 * w + 5];
-      chi2_blocks[8 * w + 7] = fs[w];
+      // sn (written by the solve kernel before the other blocks are added), bao, cmb, the CMB distance vector, cc, fs8, then
+      // the two fitting formulae the blocks evaluated: z* and r_drag (0 where no block needs them)
+      double* o = chi2_blocks + 10 * w;
+      const double* b = &b8[8 * (size_t)w];
+      o[0] = sn[w];
+      o[1] = b[0]; o[2] = b[1]; o[3] = b[2]; o[4] = b[3]; o[5] = b[4]; o[6] = b[5];
+      o[7] = fs[w];
+      o[8] = b[6]; o[9] = b[7];
     }
   }
   return CF_OK;

@@ -715,7 +715,7 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
 // (inside walker_kernel these serial sections held a 72 KB table workgroup for as long as the table build and the
 // SN loop together).  Sixteen lanes, not a wave: the powers and the BAO data occupy 4-14 lanes per walker, and a
 // SIMD spends a whole wave-instruction on them however many lanes are active.
-// chi2_extra[w] = chi2_bao + chi2_cmb + chi2_cc;  blocks_out[w] = (bao, cmb, cmb vector[3], cc), bao_out[w][k] optional.
+// chi2_extra[w] = chi2_bao + chi2_cmb + chi2_cc;  blocks_out[w] = (bao, cmb, cmb vector[3], cc, z*, r_d), bao_out[w][k] optional.
 //   z* / r_drag: sums of products of powers (14 calls of pow), one power per lane, two dependent rounds, combined
 //   in the reference's order                               cmb/data_planck_act_compression.py:86-124
 //   CMB: lane l takes nodes l, l + 16, ... of r_s(z*) (in a) and D_M(z*) (in z), a butterfly adds the lanes
@@ -869,8 +869,10 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
   if (sl == 0 && live) {
     chi2_extra[w] = c_cmb + c_bao + c_cc;
     if (blocks_out) {
-      blocks_out[6 * w + 0] = c_bao; blocks_out[6 * w + 1] = c_cmb; blocks_out[6 * w + 5] = c_cc;
-      if (d.cmb_mode) { blocks_out[6 * w + 2] = vec[0]; blocks_out[6 * w + 3] = vec[1]; blocks_out[6 * w + 4] = vec[2]; }
+      blocks_out[8 * w + 0] = c_bao; blocks_out[8 * w + 1] = c_cmb; blocks_out[8 * w + 5] = c_cc;
+      if (d.cmb_mode) { blocks_out[8 * w + 2] = vec[0]; blocks_out[8 * w + 3] = vec[1]; blocks_out[8 * w + 4] = vec[2]; }
+      blocks_out[8 * w + 6] = z_star;  // 0 where no block needs them
+      blocks_out[8 * w + 7] = r_d;
     }
   }
 }

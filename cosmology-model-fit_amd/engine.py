@@ -275,10 +275,10 @@ class LikelihoodEngine:
         dl = np.empty((W, n)) if n else None
         bt = np.empty((W, nb)) if nb else None
         ft = np.empty((W, nf)) if nf else None
-        blocks = np.empty((W, 8))
+        blocks = np.empty((W, 10))
         L.check(L.lib().cf_eval_parts(self._h, _ptr(th), W, _ptr(dm), _ptr(mc), _ptr(dl), _ptr(blocks), _ptr(bt), _ptr(ft)))
         return dict(dm=dm, mu_corr=mc, delta=dl, chi2_blocks=blocks[:, :3], cmb_vector=blocks[:, 3:6], chi2_cc=blocks[:, 6],
-                    chi2_fs8=blocks[:, 7], bao_theory=bt, fs8_theory=ft)
+                    chi2_fs8=blocks[:, 7], z_star=blocks[:, 8], r_drag=blocks[:, 9], bao_theory=bt, fs8_theory=ft)
 
     def distance_table(self, theta):
         """(z_grid [G], cum_dm [W, G], dh_grid [W, G]) of one theta or a small batch: the grid of the scripts

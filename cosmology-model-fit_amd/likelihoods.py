@@ -591,8 +591,8 @@ class DesiFsLyaCcFs8(_Base):
 class CmbOnly(_Base):
     """cmb/cmb.py: theta = (H0, wb, wc); bounds :29-35.  The Planck+ACT (R, l_A, wb) compression alone.  ``log_likelihood`` and
     ``log_probability`` return (value, blobs) like the script (:45-70), blobs = (100 theta*, r_s(z*) in Mpc, D_M(z*) in Gpc, z*):
-    the first three follow from the (R, l_A) the device computed (D_M* = R c / (100 sqrt(wm)), r* = pi D_M* / l_A), z* from its
-    fitting formula."""
+    the first three follow from the (R, l_A) the device computed (D_M* = R c / (100 sqrt(wm)), r* = pi D_M* / l_A), z* is the
+    device's own evaluation of the fitting formula (``cf_eval_parts``)."""
     bounds = np.array([(60.0, 75.0), (0.020, 0.025), (0.05, 0.25)])
 
     def __init__(self, *, comp=None, device=0, devices=None, bounds=None):
@@ -607,10 +607,11 @@ class CmbOnly(_Base):
 
     def blobs(self, params):
         th = np.atleast_2d(np.asarray(params, float))
-        vec = self.engine.parts(th)["cmb_vector"]
+        parts = self.engine.parts(th)
+        vec = parts["cmb_vector"]
         wm = th[:, 1] + th[:, 2] + self.comp["omnu_h2"]
         dm_star = vec[:, 0] * C_KM_S / (100 * np.sqrt(wm))
-        out = np.stack([100 * np.pi / vec[:, 1], np.pi * dm_star / vec[:, 1], dm_star / 1000, cmb_data.z_star(self.comp, th[:, 1], wm)], axis=1)
+        out = np.stack([100 * np.pi / vec[:, 1], np.pi * dm_star / vec[:, 1], dm_star / 1000, parts["z_star"]], axis=1)
         return out[0] if np.ndim(params) == 1 else out
 
     def log_likelihood(self, params):

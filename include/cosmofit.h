@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 6
+#define CF_ABI_VERSION 7
 
 typedef struct cf_handle cf_handle;
 
@@ -335,7 +335,9 @@ int cf_eval_device(cf_handle* h, const double* d_theta, int64_t W, double* d_out
  *   dm_obs [W*n_sn]  DM(z_cmb)           sn/pantheon.py:58
  *   mu_corr[W*n_sn]                      sn/pantheon.py:43-49
  *   delta  [W*n_sn]  residual vector     sn/pantheon.py:59-60
- *   chi2_blocks[W*8] (chi2_sn, chi2_bao, chi2_cmb, cmb distance vector[3], chi2_cc, chi2_fs8)
+ *   chi2_blocks[W*10] (chi2_sn, chi2_bao, chi2_cmb, cmb distance vector[3], chi2_cc, chi2_fs8, z_star, r_drag: the two
+ *                     fitting formulae as the blocks evaluated them, 0 where no block needs them;
+ *                     cmb/data_planck_act_compression.py:86-124, the blobs of cmb/cmb.py:45-58)
  *                                        bao/desi_cmb_des5y.py:126-141, cmb/data_planck_act_compression.py:200-212
  *   bao_theory[W*n_bao]                  bao/desi_cmb_des5y.py:82-100
  *   fs8_theory[W*n_fs8]                  fs8_theory(a, theta) before the Alcock-Paczynski division, fs8/fs8.py:84-98 */

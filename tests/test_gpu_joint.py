@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 
 from conftest import golden
-from test_oracle_golden import _chol_of, lk_bao_desi_cmb_des5y, lk_bao_desi_des5y_bbn_theta_star
+from oracle import oracle_np as onp
+from test_oracle_golden import _chol_of, _cmbdata, lk_bao_desi_cmb_des5y, lk_bao_desi_des5y_bbn_theta_star
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-10
@@ -92,6 +93,13 @@ def test_config3_desi_cmb_des5y_golden(des5y):
     np.testing.assert_allclose(parts["chi2_blocks"], g["chi2_parts"], rtol=RTOL)
     np.testing.assert_allclose(parts["bao_theory"][:4], g["theory"], rtol=1e-12)
     np.testing.assert_allclose(parts["cmb_vector"][:4], g["cmb_dist"], rtol=1e-12)
+    # the two fitting formulae as the device evaluated them (cf_eval_parts slots 8, 9) against the oracle's restatement of
+    # cmb.z_star / cmb.r_drag (cmb/data_planck_act_compression.py:86-124; pinned to the reference's own values in
+    # tests/test_oracle_golden.py)
+    d = _cmbdata("PLANCK_ACT")
+    wb, wm = g["thetas"][:, 2], g["thetas"][:, 2] + g["thetas"][:, 3] + d["omnu_h2"]
+    np.testing.assert_allclose(parts["z_star"], [onp.z_star(d["zstar_fit"], b, m) for b, m in zip(wb, wm)], rtol=1e-13)
+    np.testing.assert_allclose(parts["r_drag"], [onp.r_drag(d["rd_fit"], b, m) for b, m in zip(wb, wm)], rtol=1e-13)
 
 
 def test_desi_cmb_des5y_h0trgb_golden(gpu):
