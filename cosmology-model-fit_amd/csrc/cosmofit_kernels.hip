@@ -85,15 +85,17 @@ extern "C" int cf_debug_walker_stamps(unsigned long long* out) {
 // `lnzp1` >= 0: ln(1 + z) of a grid node, tabulated at cf_create (theta-independent): the power of the wCDM / CPL forms
 // becomes ONE exp of a product instead of pow (+ exp): zp1^a = exp(a ln zp1), a few ulp from the library pow and a third
 // of its instructions -- the table build of the CPL model was 2.3x the LCDM one.  Absent (< 0): the reference's expression.
-template <int FDE>
+// TAB: `lnzp1` is known to be a tabulated value at compile time (the table build): the pow fallback is not even compiled in --
+// inlined eight times per thread it put ~1500 cold instructions into the hot loop.
+template <int FDE, bool TAB = false>
 __device__ __forceinline__ double f_de(const WalkerCosmo& wc, double z, double zp1, double cubed, double lnzp1 = -1.0) {
   if (FDE == CF_FDE_LCDM_D) return 1.0;
-  if (FDE == CF_FDE_WCDM_D) return lnzp1 >= 0.0 ? exp(3 * (1 + wc.w0) * lnzp1) : pow(zp1, 3 * (1 + wc.w0));
+  if (FDE == CF_FDE_WCDM_D) return (TAB || lnzp1 >= 0.0) ? exp(3 * (1 + wc.w0) * lnzp1) : pow(zp1, 3 * (1 + wc.w0));
   if (FDE == CF_FDE_THAWING_D) {
     double r = 2 * cubed / ((1.0 + wc.w0) + (1.0 - wc.w0) * cubed);
     return r * r;
   }
-  if (lnzp1 >= 0.0) return exp(fma(3 * (1 + wc.w0 + wc.wa), lnzp1, -3 * wc.wa * z / zp1));
+  if (TAB || lnzp1 >= 0.0) return exp(fma(3 * (1 + wc.w0 + wc.wa), lnzp1, -3 * wc.wa * z / zp1));
   return pow(zp1, 3 * (1 + wc.w0 + wc.wa)) * exp(-3 * wc.wa * z / zp1);
 }
 
@@ -110,15 +112,16 @@ __device__ __forceinline__ double omnu_z(const cf_dev_desc& d, double zp1) {
 // E^2(z) of both families.  `nu` < 0: evaluate the massive-neutrino density here; otherwise it is the
 // value tabulated at cf_create for this grid node (it does not depend on theta: 5 sqrt + 2 divides saved
 // per node and per walker, and the tabulated value is the reference's own arithmetic).
-template <int MODEL, int FDE>
+// TAB (the table build's register path): `nu` and `lnzp1` ARE tabulated values, the fallbacks are compiled out.
+template <int MODEL, int FDE, bool TAB = false>
 __device__ __forceinline__ double e2_of_z(const cf_dev_desc& d, const WalkerCosmo& wc, double z, double nu = -1.0, double lnzp1 = -1.0) {
   const double zp1 = 1.0 + z;
   const double cubed = zp1 * zp1 * zp1;
   if (MODEL == CF_EZ_LATE_FLAT_D)
     return (FDE == CF_FDE_LCDM_D) ? wc.Om * cubed + (1.0 - wc.Om)
-                                  : wc.Om * cubed + (1.0 - wc.Om) * f_de<FDE>(wc, z, zp1, cubed, lnzp1);
-  const double de = (FDE == CF_FDE_LCDM_D) ? wc.Ode : wc.Ode * f_de<FDE>(wc, z, zp1, cubed, lnzp1);
-  if (nu < 0.0) nu = omnu_z(d, zp1);
+                                  : wc.Om * cubed + (1.0 - wc.Om) * f_de<FDE, TAB>(wc, z, zp1, cubed, lnzp1);
+  const double de = (FDE == CF_FDE_LCDM_D) ? wc.Ode : wc.Ode * f_de<FDE, TAB>(wc, z, zp1, cubed, lnzp1);
+  if (!TAB && nu < 0.0) nu = omnu_z(d, zp1);
   return wc.Or * (cubed * zp1) + wc.Obc * cubed + de + wc.Onu * nu;  // bao/desi_cmb_des5y.py:43-48
 }
 
@@ -361,19 +364,16 @@ __device__ __forceinline__ double wave_inclusive_scan(double v) {
 // wave-boundary intervals with the carries.
 template <int MODEL, int FDE, int CH, bool LAST>
 __device__ __forceinline__ double chunk_eval(const cf_dev_desc& d, const WalkerCosmo& wc, double c_over_H0, int g0, int lane,
-                                             const double (&nu_pre)[CH], double (&dh)[CH], double (&loc)[CH]) {
+                                             const double (&nu_pre)[CH], const double (&ln)[CH], double (&dh)[CH], double (&loc)[CH]) {
   const int G = d.n_grid;
-  double ln[CH];
-  // ln(1 + z) of the nodes for the power-law dark-energy forms (theta-independent table, L2-resident)
-  constexpr bool POWER_LAW = FDE == CF_FDE_WCDM_D || FDE == CF_FDE_CPL_D;
-#pragma unroll
-  for (int k = 0; k < CH; ++k) ln[k] = (POWER_LAW && d.ln_grid) ? d.ln_grid[min(g0 + k, G - 1)] : -1.0;
+  // nu_pre / ln: the tabulated neutrino density and ln(1 + z) of the nodes (theta-independent tables, fetched by the kernel
+  // before anything else); the tables exist whenever the model needs them (cf_create), so no fallback is compiled in
 #pragma unroll
   for (int k = 0; k < CH; ++k) {
     const int g = g0 + k;
     double z = (double)g * d.step;
     if (LAST) z = g >= G - 1 ? d.z_max : z;
-    const double v = c_over_H0 * rsqrt_pos(e2_of_z<MODEL, FDE>(d, wc, z, nu_pre[k], ln[k]));
+    const double v = c_over_H0 * rsqrt_pos(e2_of_z<MODEL, FDE, true>(d, wc, z, nu_pre[k], ln[k]));
     dh[k] = (LAST && g >= G) ? 0.0 : v;
   }
   double prev = dpp_move<0x138, 0xF>(dh[CH - 1]);  // wave_shr:1; lane 0 gets 0 and skips its first interval
@@ -391,7 +391,7 @@ __device__ __forceinline__ double chunk_eval(const cf_dev_desc& d, const WalkerC
 
 template <int MODEL, int FDE, int CH>
 __device__ __forceinline__ void build_distance_table_regs(const cf_dev_desc& d, const WalkerCosmo& wc, d2* tab,
-                                                          d4* wave_pub, const double (&nu_pre)[CH]) {
+                                                          d4* wave_pub, const double (&nu_pre)[CH], const double (&ln_pre)[CH]) {
   const int G = d.n_grid;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g0 = tid * CH;
@@ -399,8 +399,8 @@ __device__ __forceinline__ void build_distance_table_regs(const cf_dev_desc& d, 
   const double c_over_H0 = wc.c / wc.H0;
   double dh[CH], loc[CH];
   const int wave_last = (tid - lane) * CH + 64 * CH - 1;  // last node of this wave
-  const double run = wave_last < G - 1 ? chunk_eval<MODEL, FDE, CH, false>(d, wc, c_over_H0, g0, lane, nu_pre, dh, loc)
-                                       : chunk_eval<MODEL, FDE, CH, true>(d, wc, c_over_H0, g0, lane, nu_pre, dh, loc);
+  const double run = wave_last < G - 1 ? chunk_eval<MODEL, FDE, CH, false>(d, wc, c_over_H0, g0, lane, nu_pre, ln_pre, dh, loc)
+                                       : chunk_eval<MODEL, FDE, CH, true>(d, wc, c_over_H0, g0, lane, nu_pre, ln_pre, dh, loc);
   CF_WSTAMP(2);
   const double incl = wave_inclusive_scan(run);
   // per wave: {sum of its intervals, dh of its first node, dh of its last node}
@@ -470,9 +470,9 @@ __device__ __forceinline__ void build_distance_table_lds(const cf_dev_desc& d, c
 
 template <int MODEL, int FDE>
 __device__ __forceinline__ void build_distance_table(const cf_dev_desc& d, const WalkerCosmo& wc, d2* tab,
-                                                     d4* wave_pub, const double (&nu_pre)[8]) {
+                                                     d4* wave_pub, const double (&nu_pre)[8], const double (&ln_pre)[8]) {
   // grids up to 4096 nodes (the reference uses 4000) take the register path, 8 nodes per thread
-  if (d.chunk_shift == 3) build_distance_table_regs<MODEL, FDE, 8>(d, wc, tab, wave_pub, nu_pre);
+  if (d.chunk_shift == 3) build_distance_table_regs<MODEL, FDE, 8>(d, wc, tab, wave_pub, nu_pre, ln_pre);
   else build_distance_table_lds<MODEL, FDE>(d, wc, tab, wave_pub);
 }
 
@@ -626,11 +626,13 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
   if (tid < 64 && d.n_sn > 0) log_tab[tid] = reinterpret_cast<const d2*>(d.log10_tab)[tid];
   // tabulated massive-neutrino density of this thread's 8 grid nodes (register path of the table build): fetched
   // before anything else so that the loads fly while theta is read and the cosmology scalars are formed
-  double nu_pre[8];
+  double nu_pre[8], ln_pre[8];
+  constexpr bool POWER_LAW = FDE == CF_FDE_WCDM_D || FDE == CF_FDE_CPL_D;  // ln(1 + z) of the nodes: zp1^a = exp(a ln zp1)
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int gc = min(tid * 8 + k, d.n_grid - 1);
-    nu_pre[k] = (MODEL == CF_EZ_PHYSICAL_D && d.nu_grid && d.chunk_shift == 3) ? d.nu_grid[gc] : -1.0;
+    nu_pre[k] = (MODEL == CF_EZ_PHYSICAL_D && d.chunk_shift == 3) ? d.nu_grid[gc] : -1.0;
+    ln_pre[k] = (POWER_LAW && d.chunk_shift == 3) ? d.ln_grid[gc] : -1.0;
   }
   const WalkerCosmo wc = make_cosmo(d, th);
   DistTable T;
@@ -643,7 +645,7 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
   T.z_max = d.z_max;
 
   CF_WSTAMP(1);
-  if (d.n_sn > 0 || d.n_aux > 0 || table_out) build_distance_table<MODEL, FDE>(d, wc, lds_tab, wave_pub, nu_pre);
+  if (d.n_sn > 0 || d.n_aux > 0 || table_out) build_distance_table<MODEL, FDE>(d, wc, lds_tab, wave_pub, nu_pre, ln_pre);
   CF_WSTAMP(4);
   if (table_out)  // accessor path (cf_eval_table): the walker's whole {cum_dm, dh} table, node order
     for (int g = tid; g < d.n_grid; g += CF_TPB_A) table_out[w * d.n_grid + g] = T.at(g);
