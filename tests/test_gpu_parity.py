@@ -3,6 +3,8 @@ GPU (-m gpu): the HIP path, called through the C-ABI, against the CPU oracle and
 vectors generated from the reference.  Tolerances: chi^2 / log-probability <= 1e-10 relative
 (BASELINE.json north_star); intermediates looser only where a cancellation amplifies rounding.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -562,3 +564,30 @@ def test_posterior_means_match_the_oracle_driven_chain_to_sampling_noise(gpu):
     assert np.all(np.abs(g.mean(axis=0) - gpu.synthetic.THETA_TRUE) < 4 * sd)
     assert 0.1 < e_gpu.acceptance_fraction() < 0.9
     lk.engine.close()
+
+
+def test_host_calls_in_place_and_through_copies_agree_bit_for_bit(gpu, tmp_path):
+    """cf_eval lets the kernels read theta from / write the results to the pinned staging block in place for batches up to
+    CF_ZEROCOPY_MAX walkers (default 16384) and goes through two copy commands above it; the knob is read once per process,
+    so the two forms run in two child processes on the same inputs."""
+    import subprocess
+    import sys
+
+    script = tmp_path / "zc.py"
+    script.write_text(
+        "import importlib, sys, numpy as np\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "amd = importlib.import_module('cosmology-model-fit_amd')\n"
+        "syn = amd.synthetic.pantheon_like(n_sn=300, seed=2)\n"
+        "lk = amd.sn_pantheon.PantheonLikelihood(syn['z_cmb'], syn['z_hel'], syn['obs'], chol=syn['chol'])\n"
+        "th = amd.synthetic.walkers(amd.sn_pantheon.bounds, 1000, seed=4)\n"
+        "th[5, 1] = 200.0  # out of the box: -inf\n"
+        "out = np.concatenate([lk.log_probs_vectorized(th[:W]) for W in (1, 33, 1000)] + [lk.chi_squared(th[:77])])\n"
+        "np.save(sys.argv[1], out)\n")
+    outs = []
+    for tag, zc in (("copy", "0"), ("inplace", "100000")):
+        env = dict(os.environ, CF_ZEROCOPY_MAX=zc)
+        r = subprocess.run([sys.executable, str(script), str(tmp_path / (tag + ".npy"))], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(tmp_path / (tag + ".npy")))
+    assert np.array_equal(outs[0], outs[1], equal_nan=True) and np.isneginf(outs[0][1 + 5])
