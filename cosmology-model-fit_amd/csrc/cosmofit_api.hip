@@ -281,7 +281,7 @@ struct cf_handle {
   cf_dev_desc d{};
   PackedFactor pack;
   DevBuf z_cmb, z_hel, obs, sn_step, sn_rec, log10_tab;
-  DevBuf bao_z, bao_val, bao_inv_cov, bao_qty, gl_x, gl_w, fixed_mu, cc_z, cc_h, cc_inv_cov, nu_grid, ln_grid, sn_lin, sn_dir;
+  DevBuf bao_z, bao_val, bao_inv_cov, bao_qty, gl_x, gl_w, fixed_mu, cc_z, cc_h, cc_inv_cov, nu_grid, ln_grid, nu_sw, ln_sw, sn_lin, sn_dir;
   DevBuf theta, out, delta, ypk, chi2_extra, nonfinite;
   DevBuf fs8_z, fs8_val, fs8_inv_cov, fs8_fid, fs8_step_of, fs8_order, fs8_tab, fs8_pts;
   DevBuf bao_nodes, bao_base;  // [max_walkers][n_bao][CF_BAO_NODES] table nodes for small_blocks_kernel; first node per datum
@@ -318,6 +318,16 @@ static int32_t aux_node_base(const cf_dev_desc& d, double xi) {
   if (i < G - 2 && (double)(i + 1) * d.step < xi) ++i;
   int b = i - 2;
   return b < 0 ? 0 : (b > G - CF_BAO_NODES ? G - CF_BAO_NODES : b);
+}
+
+// A per-node table in the order the 512 threads of walker_kernel fetch it (thread t owns nodes 8 t .. 8 t + 7):
+// out[k * 512 + t] = table[min(8 t + k, n - 1)]   (cosmofit_device.h: nu_sw / ln_sw)
+static std::vector<double> swizzle_for_walker_threads(const std::vector<double>& table) {
+  std::vector<double> out(8 * 512);
+  const size_t n = table.size();
+  for (int k = 0; k < 8; ++k)
+    for (int t = 0; t < 512; ++t) out[(size_t)k * 512 + t] = table[std::min((size_t)(8 * t + k), n - 1)];
+  return out;
 }
 
 static int upload_vec(DevBuf& b, const double* src, int64_t n) {
@@ -767,6 +777,11 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
     int rc;
     if ((rc = upload_vec(h->nu_grid, nu.data(), c->n_grid))) return bail(rc);
     d.nu_grid = h->nu_grid.as<const double>();
+    if (d.chunk_shift == 3) {
+      const std::vector<double> sw = swizzle_for_walker_threads(nu);
+      if ((rc = upload_vec(h->nu_sw, sw.data(), (int64_t)sw.size()))) return bail(rc);
+      d.nu_sw = h->nu_sw.as<const double>();
+    }
   }
   if (c->fde == CF_FDE_WCDM || c->fde == CF_FDE_CPL) {
     // ln(1 + z) at the grid nodes, correctly rounded from extended precision: the power-law dark-energy forms become one exp
@@ -778,6 +793,11 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
     int rc;
     if ((rc = upload_vec(h->ln_grid, ln.data(), c->n_grid))) return bail(rc);
     d.ln_grid = h->ln_grid.as<const double>();
+    if (d.chunk_shift == 3) {
+      const std::vector<double> sw = swizzle_for_walker_threads(ln);
+      if ((rc = upload_vec(h->ln_sw, sw.data(), (int64_t)sw.size()))) return bail(rc);
+      d.ln_sw = h->ln_sw.as<const double>();
+    }
   }
   if (c->n_cc > 0) {
     int rc;

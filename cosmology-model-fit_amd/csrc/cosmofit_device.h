@@ -105,6 +105,11 @@ struct cf_dev_desc {
   double nu_qs_sq[5], nu_ws[5];
   const double* nu_grid;  // [n_grid] massive-neutrino density ratio at the grid nodes (theta-independent), or null
   const double* ln_grid;  // [n_grid] ln(1 + z) at the grid nodes (wCDM / CPL dark energy: zp1^a = exp(a ln zp1)), or null
+  // the same two tables in the order the 512 threads of walker_kernel fetch them (thread t owns nodes 8 t .. 8 t + 7):
+  // [k * 512 + t] = table[min(8 t + k, n_grid - 1)], so that a wave's load of its k-th nodes is 512 contiguous bytes instead of
+  // 64 cache lines; only for the register path of the table build (n_grid <= 4096), else null
+  const double* nu_sw;
+  const double* ln_sw;
   // BAO block
   int32_t n_bao, bao_dh_exact, rd_from_fit, rd_wm_late;  // rd_wm_late: the r_drag fit takes wm = Omega_m h^2 (late-time flat model)
   const double* bao_z;

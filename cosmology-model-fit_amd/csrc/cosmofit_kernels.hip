@@ -630,9 +630,9 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
   constexpr bool POWER_LAW = FDE == CF_FDE_WCDM_D || FDE == CF_FDE_CPL_D;  // ln(1 + z) of the nodes: zp1^a = exp(a ln zp1)
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const int gc = min(tid * 8 + k, d.n_grid - 1);
-    nu_pre[k] = (MODEL == CF_EZ_PHYSICAL_D && d.chunk_shift == 3) ? d.nu_grid[gc] : -1.0;
-    ln_pre[k] = (POWER_LAW && d.chunk_shift == 3) ? d.ln_grid[gc] : -1.0;
+    // swizzled copies: thread-contiguous chunks of the natural table would make every one of these loads touch 64 cache lines
+    nu_pre[k] = (MODEL == CF_EZ_PHYSICAL_D && d.chunk_shift == 3) ? d.nu_sw[k * CF_TPB_A + tid] : -1.0;
+    ln_pre[k] = (POWER_LAW && d.chunk_shift == 3) ? d.ln_sw[k * CF_TPB_A + tid] : -1.0;
   }
   const WalkerCosmo wc = make_cosmo(d, th);
   DistTable T;
