@@ -738,7 +738,7 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
     // what the ODE's coefficients need that does not depend on theta, at the 2 S + 1 boundaries and midpoints of the steps:
     // a = exp(x), 1 + z, the massive-neutrino density ratio and nu 3 (1 + w_nu) / (1 + z)   cmb/data_planck_act_compression.py:53-83
     const int npts = 2 * d.fs8_steps + 1;
-    std::vector<double> tab((size_t)npts * 4);
+    std::vector<double> tab((size_t)(2 * (d.fs8_steps / 256)) * 257 * 4, 0.0);
     for (int m = 0; m < npts; ++m) {
       const double a = m == npts - 1 ? 1.0 : std::exp(x0 + m * (0.5 * hstep)), zp1 = 1.0 / a;
       double nu = 0.0, dnu = 0.0;
@@ -755,7 +755,10 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
         const double w_nu = (1.0 / 3) - (1.0 / 3) * mz_sq * num / den;
         dnu = nu * 3 * (1.0 + w_nu) / zp1;
       }
-      tab[4 * m] = a; tab[4 * m + 1] = zp1; tab[4 * m + 2] = nu; tab[4 * m + 3] = dnu;
+      // stored in the order the 256 lanes of growth_kernel fetch it: point m at [(m % 2C) * 257 + m / 2C], C = steps / 256
+      const int c2 = 2 * (d.fs8_steps / 256);
+      const size_t at = (size_t)(m % c2) * 257 + (size_t)(m / c2);
+      tab[4 * at] = a; tab[4 * at + 1] = zp1; tab[4 * at + 2] = nu; tab[4 * at + 3] = dnu;
     }
     if ((rc = upload_vec(h->fs8_tab, tab.data(), (int64_t)tab.size()))) return bail(rc);
     d.fs8_tab = h->fs8_tab.as<const double>();

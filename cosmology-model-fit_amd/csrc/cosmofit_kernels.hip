@@ -949,7 +949,7 @@ __device__ __forceinline__ M22 shfl_up_m(const M22& m, int delta) {
   return {__shfl_up(m.a, delta), __shfl_up(m.b, delta), __shfl_up(m.c, delta), __shfl_up(m.d, delta)};
 }
 
-// A(x) at table point m (boundary i = m / 2 for even m, the midpoint of step (m - 1) / 2 for odd m)
+// A(x) at the table point stored at index m of fs8_tab (see growth_kernel for the order)
 template <int MODEL, int FDE>
 __device__ __forceinline__ void growth_coef(const cf_dev_desc& d, const WalkerCosmo& wc, double om, int m, double lnzp1, double& a,
                                             double& s, double& p) {
@@ -1007,14 +1007,17 @@ growth_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, const 
   M22 M[C];
   double s_at[C], p_at[C];  // A at the start boundary of each step: d delta'/dx = s delta - p delta'
   double a0, s0, p0, s_end, p_end;
-  growth_coef<MODEL, FDE>(d, wc, om, 2 * C * tid, -(x0 + (2 * C * tid) * hh), a0, s0, p0);
+  // table point m (boundary / midpoint number) lives at [(m % 2C) * 257 + m / 2C]: lane t reads its j-th point from row j at
+  // column t -- a wave's load is contiguous (from [m] every lane would touch its own cache line); cf_create stores it so
+  auto sw = [](int m) { return (m % (2 * C)) * 257 + m / (2 * C); };
+  growth_coef<MODEL, FDE>(d, wc, om, sw(2 * C * tid), -(x0 + (2 * C * tid) * hh), a0, s0, p0);
   M22 Q{1.0, 0.0, 0.0, 1.0};
 #pragma unroll
   for (int j = 0; j < C; ++j) {
     const int m = 2 * (C * tid + j);
     double am, sm, pm, a1, s1, p1;
-    growth_coef<MODEL, FDE>(d, wc, om, m + 1, -(x0 + (m + 1) * hh), am, sm, pm);
-    growth_coef<MODEL, FDE>(d, wc, om, m + 2, m + 2 == 2 * S ? 0.0 : -(x0 + (m + 2) * hh), a1, s1, p1);
+    growth_coef<MODEL, FDE>(d, wc, om, sw(m + 1), -(x0 + (m + 1) * hh), am, sm, pm);
+    growth_coef<MODEL, FDE>(d, wc, om, sw(m + 2), m + 2 == 2 * S ? 0.0 : -(x0 + (m + 2) * hh), a1, s1, p1);
     const M22 A0{0.0, a0, s0, -p0}, Ah{0.0, am, sm, -pm}, A1{0.0, a1, s1, -p1};
     const M22 K2 = mm(Ah, M22{1.0, hh * A0.b, hh * A0.c, 1.0 + hh * A0.d});
     const M22 K3 = mm(Ah, M22{1.0 + hh * K2.a, hh * K2.b, hh * K2.c, 1.0 + hh * K2.d});
