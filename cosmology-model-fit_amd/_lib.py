@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COSMOFIT_LIB") or os.path.join(_HERE, "libcosmofit_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-CF_ABI_VERSION = 7
+CF_ABI_VERSION = 8
 CF_P_NSLOTS = 15
 SLOTS = ("offset", "H0", "Om", "obh2", "och2", "w0", "wa", "v", "rd", "fcc", "lin", "v2", "v3", "s8", "fs8err")
 
@@ -121,9 +121,11 @@ EXPORTS = {
     "cf_selftest_invpack_host": (C.c_int, [_VP, _I64, _I64, _VP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "cf_selftest_log10": (C.c_int, [_VP, _I64, _VP]),
     "cf_selftest_log10_tab": (C.c_int, [_VP, _I64, _VP]),
-    "cf_ens_active_set": (C.c_int, [C.c_uint64, _I64, _I64, C.c_int32, _I64, _VP, _VP, _VP]),
-    "cf_ens_kde_prepare": (C.c_int, [_VP, _I64, C.c_int32, C.c_int32, C.c_uint64, _VP, _VP, _VP]),
-    "cf_ens_propose": (C.c_int, [C.c_int32, _VP, _I64, C.c_int32, C.c_int32, C.c_uint64, _VP, _I64, C.c_uint64, C.c_double,
+    "cf_ens_active_count": (_I64, [C.c_uint64, _I32, _I32, _I64, _I64]),
+    "cf_ens_comp_count": (_I64, [C.c_uint64, _I32, _I32, _I64]),
+    "cf_ens_active_set": (C.c_int, [C.c_uint64, _I32, _I32, _I64, _I64, _VP, _VP, _VP]),
+    "cf_ens_kde_prepare": (C.c_int, [_VP, _I64, _I32, _I32, _I32, C.c_uint64, _VP, _VP, _VP]),
+    "cf_ens_propose": (C.c_int, [_I32, _VP, _I64, _I32, _I32, _I32, C.c_uint64, _VP, _I64, C.c_uint64, C.c_double,
                                  C.c_double, _VP, _VP, _VP, _VP, _VP]),
     "cf_ens_accept": (C.c_int, [_VP, _VP, _I64, C.c_int32, C.c_uint64, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "cf_selftest_pack_host": (C.c_int, [_VP, _I64, _I64, _VP, C.POINTER(C.c_double), C.POINTER(_I64)]),

@@ -1,35 +1,40 @@
 """
 Walker ensemble sharded over the GPUs of one node.
 
-One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests).
-Rank r owns a contiguous slice of the W walkers.  The log-probability of a walker depends only on its own
-theta, so the evaluation itself needs no collective; the ensemble MOVE does: a red/blue half-step draws the
-partner of every active walker from the complementary half, which lives on all ranks -> one all-gather of the
-walker positions per half-step (W_local x ndim doubles per rank; 128 KiB at 4096 x 4: latency-bound, so a
-single flat all-gather, no bucketing).
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests and for rank processes
+that share one GPU, where the all-gather is staged through the host).  Rank r owns a contiguous slice of the W walkers.
+The log-probability of a walker depends only on its own theta, so the evaluation itself needs no collective; the
+ensemble MOVE does: the update of one split draws the partners of every active walker from the complementary set, which
+lives on all ranks -> one all-gather of the walker positions per split update (W_local x ndim doubles per rank; 128 KiB
+at 4096 x 4: latency-bound, so a single flat all-gather, no bucketing).
 
 Moves (the ones the reference's scripts configure on emcee): the Goodman & Weare stretch move (emcee's
 default, used by the reference's quasars/ scripts), the differential-evolution move and the KDE move with
 Silverman's bandwidth (``moves = [(KDEMove(bw_method="silverman"), 0.30), (DEMove(), 0.70)]``,
 sn/pantheon.py:114-117).  One move is drawn per step with the configured weights, as emcee does.
-Random numbers come from a counter-based generator keyed on (seed, step, half, GLOBAL walker index,
+Random numbers come from a counter-based generator keyed on (seed, step, split, GLOBAL walker index,
 stream), and every quantity a proposal uses is computed from the gathered (global) ensemble with
 per-element arithmetic, so a chain is bit-identical for any number of ranks — that is what the gloo
-tests check.
+tests check (tensor statement on CPU; the library's kernels with 2 and 3 rank processes on one GPU).
 
 `log_prob_fn(theta[W, ndim] tensor) -> tensor[W]` is pluggable: on a GPU it is
 ``LikelihoodEngine.torch_log_prob`` (HIP kernels through cf_eval_device on the current stream).
 
-The proposal and accept arithmetic runs in the library's own kernels (cf_ens_kde_prepare / cf_ens_propose /
-cf_ens_accept, csrc/cosmofit_ensemble.hip: two or three launches per half-step, no host round trip).  This module is
-the DRIVER only: sharding, the all-gather, the step loop, the random-stream keys.  There is no tensor-library fallback:
-an ensemble on CPU tensors needs an explicit ``moves_impl`` -- the test-suite passes ``oracle.moves_torch.TensorMoves``,
-the tensor statement of the same moves, to rehearse the multi-rank logic under gloo and to check the kernels.
+The proposal and accept arithmetic runs in the library's own kernels (cf_ens_active_set / cf_ens_kde_prepare /
+cf_ens_propose / cf_ens_accept, csrc/cosmofit_ensemble.hip: three or four launches per split update, no host round trip).
+This module is the DRIVER only: sharding, the all-gather, the step loop, the random-stream keys.  There is no
+tensor-library fallback: an ensemble on CPU tensors needs an explicit ``moves_impl`` -- the test-suite passes
+``oracle.moves_torch.TensorMoves``, the tensor statement of the same moves, to rehearse the multi-rank logic under gloo and
+to check the kernels.
 
-Halves.  emcee's RedBlueMove re-draws the two halves every step; here ``randomize_split=True`` (default) flips each
-consecutive pair of walkers (2c, 2c + 1) with a counter-based random bit per step, so the halves change every step
-while every rank still owns exactly half of its walkers in each half (no host round trip, chains independent of the
-number of ranks); ``randomize_split=False`` keeps the even / odd parity classes for the whole run.
+Splits.  emcee's RedBlueMove updates ``nsplits`` sets of walkers in turn, each from the union of the others, and re-draws
+the sets every step; StretchMove and KDEMove use two sets, **DEMove three** (emcee's ``DEMove.__init__`` sets
+``nsplits = 3``), so a DE step here is three split updates of a third of the ensemble each, proposing from the other two
+thirds (``de_splits=2`` gives the two-halves variant).  Walkers are taken in consecutive groups of S = nsplits: walker
+S c + b belongs to split perm_c[b]; ``randomize_split=True`` (default) draws perm_c as a counter-based random permutation
+per group and step, so the sets change every step while every split keeps exactly one member of every group (any shard
+owns its fair share of each split, no host round trip, chains independent of the number of ranks and of where the shard
+boundaries fall); ``randomize_split=False`` keeps the classes (index mod S) for the whole run.
 """
 from __future__ import annotations
 
@@ -67,14 +72,15 @@ def _mix_int(x: int) -> int:
 
 
 def stream_key(seed: int, step: int, half: int, stream: int = 0) -> int:
-    """Unsigned 64-bit key of random stream `stream` for (seed, step, half); stream s has key(stream 0) + s.
+    """Unsigned 64-bit key of random stream `stream` for (seed, step, half = the split being updated: 0, 1 [, 2]); stream s has
+    key(stream 0) + s.
 
-    seed and step each pass through their own hash round, so the 512 consecutive keys of one (seed, step) -- 256
-    streams for each half -- sit at a pseudo-random 64-bit offset: the streams of different steps, halves or seeds
+    seed and step each pass through their own hash round, so the 768 consecutive keys of one (seed, step) -- 256
+    streams for each split -- sit at a pseudo-random 64-bit offset: the streams of different steps, halves or seeds
     never share a key (an arithmetic key such as (seed * K + step) * 8 + half * 4 + stream makes the KDE move's noise
     streams of step t coincide with the partner / accept streams of step t + 1)."""
-    if not (0 <= stream < MAX_STREAMS) or half not in (0, 1):
-        raise ValueError(f"stream must be in 0..{MAX_STREAMS - 1} and half in (0, 1)")
+    if not (0 <= stream < MAX_STREAMS) or half not in (0, 1, 2):
+        raise ValueError(f"stream must be in 0..{MAX_STREAMS - 1} and the split in (0, 1, 2)")
     base = _mix_int(_mix_int(seed * 0x9E3779B97F4A7C15 + 0x5851F42D4C957F2D) ^ (step & _U64))
     return (base + (half << 8) + stream) & _U64
 
@@ -84,6 +90,37 @@ def uniform01_scalar(key: int, counter: int) -> float:
     x = _mix_int(((counter & _U64) * 0x9E3779B97F4A7C15 + key) & _U64)
     x = _mix_int((x + 0x9E3779B97F4A7C15) & _U64)
     return (x >> 11) * (1.0 / 9007199254740992.0)
+
+
+_PERM3 = ((0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0))
+
+
+def split_perm(split_key: int, n_splits: int, group: int):
+    """perm_c of walker group `group`: walker S c + b belongs to split perm_c[b] (cosmofit_ensemble.hip: ens_split_of)."""
+    if split_key == 0:
+        return tuple(range(n_splits))
+    x = _mix_int(((group & _U64) * 0x9E3779B97F4A7C15 + split_key) & _U64)
+    x = _mix_int((x + 0x9E3779B97F4A7C15) & _U64)
+    if n_splits == 2:
+        f = x >> 63
+        return (f, 1 - f)
+    return _PERM3[((x >> 40) * 6) >> 24]
+
+
+def active_count(split_key: int, n_splits: int, split: int, start: int, stop: int) -> int:
+    """Walkers of split `split` in the shard [start, stop): one per group, less the cut first / last group's member
+    (the library's cf_ens_active_count, on Python ints: the driver sizes its launches without a device round trip)."""
+    if stop <= start:
+        return 0
+    c0, c1 = start // n_splits, (stop - 1) // n_splits
+    n = c1 - c0 + 1
+    id0 = n_splits * c0 + split_perm(split_key, n_splits, c0).index(split)
+    id1 = n_splits * c1 + split_perm(split_key, n_splits, c1).index(split)
+    if not (start <= id0 < stop):
+        n -= 1
+    if c1 > c0 and not (start <= id1 < stop):
+        n -= 1
+    return n
 
 
 REFERENCE_MOVES = (("kde", 0.30), ("de", 0.70))  # sn/pantheon.py:114-117
@@ -98,36 +135,32 @@ class NativeMoves:
         from . import _lib as L
 
         self.L, self.lib = L, L.lib()  # raises if the HIP library is missing
-        dev, nmax = e.x.device, max(1, (e.stop - e.start + 1) // 2)
+        dev, nmax = e.x.device, (e.stop - e.start) // 2 + 2
         self.y = torch.empty((nmax, e.ndim), dtype=torch.float64, device=dev)
         self.logfac = torch.empty(nmax, dtype=torch.float64, device=dev)
         self.kde_params = torch.empty(2 * e.ndim * e.ndim + 1, dtype=torch.float64, device=dev)
-        self.kde_wc = torch.empty((e.n_total // 2, e.ndim), dtype=torch.float64, device=dev)
+        self.kde_wc = torch.empty(((2 * e.n_total + 2) // 3, e.ndim), dtype=torch.float64, device=dev)
         self.n_acc = torch.zeros(1, dtype=torch.int64, device=dev)
         self.ids = torch.empty(nmax, dtype=torch.int64, device=dev)
         self.idx = torch.empty(nmax, dtype=torch.int64, device=dev)
-        # fixed-parity halves of this rank's shard (ragged shards and randomize_split=False)
-        self.fixed = [(e.ids[(e.ids % 2) == h].contiguous(), (e.ids[(e.ids % 2) == h] - e.start).contiguous()) for h in (0, 1)]
 
-    def half_step(self, e, move, half, allpos, split_key):
+    def split_step(self, e, move, n_splits, split, allpos, split_key):
         L, lib = self.L, self.lib
         kind = _KIND[move]
         stream = torch.cuda.current_stream(e.x.device).cuda_stream
-        if split_key:  # this step's halves: walker 2c + (half ^ flip_c) of every local pair -- one small launch, no host sync
-            n_pairs = (e.stop - e.start) // 2
-            ids, idx = self.ids[:n_pairs], self.idx[:n_pairs]
-            L.check(lib.cf_ens_active_set(split_key, e.start // 2, n_pairs, half, e.start, ids.data_ptr(), idx.data_ptr(), stream))
-        else:
-            ids, idx = self.fixed[half]
-        n = int(ids.numel())
+        # this step's active set: the shard's walkers of split `split` -- one small launch, no host sync (the count is
+        # arithmetic on the shard bounds and two group permutations)
+        n = active_count(split_key, n_splits, split, e.start, e.stop)
         if n == 0:
             return
-        key0 = stream_key(e.seed, e.step_count, half)
+        ids, idx = self.ids[:n], self.idx[:n]
+        L.check(lib.cf_ens_active_set(split_key, n_splits, split, e.start, e.stop, ids.data_ptr(), idx.data_ptr(), stream))
+        key0 = stream_key(e.seed, e.step_count, split)
         if kind == 2:
-            L.check(lib.cf_ens_kde_prepare(allpos.data_ptr(), e.n_total, e.ndim, half, split_key, self.kde_params.data_ptr(),
-                                           self.kde_wc.data_ptr(), stream))
+            L.check(lib.cf_ens_kde_prepare(allpos.data_ptr(), e.n_total, e.ndim, n_splits, split, split_key,
+                                           self.kde_params.data_ptr(), self.kde_wc.data_ptr(), stream))
         y, logfac = self.y[:n], self.logfac[:n]
-        L.check(lib.cf_ens_propose(kind, allpos.data_ptr(), e.n_total, e.ndim, half, split_key, ids.data_ptr(), n, key0,
+        L.check(lib.cf_ens_propose(kind, allpos.data_ptr(), e.n_total, e.ndim, n_splits, split, split_key, ids.data_ptr(), n, key0,
                                    float(e.a), float(e.de_sigma), self.kde_params.data_ptr(), self.kde_wc.data_ptr(),
                                    y.data_ptr(), logfac.data_ptr(), stream))
         lp_new = e.log_prob_fn(y)
@@ -139,36 +172,33 @@ class NativeMoves:
 class ShardedEnsemble:
     def __init__(self, log_prob_fn: Callable[[torch.Tensor], torch.Tensor], positions: torch.Tensor, *,
                  seed: int = 42, a: float = 2.0, moves=STRETCH_ONLY, de_sigma: float = 1e-5, group=None,
-                 randomize_split: bool = True, moves_impl=None):
+                 randomize_split: bool = True, de_splits: int = 3, moves_impl=None):
         """positions: [W_total, ndim] float64 initial ensemble, identical on every rank (it is sliced here).
         moves: sequence of (name, weight), name in {"stretch", "de", "kde"}; one is drawn per step.
-        randomize_split: re-draw the two halves every step (pair flips); needs shards of whole pairs.
+        randomize_split: re-draw the splits every step (a random permutation per group of walkers); any shard boundaries.
+        de_splits: sets of a DE step: 3 = emcee's DEMove (default), 2 = two halves like the other moves.
         moves_impl: None = the library's kernels (positions must live on a GPU); tests pass the tensor statement."""
         names = set(_KIND)
         if not moves or any(m not in names or w <= 0 for m, w in moves):
             raise ValueError(f"moves must be a non-empty sequence of (name in {sorted(names)}, weight > 0)")
+        if de_splits not in (2, 3):
+            raise ValueError("de_splits must be 3 (emcee's DEMove) or 2")
         tot = float(sum(w for _, w in moves))
         self.moves = [(m, w / tot) for m, w in moves]
-        self.de_sigma = de_sigma
+        self.de_sigma, self.de_splits = de_sigma, de_splits
         self.group = group
         self.distributed = dist is not None and dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.distributed else 1
         self.rank = dist.get_rank(group) if self.distributed else 0
         self.n_total, self.ndim = positions.shape
-        if self.n_total % 2:
-            raise ValueError("the ensemble needs an even number of walkers (two halves)")
+        if self.n_total % 2 or self.n_total < 6:
+            raise ValueError("the ensemble needs an even number (>= 6) of walkers")
         self.start, self.stop = shard_bounds(self.n_total, self.world, self.rank)
         counts = [shard_bounds(self.n_total, self.world, r) for r in range(self.world)]
-        whole_pairs = all(a_ % 2 == 0 and b % 2 == 0 for a_, b in counts)
-        if randomize_split and not whole_pairs:
-            raise ValueError("randomize_split needs every rank's shard to hold whole walker pairs (even shard boundaries); "
-                             "use a walker count divisible by 2 x the number of ranks, or randomize_split=False")
         self.randomize_split = randomize_split
         self.log_prob_fn = log_prob_fn
         self.x = positions[self.start:self.stop].clone().contiguous()
         self.ids = torch.arange(self.start, self.stop, dtype=torch.int64, device=self.x.device)
-        self.local_pairs = (torch.arange(self.start // 2, self.stop // 2, dtype=torch.int64, device=self.x.device)
-                            if whole_pairs else None)
         self.seed, self.a, self.step_count = seed, a, 0
         self.logp = self.log_prob_fn(self.x)
         self._n_accepted = 0
@@ -177,6 +207,9 @@ class ShardedEnsemble:
         self._max_local = max(b - a_ for a_, b in counts)
         self._counts = counts
         self._allpos = None
+        # a backend without device collectives (gloo: rank processes sharing one GPU, CPU rehearsals): the all-gather of
+        # device-resident positions is staged through the host
+        self._host_staged = self.distributed and self.x.is_cuda and "nccl" not in str(dist.get_backend(group)).lower()
         if moves_impl is None:
             if not self.x.is_cuda:
                 raise RuntimeError("ShardedEnsemble runs its moves in the library's HIP kernels: the positions must be on an "
@@ -185,21 +218,36 @@ class ShardedEnsemble:
         self.impl = moves_impl
 
     # ---- the exchange step ---------------------------------------------------------------------------
+    def _all_gather(self, out: torch.Tensor, inp: torch.Tensor) -> torch.Tensor:
+        """dist.all_gather_into_tensor(out, inp); through host copies when the backend has no device collectives."""
+        if self._host_staged:
+            host = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(host, inp.cpu(), group=self.group)
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out, inp, group=self.group)
+        return out
+
+    def _gather_rows(self, local: torch.Tensor) -> torch.Tensor:
+        """Every rank's rows of `local` ([W_local, ...]) in rank order ([W_total, ...]) on every rank."""
+        if self._equal:
+            return self._all_gather(torch.empty((self.n_total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device), local)
+        # ragged shards: pad to the largest shard, gather, strip
+        pad = torch.zeros((self._max_local,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[: local.shape[0]] = local
+        buf = self._all_gather(torch.empty((self.world * self._max_local,) + tuple(local.shape[1:]), dtype=local.dtype,
+                                           device=local.device), pad)
+        return torch.cat([buf[r * self._max_local: r * self._max_local + (b - a_)] for r, (a_, b) in enumerate(self._counts)])
+
     def gather_positions(self) -> torch.Tensor:
         """All walkers' positions [W_total, ndim] on every rank (one collective)."""
         if self.world == 1:
             return self.x
         if self._equal:
-            if self._allpos is None:  # one buffer for the life of the ensemble: the collective runs every half-step
+            if self._allpos is None:  # one buffer for the life of the ensemble: the collective runs every split update
                 self._allpos = torch.empty((self.n_total, self.ndim), dtype=self.x.dtype, device=self.x.device)
-            dist.all_gather_into_tensor(self._allpos, self.x, group=self.group)
-            return self._allpos
-        # ragged shards: pad to the largest shard, gather, strip
-        pad = torch.zeros((self._max_local, self.ndim), dtype=self.x.dtype, device=self.x.device)
-        pad[: self.x.shape[0]] = self.x
-        buf = torch.empty((self.world * self._max_local, self.ndim), dtype=self.x.dtype, device=self.x.device)
-        dist.all_gather_into_tensor(buf, pad, group=self.group)
-        return torch.cat([buf[r * self._max_local: r * self._max_local + (b - a_)] for r, (a_, b) in enumerate(self._counts)])
+            return self._all_gather(self._allpos, self.x)
+        return self._gather_rows(self.x)
 
     def _pick_move(self) -> str:
         u = uniform01_scalar(stream_key(self.seed, self.step_count, 0, _MOVE_STREAM), 0)
@@ -210,14 +258,15 @@ class ShardedEnsemble:
                 return name
         return self.moves[-1][0]
 
-    # ---- one ensemble step = two red/blue half-steps --------------------------------------------------------
+    # ---- one ensemble step = the split updates of the step's move (two halves; three thirds for DE) -------------------
     def step(self):
-        """Per half-step: all-gather -> [KDE fit] -> propose -> log P -> accept; with the library's kernels everything is
+        """Per split: all-gather -> [KDE fit] -> propose -> log P -> accept; with the library's kernels everything is
         asynchronous on the current stream."""
         move = self._pick_move()
+        n_splits = self.de_splits if move == "de" else 2
         split_key = stream_key(self.seed, self.step_count, 0, _SPLIT_STREAM) if self.randomize_split else 0
-        for half in (0, 1):
-            self.impl.half_step(self, move, half, self.gather_positions(), split_key)
+        for split in range(n_splits):
+            self.impl.split_step(self, move, n_splits, split, self.gather_positions(), split_key)
         self.step_count += 1
 
     @property
@@ -235,7 +284,8 @@ class ShardedEnsemble:
         return self
 
     def acceptance_fraction(self) -> float:
-        acc = torch.tensor([self.n_accepted, self.n_proposed], dtype=torch.float64, device=self.x.device)
+        acc = torch.tensor([self.n_accepted, self.n_proposed], dtype=torch.float64,
+                           device="cpu" if self._host_staged else self.x.device)
         if self.world > 1:
             dist.all_reduce(acc, group=self.group)
         return float(acc[0] / torch.clamp(acc[1], min=1.0))
@@ -245,9 +295,4 @@ class ShardedEnsemble:
         pos = self.gather_positions()
         if self.world == 1:
             return pos, self.logp
-        pad = torch.zeros(self._max_local, dtype=self.logp.dtype, device=self.logp.device)
-        pad[: self.logp.shape[0]] = self.logp
-        buf = torch.empty(self.world * self._max_local, dtype=self.logp.dtype, device=self.logp.device)
-        dist.all_gather_into_tensor(buf, pad, group=self.group)
-        lp = torch.cat([buf[r * self._max_local: r * self._max_local + (b - a_)] for r, (a_, b) in enumerate(self._counts)])
-        return pos, lp
+        return pos, self._gather_rows(self.logp)

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 7
+#define CF_ABI_VERSION 8
 
 typedef struct cf_handle cf_handle;
 
@@ -407,28 +407,35 @@ int cf_selftest_log10_tab(const double* x, int64_t n, double* out);
 
 /* ---- Device-resident ensemble moves (the sampler side of sn/pantheon.py:108-125: emcee with KDEMove 30 % +
  * DEMove 70 %, StretchMove by default elsewhere).  All pointers are device pointers on the current device, all
- * calls are asynchronous on `hip_stream`.  The two halves of the ensemble (emcee's RedBlueMove): walker 2c + b belongs to
- * half b ^ flip_c, where flip_c = 0 for split_key = 0 (fixed even / odd halves) and otherwise a counter-based random bit
- * of (split_key, c) -- the halves are re-drawn every step by flipping whole pairs, so each process keeps exactly half of
- * its walkers in each half.  d_all_pos [w_total * ndim] holds every walker's position (after the all-gather of a sharded
+ * calls are asynchronous on `hip_stream`.
+ * Splits (emcee's RedBlueMove: `nsplits` sets updated in turn, each proposing from the union of the others): n_splits = 2 for
+ * the stretch and KDE moves, 3 for the DE move (emcee's DEMove sets nsplits = 3).  Walkers are taken in consecutive groups of
+ * n_splits: walker n_splits c + b belongs to split perm_c[b], where perm_c is the identity for split_key = 0 (fixed classes
+ * index mod n_splits) and otherwise a counter-based random permutation of (split_key, c) -- the splits are re-drawn every step
+ * (emcee shuffles its index array) while every split still holds one member of every group, so every process keeps its fair
+ * share of each split.  d_all_pos [w_total * ndim] holds every walker's position (after the all-gather of a sharded
  * ensemble), d_ids [n_active] the global indices of the active walkers this process owns, and the complementary set of
- * half `half` is the other member of every pair, in pair order.  Random numbers are counter-based: key0 = the 64-bit key
- * of stream 0 for this (seed, step, half) (cosmology-model-fit_amd/ensemble.py: stream_key), so a chain does not depend
- * on how the walkers are sharded over processes.
+ * split `split` is every walker of the other splits in ascending index order.  Random numbers are counter-based: key0 = the
+ * 64-bit key of stream 0 for this (seed, step, split) (cosmology-model-fit_amd/ensemble.py: stream_key), so a chain does not
+ * depend on how the walkers are sharded over processes.
+ *   cf_ens_active_count / cf_ens_comp_count: HOST functions (no device needed): the number of walkers of split `split` in the
+ *     shard [shard_start, shard_stop), and the size of its complementary set in an ensemble of w_total walkers; -1 on bad arguments.
+ *   cf_ens_active_set: the active walkers of split `split` that the shard [shard_start, shard_stop) owns, ascending:
+ *     d_ids [cf_ens_active_count] global indices, d_local_idx = d_ids - shard_start.
  *   cf_ens_kde_prepare: Silverman-bandwidth Gaussian KDE of the complementary set: d_params [2 ndim^2 + 1] =
- *     {chol (lower), inv(chol)^T, log normalisation}, d_wc [w_total / 2 * ndim] = whitened complementary positions.
+ *     {chol (lower), inv(chol)^T, log normalisation}, d_wc [cf_ens_comp_count * ndim] = whitened complementary positions.
  *   cf_ens_propose: kind 0 stretch (scale a), 1 differential evolution (gamma0 = 2.38 / sqrt(2 ndim), jitter de_sigma),
  *     2 KDE independence proposal; d_y [n_active * ndim], d_log_factor [n_active] = log Hastings factor.
  *   cf_ens_accept: accept with probability min(1, exp(log_factor + lp_new - lp_old)) (NaN never accepts); updates
- *     d_x_local / d_logp_local at d_local_idx [n_active] and adds the number of accepted moves to *d_n_accepted.
- *   cf_ens_active_set: the active walkers of half `half` among this process's pairs [pair_begin, pair_begin + n_pairs):
- *     d_ids [n_pairs] = 2c + (half ^ flip_c), d_local_idx [n_pairs] = d_ids - shard_start (shard_start = 2 pair_begin). */
-int cf_ens_active_set(uint64_t split_key, int64_t pair_begin, int64_t n_pairs, int32_t half, int64_t shard_start,
+ *     d_x_local / d_logp_local at d_local_idx [n_active] and adds the number of accepted moves to *d_n_accepted. */
+int64_t cf_ens_active_count(uint64_t split_key, int32_t n_splits, int32_t split, int64_t shard_start, int64_t shard_stop);
+int64_t cf_ens_comp_count(uint64_t split_key, int32_t n_splits, int32_t split, int64_t w_total);
+int cf_ens_active_set(uint64_t split_key, int32_t n_splits, int32_t split, int64_t shard_start, int64_t shard_stop,
                       int64_t* d_ids, int64_t* d_local_idx, void* hip_stream);
-int cf_ens_kde_prepare(const double* d_all_pos, int64_t w_total, int32_t ndim, int32_t half, uint64_t split_key,
-                       double* d_params, double* d_wc, void* hip_stream);
-int cf_ens_propose(int32_t kind, const double* d_all_pos, int64_t w_total, int32_t ndim, int32_t half, uint64_t split_key,
-                   const int64_t* d_ids, int64_t n_active, uint64_t key0, double a, double de_sigma,
+int cf_ens_kde_prepare(const double* d_all_pos, int64_t w_total, int32_t ndim, int32_t n_splits, int32_t split,
+                       uint64_t split_key, double* d_params, double* d_wc, void* hip_stream);
+int cf_ens_propose(int32_t kind, const double* d_all_pos, int64_t w_total, int32_t ndim, int32_t n_splits, int32_t split,
+                   uint64_t split_key, const int64_t* d_ids, int64_t n_active, uint64_t key0, double a, double de_sigma,
                    const double* d_kde_params, const double* d_kde_wc, double* d_y, double* d_log_factor,
                    void* hip_stream);
 int cf_ens_accept(const int64_t* d_ids, const int64_t* d_local_idx, int64_t n_active, int32_t ndim, uint64_t key0,

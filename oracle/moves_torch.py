@@ -11,12 +11,13 @@ TEST INFRASTRUCTURE ONLY, like everything under ``oracle/``: the product's moves
 What is restated (emcee is not installed here, so the pin is the published algorithm + scipy's gaussian_kde):
   stretch move   Goodman & Weare 2010; emcee ``StretchMove(a=2)``: z ~ g(z) ∝ 1/sqrt(z) on [1/a, a], q = c_j + z (x - c_j),
                  log factor (ndim - 1) ln z.
-  DE move        emcee ``DEMove``: q = x + g0 (1 + sigma N(0,1)) (c_j - c_k), j != k, g0 = 2.38 / sqrt(2 ndim), sigma = 1e-5.
+  DE move        emcee ``DEMove``: q = x + g0 (1 + sigma N(0,1)) (c_j - c_k), j != k, g0 = 2.38 / sqrt(2 ndim), sigma = 1e-5;
+                 emcee's DEMove sets ``nsplits = 3``: each third of the ensemble proposes from the other two thirds.
   KDE move       emcee ``KDEMove(bw_method="silverman")``: independence proposal from scipy.stats.gaussian_kde of the
                  complementary set, log factor log kde(x) - log kde(q)          (reference: sn/pantheon.py:114-117).
-  red/blue split two halves updated in turn, each proposing from the other (emcee ``RedBlueMove``); the halves are either the
-                 fixed parity classes of the global walker index or, with a split key, re-drawn every step by flipping
-                 each consecutive pair (2c, 2c + 1) with a counter-based random bit.
+  red/blue split S sets updated in turn, each proposing from the union of the others (emcee ``RedBlueMove``, S = nsplits: 2, or 3
+                 for DE); walker S c + b belongs to split perm_c[b]: the fixed classes index mod S or, with a split key,
+                 re-drawn every step by a counter-based random permutation of every consecutive group of S walkers.
 """
 from __future__ import annotations
 
@@ -59,6 +60,23 @@ def flips_from_key(split_key: int, pairs: torch.Tensor) -> torch.Tensor:
     if split_key == 0:
         return torch.zeros_like(pairs)
     return _lsr(_hash(split_key, pairs), 63)
+
+
+_PERM3 = ((0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0))
+
+
+def split_of(split_key: int, n_splits: int, ids: torch.Tensor) -> torch.Tensor:
+    """Split (0 .. n_splits - 1) of every walker index in `ids`: walker S c + b belongs to perm_c[b] -- the identity for
+    split_key == 0, the pair flip for S = 2, one of the six permutations of a triple (index floor(6 u), u = the top 24 bits
+    of the group's hash) for S = 3.  cosmofit_ensemble.hip: ens_split_of."""
+    c, b = ids // n_splits, ids % n_splits
+    if split_key == 0:
+        return b
+    x = _hash(split_key, c)
+    if n_splits == 2:
+        return b ^ _lsr(x, 63)
+    p = _lsr(_lsr(x, 40) * 6, 24)
+    return torch.tensor(_PERM3, dtype=torch.int64, device=ids.device)[p, b]
 
 
 class TensorMoves:
@@ -118,22 +136,19 @@ class TensorMoves:
         q = comp[j] + noise @ chol.T
         return q, self.kde_logpdf(xa, comp, chol_inv_t, log_norm) - self.kde_logpdf(q, comp, chol_inv_t, log_norm)
 
-    # ---- one red/blue half-step on the driver's state ---------------------------------------------------------------
-    def half_step(self, e, move, half, allpos, split_key):
-        """Active set: this rank's walkers 2c + (half ^ flip_c); complementary set: the walkers 2c + (1 - half) ^ flip_c of
-        every pair, in pair order (the same order the kernels' comp_row uses)."""
-        all_pairs = torch.arange(e.n_total // 2, dtype=torch.int64, device=allpos.device)
-        comp = allpos[2 * all_pairs + ((1 - half) ^ flips_from_key(split_key, all_pairs))]
-        if e.local_pairs is not None:
-            ids = 2 * e.local_pairs + (half ^ flips_from_key(split_key, e.local_pairs))
-        else:  # ragged shards (fixed parity only)
-            ids = e.ids[(e.ids % 2) == half]
+    # ---- the update of one split on the driver's state -----------------------------------------------------------------
+    def split_step(self, e, move, n_splits, split, allpos, split_key):
+        """Active set: this rank's walkers of split `split`, ascending; complementary set: every walker of the other splits,
+        ascending (the order the kernels' comp_row uses)."""
+        all_ids = torch.arange(e.n_total, dtype=torch.int64, device=allpos.device)
+        comp = allpos[split_of(split_key, n_splits, all_ids) != split]
+        ids = e.ids[split_of(split_key, n_splits, e.ids) == split]
         if ids.numel() == 0:
             return
         li = ids - e.start
         propose = {"stretch": self.propose_stretch, "de": self.propose_de, "kde": self.propose_kde}[move]
-        u_acc = self.uniform01(e.seed, e.step_count, half, ids, 2)
-        y, log_factor = propose(e, e.x[li], ids, comp, half)
+        u_acc = self.uniform01(e.seed, e.step_count, split, ids, 2)
+        y, log_factor = propose(e, e.x[li], ids, comp, split)
         lp_new = e.log_prob_fn(y.contiguous())
         accept = torch.log(u_acc) < log_factor + lp_new - e.logp[li]  # NaN never accepts
         idx = li[accept]

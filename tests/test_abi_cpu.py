@@ -173,14 +173,42 @@ def test_ensemble_entry_points_validate_their_arguments(pkg):
     ids = (C.c_int64 * 8)()
     p = lambda a: C.cast(a, C.c_void_p)
     with pytest.raises(pkg.CosmofitError, match="even number"):
-        L.check(lib.cf_ens_kde_prepare(p(buf), 7, 4, 0, 0, p(buf), p(buf), None))
+        L.check(lib.cf_ens_kde_prepare(p(buf), 7, 4, 2, 0, 0, p(buf), p(buf), None))
     with pytest.raises(pkg.CosmofitError, match="ndim"):
-        L.check(lib.cf_ens_propose(0, p(buf), 8, 17, 0, 0, p(ids), 4, 1, 2.0, 1e-5, None, None, p(buf), p(buf), None))
-    with pytest.raises(pkg.CosmofitError, match="half"):
-        L.check(lib.cf_ens_propose(0, p(buf), 8, 4, 2, 0, p(ids), 4, 1, 2.0, 1e-5, None, None, p(buf), p(buf), None))
+        L.check(lib.cf_ens_propose(0, p(buf), 8, 17, 2, 0, 0, p(ids), 4, 1, 2.0, 1e-5, None, None, p(buf), p(buf), None))
+    with pytest.raises(pkg.CosmofitError, match="n_splits"):
+        L.check(lib.cf_ens_propose(0, p(buf), 8, 4, 4, 0, 0, p(ids), 4, 1, 2.0, 1e-5, None, None, p(buf), p(buf), None))
+    with pytest.raises(pkg.CosmofitError, match="split must be"):
+        L.check(lib.cf_ens_propose(0, p(buf), 8, 4, 2, 2, 0, p(ids), 4, 1, 2.0, 1e-5, None, None, p(buf), p(buf), None))
     with pytest.raises(pkg.CosmofitError, match="kind"):
-        L.check(lib.cf_ens_propose(3, p(buf), 8, 4, 0, 0, p(ids), 4, 1, 2.0, 1e-5, None, None, p(buf), p(buf), None))
+        L.check(lib.cf_ens_propose(3, p(buf), 8, 4, 2, 0, 0, p(ids), 4, 1, 2.0, 1e-5, None, None, p(buf), p(buf), None))
     with pytest.raises(pkg.CosmofitError, match="null"):
-        L.check(lib.cf_ens_propose(2, p(buf), 8, 4, 0, 0, p(ids), 4, 1, 2.0, 1e-5, None, None, p(buf), p(buf), None))  # KDE without its fit
+        L.check(lib.cf_ens_propose(2, p(buf), 8, 4, 2, 0, 0, p(ids), 4, 1, 2.0, 1e-5, None, None, p(buf), p(buf), None))  # KDE without its fit
     with pytest.raises(pkg.CosmofitError, match="null"):
         L.check(lib.cf_ens_accept(p(ids), p(ids), 4, 4, 1, p(buf), p(buf), p(buf), p(buf), p(buf), None, None))
+    with pytest.raises(pkg.CosmofitError, match="shard range"):
+        L.check(lib.cf_ens_active_set(5, 3, 1, 10, 4, p(ids), p(ids), None))
+    assert lib.cf_ens_active_count(5, 4, 0, 0, 10) == -1 and lib.cf_ens_comp_count(5, 2, 2, 10) == -1
+
+
+def test_split_counts_of_the_library_match_the_driver_and_the_tensor_statement(pkg):
+    """cf_ens_active_count / cf_ens_comp_count (host functions of the library) == ensemble.active_count (Python ints) == a
+    count over oracle.moves_torch.split_of, for two and three splits, fixed and re-drawn, at shard boundaries that cut groups."""
+    import torch
+    from oracle import moves_torch
+
+    E, lib = pkg.ensemble, pkg.lib()
+    for key in (0, E.stream_key(7, 3, 0, E._SPLIT_STREAM), E.stream_key(8, 1000003, 0, E._SPLIT_STREAM)):
+        for S in (2, 3):
+            for W in (6, 32, 50, 151):
+                ids = torch.arange(W, dtype=torch.int64)
+                sp = moves_torch.split_of(key, S, ids)
+                for c in range((W + S - 1) // S):  # every split holds exactly one member of every whole group
+                    grp = sp[S * c: S * c + S].tolist()
+                    assert sorted(grp) == list(range(S))[: len(grp)] or len(grp) < S
+                    assert tuple(grp) == E.split_perm(key, S, c)[: len(grp)]
+                for s in range(S):
+                    assert lib.cf_ens_comp_count(key, S, s, W) == int((sp != s).sum())
+                    for start, stop in ((0, W), (1, W - 1), (2, 5), (W // 3, 2 * W // 3 + 1), (4, 4), (W - 1, W)):
+                        want = int((sp[start:stop] == s).sum())
+                        assert lib.cf_ens_active_count(key, S, s, start, stop) == want == E.active_count(key, S, s, start, stop)

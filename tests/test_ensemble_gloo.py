@@ -86,10 +86,10 @@ def test_counter_rng_is_a_pure_function_and_uniform():
     assert abs(float(((u - 0.5) * (v - 0.5)).mean())) < 1e-3  # consecutive steps uncorrelated
 
 
-@pytest.mark.parametrize("world,W,randomize", [(2, 64, True), (2, 64, False), (3, 48, True), (3, 50, False)])
+@pytest.mark.parametrize("world,W,randomize", [(2, 64, True), (2, 64, False), (3, 48, True), (3, 50, False), (3, 50, True)])
 def test_chain_is_bit_identical_for_any_number_of_ranks(tmp_path, world, W, randomize):
-    """world_size 2 (equal shards) and 3 (whole-pair shards with the per-step split; ragged shards with the fixed parity
-    halves) reproduce the single-process chain exactly."""
+    """world_size 2 (equal shards) and 3 (equal and ragged shards, also with shard boundaries that cut a walker pair) reproduce
+    the single-process chain exactly, with the fixed classes and with the per-step re-drawn splits."""
     ref = _run(1, W, 25, tmp_path, randomize=randomize)
     got = _run(world, W, 25, tmp_path, randomize=randomize)
     assert torch.equal(ref["pos"], got["pos"])
@@ -108,11 +108,41 @@ def test_stretch_move_samples_the_target(tmp_path):
 REF_MOVES = (("kde", 0.30), ("de", 0.70))  # sn/pantheon.py:114-117
 
 
-def test_reference_move_mixture_is_bit_identical_across_ranks(tmp_path):
-    ref = _run(1, 64, 20, tmp_path, REF_MOVES)
-    got = _run(2, 64, 20, tmp_path, REF_MOVES)
+@pytest.mark.parametrize("world,W", [(2, 64), (3, 50)])
+def test_reference_move_mixture_is_bit_identical_across_ranks(tmp_path, world, W):
+    """KDE on two halves + DE on three thirds (emcee's DEMove: nsplits = 3), shards that cut pairs and triples."""
+    ref = _run(1, W, 20, tmp_path, REF_MOVES)
+    got = _run(world, W, 20, tmp_path, REF_MOVES)
     assert torch.equal(ref["pos"], got["pos"]) and torch.equal(ref["lp"], got["lp"])
     assert ref["acc"] == got["acc"] and 0.05 < ref["acc"] < 0.95
+
+
+def test_de_move_runs_on_three_splits_like_emcee():
+    """emcee's DEMove sets nsplits = 3 (the reference hands it 70 % of the steps, sn/pantheon.py:114-117): a DE step is three
+    split updates of W / 3 walkers each, every proposal built from two walkers of the OTHER two thirds; the other moves use two
+    halves; de_splits=2 is the two-halves variant."""
+    E = load_pkg().ensemble
+    calls = []
+
+    class Spy(moves_torch.TensorMoves):
+        def split_step(self, e, move, n_splits, split, allpos, split_key):
+            all_ids = torch.arange(e.n_total, dtype=torch.int64)
+            sp = moves_torch.split_of(split_key, n_splits, all_ids)
+            calls.append((move, n_splits, split, int((sp == split).sum()), int((sp != split).sum())))
+            return super().split_step(e, move, n_splits, split, allpos, split_key)
+
+    ens = E.ShardedEnsemble(gauss_logp, _init_positions(150), seed=5, moves=(("de", 1.0),), moves_impl=Spy(E.stream_key))
+    ens.run(2)
+    assert calls == [("de", 3, s, 50, 100) for s in (0, 1, 2)] * 2 and ens.n_proposed == 300
+    calls.clear()
+    ens = E.ShardedEnsemble(gauss_logp, _init_positions(32), seed=5, moves=(("de", 1.0),), moves_impl=Spy(E.stream_key))
+    ens.run(1)  # 32 walkers (BASELINE configs[0]): thirds of 10-11, every walker proposed exactly once per step
+    assert [c[:3] for c in calls] == [("de", 3, s) for s in (0, 1, 2)] and sum(c[3] for c in calls) == 32
+    assert all(10 <= c[3] <= 11 and c[3] + c[4] == 32 for c in calls)
+    calls.clear()
+    E.ShardedEnsemble(gauss_logp, _init_positions(32), seed=5, moves=(("kde", 1.0),), moves_impl=Spy(E.stream_key)).run(1)
+    E.ShardedEnsemble(gauss_logp, _init_positions(32), seed=5, moves=(("de", 1.0),), de_splits=2, moves_impl=Spy(E.stream_key)).run(1)
+    assert [c[:5] for c in calls] == [("kde", 2, 0, 16, 16), ("kde", 2, 1, 16, 16), ("de", 2, 0, 16, 16), ("de", 2, 1, 16, 16)]
 
 
 @pytest.mark.parametrize("moves", [(("de", 1.0),), (("kde", 1.0),), REF_MOVES])
@@ -147,7 +177,7 @@ def test_stream_keys_never_collide_across_steps_halves_and_streams():
     keys = {}
     for seed in (41, 42, 43):
         for step in list(range(0, 6)) + [1000003, 1000004]:
-            for half in (0, 1):
+            for half in (0, 1, 2):
                 for s in streams:
                     k = ens.stream_key(seed, step, half, s)
                     assert k not in keys, f"key collision: {(seed, step, half, s)} vs {keys[k]}"
@@ -171,34 +201,35 @@ def test_the_driver_has_no_cpu_fallback():
         load_pkg().ensemble.ShardedEnsemble(gauss_logp, _init_positions(8))
 
 
-def test_randomized_halves_change_every_step_and_stay_balanced():
-    """emcee's RedBlueMove re-draws the halves every step; here whole pairs flip (counter-based bit per pair and step):
-    each half holds exactly one member of every pair, the assignment differs from step to step (the kernels' own hash is
-    checked against this one in tests/test_gpu_parity.py), and odd shard boundaries are refused."""
+def test_randomized_splits_change_every_step_and_stay_balanced():
+    """emcee's RedBlueMove re-draws its sets every step; here every consecutive group of S walkers is permuted (counter-based
+    permutation per group and step): each split holds exactly one member of every group, the assignment differs from step to step
+    (the kernels' own hash is checked against this one in tests/test_gpu_parity.py), all 2 / 6 permutations occur equally often."""
     E = load_pkg().ensemble
-    pairs = torch.arange(0, 4096, dtype=torch.int64)
-    flips = []
-    for step in range(4):
-        key = E.stream_key(7, step, 0, E._SPLIT_STREAM)
-        f = moves_torch.flips_from_key(key, pairs)
-        assert set(f.tolist()) == {0, 1} and abs(float(f.double().mean()) - 0.5) < 0.03
-        flips.append(f)
-    assert not torch.equal(flips[0], flips[1]) and not torch.equal(flips[1], flips[2])
-    assert torch.equal(moves_torch.flips_from_key(0, pairs), torch.zeros_like(pairs))
+    ids = torch.arange(0, 6 * 4096, dtype=torch.int64)
+    for S in (2, 3):
+        seen = []
+        for step in range(4):
+            key = E.stream_key(7, step, 0, E._SPLIT_STREAM)
+            sp = moves_torch.split_of(key, S, ids).reshape(-1, S)
+            assert torch.equal(sp.sort(dim=1).values, torch.arange(S).expand_as(sp))
+            code = (sp * torch.tensor([S ** k for k in range(S)])).sum(dim=1)
+            freq = torch.bincount(code).double()
+            freq = freq[freq > 0] / code.numel()
+            assert freq.numel() == (2 if S == 2 else 6) and float((freq - 1.0 / freq.numel()).abs().max()) < 0.015
+            seen.append(sp)
+        assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+        assert torch.equal(moves_torch.split_of(0, S, ids), ids % S)
+    pairs = torch.arange(0, 4096, dtype=torch.int64)  # S = 2 is the pair flip of rounds 1-2 (chains of those rounds unchanged)
+    key = E.stream_key(7, 1, 0, E._SPLIT_STREAM)
+    assert torch.equal(moves_torch.split_of(key, 2, 2 * pairs), moves_torch.flips_from_key(key, pairs))
 
 
-def _ragged_worker(rank, world, port):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        load_pkg().ensemble.ShardedEnsemble(gauss_logp, _init_positions(50), moves_impl=_tensor_moves(), randomize_split=True)
-        ok = False
-    except ValueError as e:
-        ok = "whole walker pairs" in str(e)
-    assert ok
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def test_randomize_split_refuses_shards_that_cut_a_pair():
-    mp.spawn(_ragged_worker, args=(3, _free_port()), nprocs=3, join=True)
+def test_odd_and_tiny_ensembles_are_refused():
+    E = load_pkg().ensemble
+    with pytest.raises(ValueError, match="even number"):
+        E.ShardedEnsemble(gauss_logp, _init_positions(9), moves_impl=_tensor_moves())
+    with pytest.raises(ValueError, match="even number"):
+        E.ShardedEnsemble(gauss_logp, _init_positions(4), moves_impl=_tensor_moves())
+    with pytest.raises(ValueError, match="de_splits"):
+        E.ShardedEnsemble(gauss_logp, _init_positions(8), moves_impl=_tensor_moves(), de_splits=4)

@@ -271,9 +271,11 @@ def test_device_ensemble_stretch_move_matches_oracle_driven_chain(gpu):
 @pytest.mark.parametrize("ndim,n_total", [(4, 512), (6, 130), (1, 64)])
 @pytest.mark.parametrize("randomize", [False, True])
 def test_native_ensemble_moves_match_the_tensor_statement(gpu, ndim, n_total, randomize):
-    """cf_ens_kde_prepare / cf_ens_propose / cf_ens_accept against oracle/moves_torch.py's tensor statement of the same moves
-    (same counter-based random numbers): proposals, Hastings factors, KDE fit, accept decisions -- with the fixed parity
-    halves and with the per-step pair flips."""
+    """cf_ens_active_set / cf_ens_kde_prepare / cf_ens_propose / cf_ens_accept against oracle/moves_torch.py's tensor statement of
+    the same moves (same counter-based random numbers): active sets, proposals, Hastings factors, KDE fit, accept decisions --
+    for two and three splits, with the fixed classes and the per-step re-drawn splits, and for SHARDS that do not start at
+    walker 0 (shard_start != 0, boundaries that cut pairs and triples): the local index of a walker is its global index less the
+    shard start, which is what a rank r > 0 of the sharded ensemble hands to the kernels."""
     torch = pytest.importorskip("torch")
     from oracle import moves_torch
 
@@ -286,49 +288,62 @@ def test_native_ensemble_moves_match_the_tensor_statement(gpu, ndim, n_total, ra
     assert isinstance(ens.impl, E.NativeMoves)
     tm = moves_torch.TensorMoves(E.stream_key)
     lib, L, stream = gpu.lib(), gpu._lib, torch.cuda.current_stream(dev).cuda_stream
-    pairs = torch.arange(n_total // 2, dtype=torch.int64, device=dev)
+    all_ids = torch.arange(n_total, dtype=torch.int64, device=dev)
     kde_params = torch.empty(2 * ndim * ndim + 1, dtype=torch.float64, device=dev)
-    kde_wc = torch.empty((n_total // 2, ndim), dtype=torch.float64, device=dev)
+    kde_wc = torch.empty((n_total, ndim), dtype=torch.float64, device=dev)
+    lp_all = f(pos)
+    shards = [(0, n_total), (n_total // 3 + 1, 2 * n_total // 3), (n_total - 7, n_total), (5, 6)]
     for step in (0, 5):
         ens.step_count = step
         split_key = E.stream_key(ens.seed, step, 0, E._SPLIT_STREAM) if randomize else 0
-        flips = moves_torch.flips_from_key(split_key, pairs)
-        if randomize:
-            assert 0 < int(flips.sum()) < n_total // 2
-        for half in (0, 1):
-            ids = (2 * pairs + (half ^ flips)).contiguous()
-            idx = ids.clone()  # one rank: local index = global index
-            if randomize:  # the library's own active set (cf_ens_active_set) = the oracle's pair flips
-                k_ids, k_idx = torch.empty_like(ids), torch.empty_like(ids)
-                L.check(lib.cf_ens_active_set(split_key, 0, n_total // 2, half, 0, k_ids.data_ptr(), k_idx.data_ptr(), stream))
-                torch.cuda.synchronize()
-                assert torch.equal(k_ids, ids) and torch.equal(k_idx, idx)
-            comp = pos[2 * pairs + ((1 - half) ^ flips)]
-            n, key0 = int(ids.numel()), E.stream_key(ens.seed, step, half)
-            for kind, name in enumerate(("stretch", "de", "kde")):
-                want_y, want_lf = getattr(tm, "propose_" + name)(ens, pos[ids], ids, comp, half)
-                if kind == 2:
-                    L.check(lib.cf_ens_kde_prepare(pos.data_ptr(), n_total, ndim, half, split_key, kde_params.data_ptr(),
-                                                   kde_wc.data_ptr(), stream))
-                y, lf = torch.empty((n, ndim), dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev)
-                L.check(lib.cf_ens_propose(kind, pos.data_ptr(), n_total, ndim, half, split_key, ids.data_ptr(), n, key0, ens.a,
-                                           ens.de_sigma, kde_params.data_ptr(), kde_wc.data_ptr(), y.data_ptr(), lf.data_ptr(), stream))
-                torch.cuda.synchronize()
-                np.testing.assert_allclose(y.cpu().numpy(), want_y.cpu().numpy(), rtol=1e-11, atol=1e-12, err_msg=name)
-                np.testing.assert_allclose(lf.cpu().numpy(), want_lf.cpu().numpy(), rtol=1e-9, atol=1e-9, err_msg=name)
-                # accept: same decisions as log(u) < log_factor + lp_new - lp_old, counted on the device
-                x_loc, lp_loc = ens.x.clone(), ens.logp.clone()
-                lp_new = f(y)
-                u = tm.uniform01(ens.seed, step, half, ids, 2)
-                want_acc = torch.log(u) < (lf + lp_new - lp_loc[idx])
-                count = torch.zeros(1, dtype=torch.int64, device=dev)
-                L.check(lib.cf_ens_accept(ids.data_ptr(), idx.data_ptr(), n, ndim, key0, y.data_ptr(), lp_new.data_ptr(),
-                                          lf.data_ptr(), x_loc.data_ptr(), lp_loc.data_ptr(), count.data_ptr(), stream))
-                torch.cuda.synchronize()
-                assert int(count.item()) == int(want_acc.sum())
-                exp_x = ens.x.clone()
-                exp_x[idx[want_acc]] = y[want_acc]
-                assert torch.equal(x_loc, exp_x)
+        for S in (2, 3):
+            sp = moves_torch.split_of(split_key, S, all_ids)
+            if randomize:
+                assert not torch.equal(sp, all_ids % S)
+            for split in range(S):
+                comp = pos[sp != split]
+                assert lib.cf_ens_comp_count(split_key, S, split, n_total) == comp.shape[0]
+                key0 = E.stream_key(ens.seed, step, split)
+                for start, stop in shards:
+                    ids = all_ids[start:stop][sp[start:stop] == split].contiguous()
+                    idx = ids - start
+                    n = int(ids.numel())
+                    assert lib.cf_ens_active_count(split_key, S, split, start, stop) == n == E.active_count(split_key, S, split, start, stop)
+                    # the library's own active set, sentinel-filled buffers one entry longer than the count
+                    k_ids = torch.full((n + 1,), -7, dtype=torch.int64, device=dev)
+                    k_idx = torch.full((n + 1,), -7, dtype=torch.int64, device=dev)
+                    L.check(lib.cf_ens_active_set(split_key, S, split, start, stop, k_ids.data_ptr(), k_idx.data_ptr(), stream))
+                    torch.cuda.synchronize()
+                    assert torch.equal(k_ids[:n], ids) and torch.equal(k_idx[:n], idx) and int(k_ids[n]) == -7 and int(k_idx[n]) == -7
+                    if n == 0:
+                        continue
+                    x_shard, lp_shard = pos[start:stop].clone(), lp_all[start:stop].clone()
+                    for kind, name in enumerate(("stretch", "de", "kde")):
+                        want_y, want_lf = getattr(tm, "propose_" + name)(ens, pos[ids], ids, comp, split)
+                        if kind == 2:
+                            L.check(lib.cf_ens_kde_prepare(pos.data_ptr(), n_total, ndim, S, split, split_key, kde_params.data_ptr(),
+                                                           kde_wc.data_ptr(), stream))
+                        y, lf = torch.empty((n, ndim), dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev)
+                        L.check(lib.cf_ens_propose(kind, pos.data_ptr(), n_total, ndim, S, split, split_key, k_ids.data_ptr(), n, key0,
+                                                   ens.a, ens.de_sigma, kde_params.data_ptr(), kde_wc.data_ptr(), y.data_ptr(),
+                                                   lf.data_ptr(), stream))
+                        torch.cuda.synchronize()
+                        np.testing.assert_allclose(y.cpu().numpy(), want_y.cpu().numpy(), rtol=1e-11, atol=1e-12, err_msg=name)
+                        np.testing.assert_allclose(lf.cpu().numpy(), want_lf.cpu().numpy(), rtol=1e-9, atol=1e-9, err_msg=name)
+                        # accept on the SHARD's arrays (local indices): same decisions as log(u) < log_factor + lp_new - lp_old
+                        x_loc, lp_loc = x_shard.clone(), lp_shard.clone()
+                        lp_new = f(y)
+                        u = tm.uniform01(ens.seed, step, split, ids, 2)
+                        want_acc = torch.log(u) < (lf + lp_new - lp_shard[idx])
+                        count = torch.zeros(1, dtype=torch.int64, device=dev)
+                        L.check(lib.cf_ens_accept(k_ids.data_ptr(), k_idx.data_ptr(), n, ndim, key0, y.data_ptr(), lp_new.data_ptr(),
+                                                  lf.data_ptr(), x_loc.data_ptr(), lp_loc.data_ptr(), count.data_ptr(), stream))
+                        torch.cuda.synchronize()
+                        assert int(count.item()) == int(want_acc.sum())
+                        exp_x, exp_lp = x_shard.clone(), lp_shard.clone()
+                        exp_x[idx[want_acc]] = y[want_acc]
+                        exp_lp[idx[want_acc]] = lp_new[want_acc]
+                        assert torch.equal(x_loc, exp_x) and torch.equal(lp_loc, exp_lp)
     # whole steps of the driver: the kernels' chain == the tensor statement's chain on the same target
     e_native = E.ShardedEnsemble(f, pos.clone(), seed=4, moves=E.REFERENCE_MOVES, randomize_split=randomize)
     e_tensor = E.ShardedEnsemble(f, pos.clone(), seed=4, moves=E.REFERENCE_MOVES, randomize_split=randomize, moves_impl=tm)
