@@ -34,11 +34,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix (= vector) datasheet peak: 256 CU x 4 SIMD x 2048 flop / 64 clk x 2.4 GHz
-# What v_mfma_f64_16x16x4_f64 sustains on this chip with every SIMD issuing nothing but independent MFMAs from
-# registers, 4 waves per SIMD (tools/coexec_f64_rate.hip, profiles/r01_coexec_f64_rate.txt): the pipe takes one per
-# 64 cycles and the chip then holds 2.15-2.2 GHz: 66.5 TFLOP/s on one device of the pool, 70.9 on another.  A kernel that also moves data holds a lower clock.
-FP64_MFMA_MEASURED_TFLOPS = 67.0
-
 
 def flops_per_eval_solve(n):
     """Algorithmic FP64 flops of the chi^2 phase per walker: TRSV n(n-1) + n divisions + 2n norm."""
@@ -154,7 +149,7 @@ def main():
             box += [(-3.0, 1.0), (-3.0, 2.0)]  # w0, wa: bao/desi_fs_lya_cmb.py:135-136
         box = np.array(box)
         args.n_sn, ndim, kind = int(g["z_cmb"].size), len(box), pkg.CF_OUT_LOGL
-        args.no_cpu_baseline = True
+        syn = dict(g=g, chol=chol)
     elif args.workload == "desi_des5y_bbn_theta_star":
         g = np.load(os.path.join(ROOT, "tests", "golden", "bao_desi_des5y_bbn_theta_star.npz"))
         rng = np.random.default_rng(0)
@@ -164,7 +159,7 @@ def main():
                                                    g["bao_inv_cov"], chol=chol, device=local_rank)
         box = g["bounds"]  # bao/desi_des5y_bbn_theta_star.py:122-130
         args.n_sn, ndim, kind = int(g["z_cmb"].size), 5, pkg.CF_OUT_LOGP
-        args.no_cpu_baseline = True
+        syn = dict(g=g, chol=chol)
     else:
         syn = pkg.synthetic.pantheon_like(n_sn=args.n_sn, seed=0)
         lk = sn.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"], device=local_rank, **solve_kw)
@@ -223,7 +218,7 @@ def main():
     stride = max(1, min(8, args.steps // 5))
     eng.enable_timing(min(args.steps + args.warmup, 4096), stride)
     dt = timed_pass()
-    kms = eng.kernel_ms()
+    kms = eng.kernel_ms3()
     n_warm_samples = (args.warmup + stride - 1) // stride  # samples that fell into the W warm-up steps
     kms = kms[n_warm_samples:] or kms
     eng.enable_timing(0)
@@ -248,16 +243,19 @@ def main():
 
     if rank == 0:
         solve_kernel = "tri_gemm_chi2_kernel" if eng.info()["solve_mode"] == pkg.CF_SOLVE_INVERSE_GEMM else "trsm_chi2_kernel"
-        resid_ms = float(np.mean([a for a, _ in kms]))
-        solve_ms = float(np.mean([b for _, b in kms]))
+        walker_ms = float(np.mean([k[0] for k in kms]))
+        blocks_ms = float(np.mean([k[1] for k in kms]))
+        solve_ms = float(np.mean([k[2] for k in kms]))
         solve_flops = flops_per_eval_solve(args.n_sn) * Wl
         achieved = solve_flops / (solve_ms * 1e-3) / 1e12
         traffic, traffic_source = pmc_traffic(args.workload if args.fde == "lcdm" else f"{args.workload}:{args.fde}", args.n_sn, Wl,
                                               solve_kernel)
         out = {
-            "metric": {"pantheon": "walker-logL evals/s, Pantheon+ 1701-SN full-cov chi2",
-                       "desi_cmb_des5y": "walker-logL evals/s, DESI BAO + Planck/ACT CMB + DES-SN joint chi2 (config 3 shape)",
-                       "desi_des5y_bbn_theta_star": "walker-logL evals/s, DESI BAO + l_A + BBN + DES-SN joint log P (config 5 shape)",
+            # `value`: theta already resident in HBM when the timed region starts (the bench contract); the same metric as
+            # SURVEY 8(d) words it -- host buffers in and out, PCIe and the synchronisation included -- is `value_host_visible`
+            "metric": {"pantheon": "walker-logL evals/s, Pantheon+ 1701-SN full-cov chi2, theta resident in HBM",
+                       "desi_cmb_des5y": "walker-logL evals/s, DESI BAO + Planck/ACT CMB + DES-SN joint chi2 (config 3 shape), theta resident in HBM",
+                       "desi_des5y_bbn_theta_star": "walker-logL evals/s, DESI BAO + l_A + BBN + DES-SN joint log P (config 5 shape), theta resident in HBM",
                        }[args.workload],
             "value": W_total * args.steps / dt,
             "unit": "evals/s",
@@ -269,7 +267,8 @@ def main():
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" if args.workload == "pantheon" else
+                    "fixture redshifts / magnitudes / BAO data (tests/golden) + seeded synthetic SN covariance, synthetic walkers",
             "config": {
                 "workload": (f"Pantheon+-shaped {args.n_sn}-SN full-cov flat-LCDM chi2 + prior, "
                              f"{Wl} walkers per GPU per step (BASELINE configs[1] at N=1), G=4000, theta resident in HBM")
@@ -301,10 +300,9 @@ def main():
                 "traffic_source": traffic_source,
                 "flops_per_launch": solve_flops,
                 "avg_kernel_ms": solve_ms,
-                "measured_mfma_f64_ceiling": FP64_MFMA_MEASURED_TFLOPS,
-                "frac_of_measured_ceiling": achieved / FP64_MFMA_MEASURED_TFLOPS,
             },
-            "kernels_ms": {"walker_kernel": resid_ms, solve_kernel: solve_ms},
+            "kernels_ms": {"walker_kernel": walker_ms, "small_blocks_kernel": blocks_ms if (args.workload != "pantheon") else None,
+                           solve_kernel: solve_ms},
             "kernel_timing": f"HIP events on the launch stream, every {stride}th of the {args.steps} timed steps ({len(kms)} samples)",
             "preconditioning": {"untimed_evaluations_before_warmup": n_pre, "ms": args.precondition_ms},
             "from_idle": None if dt_idle is None else {
@@ -334,11 +332,12 @@ def main():
             # SURVEY 8(d)'s own wording of the metric: wall-clock, host-visible, H2D of theta and D2H of the results
             # included -- first-class beside `value` (which is theta-resident, as the bench contract asks)
             out["value_host_visible"] = Wl * reps / (time.perf_counter() - t0)
-            out["host_visible"] = {"metric": out["metric"] + ", host numpy buffers through cf_eval (H2D + kernels + D2H + sync)",
+            out["host_visible"] = {"metric": "walker-logL evals/s, Pantheon+ 1701-SN full-cov chi2, host numpy buffers through cf_eval "
+                                             "(H2D + kernels + D2H + sync: SURVEY 8d's wording of the metric)",
                                    "value": out["value_host_visible"], "unit": "evals/s", "calls": reps}
             assert np.array_equal(host_res, result)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg, syn, lk, theta_all_host, result, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(pkg, args, syn, lk, box, kind, theta_all_host, result, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
     if use_dist:
@@ -394,43 +393,66 @@ def pmc_traffic(workload, n_sn, walkers, kernel):
     return None, None
 
 
-def cpu_baseline(pkg, syn, lk, theta, gpu_logp, budget_s):
+def oracle_likelihood(pkg, args, syn, lk, box):
+    """The oracle's statement (oracle/oracle_np.Likelihood, evaluated by the C restatement) of the likelihood being timed."""
+    from oracle import oracle_np as onp
+
+    if args.workload == "pantheon":
+        sn = pkg.sn_pantheon
+        return onp.Likelihood(ndim=4, z_max=lk.z_max, offset=onp.Slot(0), H0=onp.Slot(1), Om=onp.Slot(2), v=onp.Slot(3),
+                              z_cmb=syn["z_cmb"], z_hel=syn["z_hel"], obs=syn["obs"], chol=syn["chol"], bounds=sn.bounds,
+                              gauss=[sn.H0_PRIOR])
+    g, chol, d = syn["g"], syn["chol"], pkg.cmb_data.PLANCK_ACT
+    phys = {k: d[k] for k in ("or_h2", "omnu_h2", "o_gamma_h2", "nu_m0", "nu_rho0", "nu_qs_sq", "nu_ws")}
+    common = dict(z_max=lk.z_max, ez_model=onp.EZ_PHYSICAL, offset=onp.Slot(0), H0=onp.Slot(1), obh2=onp.Slot(2), och2=onp.Slot(3),
+                  z_cmb=g["z_cmb"], z_hel=g["z_hel"], obs=g["obs"], chol=chol, bao_z=g["bao_z"], bao_val=g["bao_val"],
+                  bao_qty=g["bao_qty"], bao_inv_cov=g["bao_inv_cov"], rd_fit=d["rd_fit"], cmb_prior=d["cmb_prior"],
+                  zstar_fit=d["zstar_fit"], **phys)
+    if args.workload == "desi_cmb_des5y":  # bao/desi_cmb_des5y.py:26-141 (tests/test_oracle_golden.py, test_variants.py)
+        extra = dict(w0=onp.Slot(5), wa=onp.Slot(6)) if args.fde == "cpl" else {}
+        return onp.Likelihood(ndim=len(box), fde=onp.FDE_CPL if args.fde == "cpl" else onp.FDE_LCDM, v=onp.Slot(4), z_turn=0.10563,
+                              cmb_mode=1, cmb_inv_cov=d["cmb_inv_cov"], **extra, **common)
+    inv = np.zeros((3, 3))  # bao/desi_des5y_bbn_theta_star.py:104-130: the l_A term alone, BBN prior, thawing dark energy
+    inv[1, 1] = 1.0 / d["cmb_cov"][1, 1]
+    return onp.Likelihood(ndim=5, fde=onp.FDE_THAWING, w0=onp.Slot(4), has_vstep=False, bao_dh_exact=True, cmb_mode=2,
+                          cmb_inv_cov=inv, bounds=g["bounds"], gauss=[(2, float(g["bbn"][0]), float(g["bbn"][1]))], **common)
+
+
+def cpu_baseline(pkg, args, syn, lk, box, kind, theta, gpu_out, budget_s):
     """The C restatement of the reference algorithm (oracle/, kind 'port') timed on this host's cores on a
     bounded sample of the same walkers; also reports the GPU-vs-CPU parity on that sample."""
-    from oracle import oracle_c, oracle_np as onp
+    from oracle import oracle_c
 
-    sn = pkg.sn_pantheon
-    co = oracle_c.COracle(onp.Likelihood(
-        ndim=4, z_max=lk.z_max, offset=onp.Slot(0), H0=onp.Slot(1), Om=onp.Slot(2), v=onp.Slot(3),
-        z_cmb=syn["z_cmb"], z_hel=syn["z_hel"], obs=syn["obs"], chol=syn["chol"],
-        bounds=sn.bounds, gauss=[sn.H0_PRIOR]))
-    nthreads = min(oracle_c.max_threads(), len(os.sched_getaffinity(0)))
+    co = oracle_c.COracle(oracle_likelihood(pkg, args, syn, lk, box))
+    usable = len(os.sched_getaffinity(0))
+    nthreads = usable  # every core this process may run on, set explicitly (the OpenMP default used half of a 256-thread box)
     # single-thread rate first (also sizes the sample)
     n1 = min(256, len(theta))
     t0 = time.perf_counter()
-    co.logp(theta[:n1], nthreads=1)
+    co.eval(theta[:n1], kind, nthreads=1)
     dt1 = time.perf_counter() - t0
     rate1 = n1 / dt1
     # bounded sample: about `budget_s` CPU-seconds of work in total (wall time = that / threads).
     # The first len(theta) walkers ARE the GPU batch (same generator stream), the rest are more draws
     # from the same prior box.
     n = int(min(65536, max(len(theta), rate1 * budget_s)))
-    sample = pkg.synthetic.walkers(sn.bounds, n, seed=0)
+    sample = pkg.synthetic.walkers(box, n, seed=0)
     m = len(theta)
     assert np.array_equal(sample[:m], theta)
-    co.logp(sample[:4 * nthreads], nthreads=nthreads)  # spin the thread pool up
+    co.eval(sample[:4 * nthreads], kind, nthreads=nthreads)  # spin the thread pool up
     t0 = time.perf_counter()
-    ref = co.logp(sample, nthreads=nthreads)
+    ref = co.eval(sample, kind, nthreads=nthreads)
     dt = time.perf_counter() - t0
     cores = co.threads_used
-    rel = float(np.max(np.abs(gpu_logp[:m] - ref[:m]) / np.abs(ref[:m])))
+    rel = float(np.max(np.abs(gpu_out[:m] - ref[:m]) / np.abs(ref[:m])))
     return {
         "value": n / dt, "unit": "evals/s", "cores": cores, "kind": "port",
         "sample": f"{n} walkers from the same prior box (the first {m} are the timed GPU batch), C restatement "
-                  f"oracle/cosmofit_oracle.c (-O2, no fast-math, OpenMP over walkers), ~{n / rate1:.0f} CPU-seconds of work; "
-                  f"single-thread: {n1 / dt1:.1f} evals/s on {n1} walkers",
+                  f"oracle/cosmofit_oracle.c (-O2, no fast-math, OpenMP over walkers, {cores} threads = every usable core), "
+                  f"~{n / rate1:.0f} CPU-seconds of work; single-thread: {n1 / dt1:.1f} evals/s on {n1} walkers",
         "single_thread_value": n1 / dt1,
-        "parity_max_rel_logp": rel,
+        "parity_max_rel": rel,
+        "parity_quantity": {0: "chi2", 1: "log L", 2: "log P"}[int(kind)],
         "host": host_cpu(),
     }
 

@@ -115,12 +115,14 @@ EXPORTS = {
     "cf_set_timing_stride": (C.c_int, [_VP, C.c_int]),
     "cf_timed_calls": (C.c_int64, [_VP]),
     "cf_kernel_ms": (C.c_int, [_VP, _I64, C.POINTER(C.c_float * 2)]),
+    "cf_kernel_ms3": (C.c_int, [_VP, _I64, C.POINTER(C.c_float * 3)]),
     "cf_interp_hermite": (C.c_int, [_VP, _I64, _VP, _VP, _VP, _I64, _VP]),
     "cf_interp_pchip": (C.c_int, [_VP, _I64, _VP, _VP, _I64, _VP]),
     "cf_solve_triangular": (C.c_int, [_VP, _I64, _I64, _VP, _I64, _VP]),
     "cf_selftest_invpack_host": (C.c_int, [_VP, _I64, _I64, _VP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "cf_selftest_log10": (C.c_int, [_VP, _I64, _VP]),
     "cf_selftest_log10_tab": (C.c_int, [_VP, _I64, _VP]),
+    "cf_selftest_exp_tab": (C.c_int, [_VP, _I64, _VP]),
     "cf_ens_active_count": (_I64, [C.c_uint64, _I32, _I32, _I64, _I64]),
     "cf_ens_comp_count": (_I64, [C.c_uint64, _I32, _I32, _I64]),
     "cf_ens_active_set": (C.c_int, [C.c_uint64, _I32, _I32, _I64, _I64, _VP, _VP, _VP]),

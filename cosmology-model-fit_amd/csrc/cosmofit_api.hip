@@ -34,6 +34,8 @@ template <int MODEL, int FDE>
 __global__ void walker_kernel(cf_dev_desc d, const double* theta, int64_t W, double* delta, double* dm_out, double* mucorr_out,
                               d2* bao_nodes, d2* table_out);
 template <int MODEL, int FDE>
+__global__ void walker_fast_kernel(cf_walker_args d, const double* theta, int64_t W, double* delta, d2* bao_nodes);
+template <int MODEL, int FDE>
 __global__ void small_blocks_kernel(cf_dev_desc d, const double* theta, int64_t W, const d2* bao_nodes, double* chi2_extra,
                                     double* blocks_out, double* bao_out);
 template <int MODEL, int FDE, int C>
@@ -45,6 +47,7 @@ __global__ void hz_kernel(cf_dev_desc d, const double* theta, const double* z, i
   extern template __global__ void growth_kernel<M, F, C>(cf_dev_desc, const double*, int64_t, const d2*, double*, int, double*, double*);
 #define CF_DECLARE_WALKER(M, F)                                                                                            \
   extern template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*, d2*); \
+  extern template __global__ void walker_fast_kernel<M, F>(cf_walker_args, const double*, int64_t, double*, d2*);         \
   extern template __global__ void small_blocks_kernel<M, F>(cf_dev_desc, const double*, int64_t, const d2*, double*,       \
                                                             double*, double*);                                            \
   extern template __global__ void hz_kernel<M, F>(cf_dev_desc, const double*, const double*, int64_t, double*);             \
@@ -58,6 +61,32 @@ static walker_fn pick_walker(int model, int fde) {
       {walker_kernel<0, 0>, walker_kernel<0, 1>, walker_kernel<0, 2>, walker_kernel<0, 3>},
       {walker_kernel<1, 0>, walker_kernel<1, 1>, walker_kernel<1, 2>, walker_kernel<1, 3>}};
   return table[model][fde];
+}
+typedef void (*walker_fast_fn)(cf_walker_args, const double*, int64_t, double*, d2*);
+static walker_fast_fn pick_walker_fast(int model, int fde) {
+  static const walker_fast_fn table[2][4] = {
+      {walker_fast_kernel<0, 0>, walker_fast_kernel<0, 1>, walker_fast_kernel<0, 2>, walker_fast_kernel<0, 3>},
+      {walker_fast_kernel<1, 0>, walker_fast_kernel<1, 1>, walker_fast_kernel<1, 2>, walker_fast_kernel<1, 3>}};
+  return table[model][fde];
+}
+// The lean kernel arguments of the production per-walker kernel, and whether this descriptor may take it: register path of the
+// table build (<= 4096 grid nodes), an SN block that fits sn_fast_loop.  CF_WALKER_GENERIC=1 forces the generic kernel (A/B).
+static bool walker_fast_ok(const cf_dev_desc& d) {
+  static const bool off = [] { const char* e = getenv("CF_WALKER_GENERIC"); return e && atoi(e) != 0; }();
+  return !off && d.chunk_shift == 3 && d.ndim <= 64 && !d.sn_fixed_mu && !d.sn_dir && !d.sn_vel_mult && (!d.sn_lin || d.lin_in_rec);
+}
+static cf_walker_args walker_args_of(const cf_dev_desc& d) {
+  cf_walker_args a{};
+  a.ndim = d.ndim; a.n_grid = d.n_grid; a.ez_model = d.ez_model; a.fde = d.fde;
+  a.chunk_shift = d.chunk_shift; a.om_mode = d.om_mode;
+  a.n_sn = d.n_sn; a.n_ld = d.n_ld;
+  a.has_vstep = d.has_vstep; a.step_pm1 = d.step_pm1; a.lin_in_rec = d.lin_in_rec; a.n_aux = d.n_aux;
+  a.z_max = d.z_max; a.step = d.step; a.c = d.c; a.inv_step = d.inv_step; a.inv_last = d.inv_last;
+  a.or_h2 = d.or_h2; a.omnu_h2 = d.omnu_h2;
+  for (int k = 0; k < CF_N_SLOTS; ++k) a.slot[k] = d.slot[k];
+  a.sn_rec = d.sn_rec; a.log10_tab = d.log10_tab; a.nu_sw = d.nu_sw; a.ln_sw = d.ln_sw; a.exp2_tab = d.exp2_tab;
+  a.bao_base = d.bao_base;
+  return a;
 }
 typedef void (*small_blocks_fn)(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, double*);
 static small_blocks_fn pick_small_blocks(int model, int fde) {
@@ -97,6 +126,17 @@ __global__ void tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const dou
                                      int64_t w_pad, double* partial, unsigned int* arrivals, const double* chi2_extra,
                                      double* out, int out_kind, unsigned long long* nonfinite, double* chi2_sn_out,
                                      int panels_per_group);
+template <int PF>
+__global__ void tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* theta, int64_t W, const double* delta,
+                                      double* partial4, unsigned int* arrivals, const double* chi2_extra, double* out, int out_kind,
+                                      unsigned long long* nonfinite, double* chi2_sn_out, int units_pad);
+#define CF_DECLARE_TRIGEMM_SMALL(PF)                                                                                             \
+  extern template __global__ void tri_gemm_small_kernel<PF>(cf_dev_desc, cf_dev_invpack, const double*, int64_t, const double*,   \
+                                                            double*, unsigned int*, const double*, double*, int, unsigned long long*, \
+                                                            double*, int);
+CF_DECLARE_TRIGEMM_SMALL(4)
+CF_DECLARE_TRIGEMM_SMALL(8)
+CF_DECLARE_TRIGEMM_SMALL(16)
 #define CF_DECLARE_TRIGEMM(NP, PF)                                                                                       \
   extern template __global__ void tri_gemm_chi2_kernel<NP, PF>(cf_dev_desc, cf_dev_invpack, const double*, int64_t,     \
                                                                const double*, int64_t, double*, unsigned int*,          \
@@ -244,6 +284,11 @@ struct PinnedBuf {
 #ifndef CF_ZEROCOPY_DEFAULT
 #define CF_ZEROCOPY_DEFAULT 16384
 #endif
+#define CF_SMALL_MAX_PANELS 16  // largest batch of the small-batch solve kernel: 256 walkers (the default switch is lower)
+#ifndef CF_SMALL_DEFAULT
+#define CF_SMALL_DEFAULT 48  // walkers: batches up to this size take the small-batch solve kernel (faster up to 32-48 walkers, even at 64,
+                             // slower beyond: profiles/r03_small_batch_solve.txt)
+#endif
 #define CF_MAX_CHUNKS 8  // sub-batches of one evaluation (walker kernel of chunk c + 1 beside the solve of chunk c)
 
 // A host thread that evaluates one replica's slice of a multi-device cf_eval (one per replica beyond the first).
@@ -265,23 +310,23 @@ struct cf_handle {
   PinnedBuf stage_in, stage_out;
   InversePack ipack;
   DevBuf partial, arrivals;  // inverse-GEMM solve: chi^2 shares per (row block, walker); arrival counters per panel
+  DevBuf partial4;           // small-batch solve: shares per (panel, row block, tile, walker), CF_SMALL_MAX_PANELS panels
   hipStream_t stream = nullptr;  // host-buffer evaluations (cf_eval, cf_eval_parts)
   hipStream_t aux = nullptr;     // second stream of a chunked evaluation
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_walker[2] = {nullptr, nullptr};
   // the ONE workspace is shared by every evaluation of this handle: an evaluation launched on a different stream
-  // than the previous one first waits for the event recorded at the end of that one
-  hipEvent_t ev_last = nullptr;
+  // than the previous one first waits (on the host) for that stream
   hipStream_t last_stream = nullptr;
   bool has_last = false;
   // timing ring: per evaluation and chunk 3 events (before the walker kernel, between it and the solve, after the solve)
   std::vector<hipEvent_t> ev;
   std::vector<int> ev_chunks;  // chunks of the evaluation in each ring slot
-  int timing_slots = 0, timing_stride = 1;
+  int timing_slots = 0, timing_stride = 1, ev_per_slot = 1;
   int64_t timed_calls = 0, eval_calls = 0;
   cf_dev_desc d{};
   PackedFactor pack;
   DevBuf z_cmb, z_hel, obs, sn_step, sn_rec, log10_tab;
-  DevBuf bao_z, bao_val, bao_inv_cov, bao_qty, gl_x, gl_w, fixed_mu, cc_z, cc_h, cc_inv_cov, nu_grid, ln_grid, nu_sw, ln_sw, sn_lin, sn_dir;
+  DevBuf bao_z, bao_val, bao_inv_cov, bao_qty, gl_x, gl_w, fixed_mu, cc_z, cc_h, cc_inv_cov, nu_grid, ln_grid, nu_sw, ln_sw, exp2_tab, sn_lin, sn_dir;
   DevBuf theta, out, delta, ypk, chi2_extra, nonfinite;
   DevBuf fs8_z, fs8_val, fs8_inv_cov, fs8_fid, fs8_step_of, fs8_order, fs8_tab, fs8_pts;
   DevBuf bao_nodes, bao_base;  // [max_walkers][n_bao][CF_BAO_NODES] table nodes for small_blocks_kernel; first node per datum
@@ -350,6 +395,13 @@ static int upload_log10_table(DevBuf& b) {
   return 0;
 }
 
+// Reduction table of exp_tab (cosmofit_kernels.hip): 2^(j/64), j < 64, correctly rounded from extended precision.
+static int upload_exp2_table(DevBuf& b) {
+  double t[64];
+  for (int j = 0; j < 64; ++j) t[j] = (double)exp2l((long double)j / 64.0L);
+  return upload_vec(b, t, 64);
+}
+
 static int ensure_workspace(cf_handle* h, int64_t W) {
   const int64_t w_pad = (W + 31) / 32 * 32;  // whole panels of the widest solve kernel (2 x 16 walkers)
   if (w_pad <= h->max_walkers) return 0;
@@ -365,6 +417,7 @@ static int ensure_workspace(cf_handle* h, int64_t W) {
   if (h->d.n_sn > 0 && h->solve_mode == CF_SOLVE_INVERSE_GEMM) {
     if (h->partial.ensure((size_t)w_pad * h->ipack.dev.n_rowblocks * 8)) return CF_ERR_HIP;
     if (h->arrivals.ensure((size_t)(w_pad / 16) * 4)) return CF_ERR_HIP;
+    if (h->partial4.ensure((size_t)CF_SMALL_MAX_PANELS * 4 * h->ipack.dev.n_rowblocks * 16 * 8)) return CF_ERR_HIP;
     HIP_TRY(hipMemsetAsync(h->arrivals.p, 0, (size_t)(w_pad / 16) * 4, h->stream));  // the kernel re-arms them itself
   }
   if (h->d.n_sn > 0) {
@@ -513,7 +566,7 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess)
     return bail(fail(CF_ERR_HIP, "hipStreamCreate failed"));
-  for (hipEvent_t* e : {&h->ev_fork, &h->ev_join, &h->ev_walker[0], &h->ev_walker[1], &h->ev_last})
+  for (hipEvent_t* e : {&h->ev_fork, &h->ev_join, &h->ev_walker[0], &h->ev_walker[1]})
     if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return bail(fail(CF_ERR_HIP, "hipEventCreate failed"));
   {
     // sub-batches of a large evaluation (CF_CHUNKS=<first>,<rest>; 0 = one batch): the distance / residual kernel of
@@ -800,6 +853,9 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
       const std::vector<double> sw = swizzle_for_walker_threads(ln);
       if ((rc = upload_vec(h->ln_sw, sw.data(), (int64_t)sw.size()))) return bail(rc);
       d.ln_sw = h->ln_sw.as<const double>();
+      // 2^(j/64), correctly rounded from extended precision: reduction table of the table build's exp (exp_tab)
+      if ((rc = upload_exp2_table(h->exp2_tab))) return bail(rc);
+      d.exp2_tab = h->exp2_tab.as<const double>();
     }
   }
   if (c->n_cc > 0) {
@@ -835,6 +891,11 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
   }
   if (h->nonfinite.ensure(8)) return bail(CF_ERR_HIP);
   if (hipMemset(h->nonfinite.p, 0, 8) != hipSuccess) return bail(fail(CF_ERR_HIP, "hipMemset failed"));
+  // the register path of walker_kernel's table build (chunk_shift == 3) reads its theta-independent tables without a
+  // run-time fallback: a descriptor that needs one and does not carry it must never reach a launch
+  if (d.chunk_shift == 3 && ((d.ez_model == CF_EZ_PHYSICAL_D && !d.nu_sw) ||
+                             ((d.fde == CF_FDE_WCDM_D || d.fde == CF_FDE_CPL_D) && (!d.ln_sw || !d.exp2_tab))))
+    return bail(fail(CF_ERR_INVALID, "cf_create: internal: the table build's neutrino / ln(1 + z) tables are missing"));
   *out = h;
   return CF_OK;
 }
@@ -908,7 +969,7 @@ extern "C" void cf_destroy(cf_handle* h) {
   (void)hipDeviceSynchronize();  // evaluations launched on callers' streams may still use the workspace
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
-  for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_walker[0], h->ev_walker[1], h->ev_last})
+  for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_walker[0], h->ev_walker[1]})
     if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   if (h->aux) (void)hipStreamDestroy(h->aux);
@@ -946,7 +1007,9 @@ extern "C" int cf_enable_timing(cf_handle* h, int slots) {
   if (slots < 0 || slots > 4096) return fail(CF_ERR_INVALID, "cf_enable_timing: slots must be in 0..4096");
   std::lock_guard<std::mutex> lk(h->mu);
   HIP_TRY(hipSetDevice(h->device));
-  while ((int)h->ev.size() < 3 * CF_MAX_CHUNKS * slots) {
+  // ring slot = 3 events per sub-batch the handle can run: one sub-batch unless the chunked pipeline is configured
+  h->ev_per_slot = h->chunk_first > 0 ? CF_MAX_CHUNKS : 1;
+  while ((int)h->ev.size() < 4 * h->ev_per_slot * slots) {
     hipEvent_t e;
     HIP_TRY(hipEventCreate(&e));
     h->ev.push_back(e);
@@ -954,6 +1017,7 @@ extern "C" int cf_enable_timing(cf_handle* h, int slots) {
   h->ev_chunks.assign((size_t)slots, 0);
   h->timing_slots = slots;
   h->timed_calls = 0;
+  h->eval_calls = 0;  // the sampling phase restarts with the ring
   return CF_OK;
 }
 
@@ -969,21 +1033,33 @@ extern "C" int cf_set_timing_stride(cf_handle* h, int stride) {
 
 extern "C" int64_t cf_timed_calls(cf_handle* h) { return h ? h->timed_calls : 0; }
 
-extern "C" int cf_kernel_ms(cf_handle* h, int64_t call, float t[2]) {
-  if (!h || !t) return fail(CF_ERR_INVALID, "cf_kernel_ms: null argument");
+// t[3] = {walker_kernel, small-block + growth kernels, solve kernel (or the bare epilogue)} of timed evaluation `call`
+extern "C" int cf_kernel_ms3(cf_handle* h, int64_t call, float t[3]) {
+  if (!h || !t) return fail(CF_ERR_INVALID, "cf_kernel_ms3: null argument");
   if (h->timing_slots == 0 || call < 0 || call >= h->timed_calls || call < h->timed_calls - h->timing_slots)
-    return fail(CF_ERR_INVALID, "cf_kernel_ms: that call is not in the timing ring");
+    return fail(CF_ERR_INVALID, "cf_kernel_ms3: that call is not in the timing ring");
   const int slot = (int)(call % h->timing_slots);
-  t[0] = t[1] = 0.0f;
+  t[0] = t[1] = t[2] = 0.0f;
   for (int c = 0; c < h->ev_chunks[slot]; ++c) {  // a chunked evaluation: the sum over its sub-batches
-    hipEvent_t* e = &h->ev[3 * (slot * CF_MAX_CHUNKS + c)];
-    float a = 0.0f, b = 0.0f;
-    HIP_TRY(hipEventSynchronize(e[2]));
-    HIP_TRY(hipEventElapsedTime(&a, e[0], e[1]));
-    HIP_TRY(hipEventElapsedTime(&b, e[1], e[2]));
-    t[0] += a;
-    t[1] += b;
+    hipEvent_t* e = &h->ev[4 * (slot * h->ev_per_slot + c)];
+    HIP_TRY(hipEventSynchronize(e[3]));
+    for (int k = 0; k < 3; ++k) {
+      float a = 0.0f;
+      HIP_TRY(hipEventElapsedTime(&a, e[k], e[k + 1]));
+      t[k] += a;
+    }
   }
+  return CF_OK;
+}
+
+// t[2] = {per-walker kernels (walker_kernel + small blocks + growth), solve kernel}
+extern "C" int cf_kernel_ms(cf_handle* h, int64_t call, float t[2]) {
+  float t3[3];
+  if (!t) return fail(CF_ERR_INVALID, "cf_kernel_ms: null argument");
+  const int rc = cf_kernel_ms3(h, call, t3);
+  if (rc) return rc;
+  t[0] = t3[0] + t3[1];
+  t[1] = t3[2];
   return CF_OK;
 }
 
@@ -1039,6 +1115,7 @@ struct TriGemmArgs {
   int out_kind;
   unsigned long long* nonfinite;
   double* chi2_sn_out;
+  double* partial4;
 };
 
 template <int NP, int PF>
@@ -1065,7 +1142,35 @@ static int launch_tri_gemm_t(const TriGemmArgs& a, hipStream_t st) {
   return 0;
 }
 
+// Small batches: one workgroup per (panel, row block, 16-row tile), see tri_gemm_small_kernel.  CF_SMALL_MAX=<walkers> moves the
+// switch (0 = never; at most 16 x CF_SMALL_MAX_PANELS), CF_SMALL_PF=4|8|16 the prefetch depth (tuning).
+template <int PF>
+static int launch_tri_gemm_small_t(const TriGemmArgs& a, hipStream_t st) {
+  const int panels = (int)((a.W + 15) / 16);
+  const int units_pad = (4 * a.pk->n_rowblocks + 7) / 8 * 8;
+  hipLaunchKernelGGL((tri_gemm_small_kernel<PF>), dim3((unsigned)(panels * units_pad)), dim3(256), 0, st, *a.d, *a.pk, a.theta, a.W,
+                     a.delta, a.partial4, a.arrivals, a.chi2_extra, a.out, a.out_kind, a.nonfinite, a.chi2_sn_out, units_pad);
+  return 0;
+}
+
+static int64_t small_batch_max() {
+  static const int64_t v = [] {
+    const char* e = getenv("CF_SMALL_MAX");
+    const long long m = e ? atoll(e) : (long long)CF_SMALL_DEFAULT;
+    return (int64_t)(m < 0 ? 0 : (m > 16 * CF_SMALL_MAX_PANELS ? 16 * CF_SMALL_MAX_PANELS : m));
+  }();
+  return v;
+}
+
 static int launch_tri_gemm(const TriGemmArgs& a, hipStream_t st) {
+  if (a.W <= small_batch_max() && a.partial4) {
+    static const int pf = [] { const char* e = getenv("CF_SMALL_PF"); return e ? atoi(e) : 16; }();
+    switch (pf) {
+      case 4: return launch_tri_gemm_small_t<4>(a, st);
+      case 8: return launch_tri_gemm_small_t<8>(a, st);
+      default: return launch_tri_gemm_small_t<16>(a, st);
+    }
+  }
   static const int shape = [] {
     const char* e = getenv("CF_GEMM_SHAPE");
     return (e && strlen(e) == 3 && e[1] == 'x') ? (e[0] - '0') * 16 + (e[2] - '0') : 0;
@@ -1098,13 +1203,19 @@ static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_
   double* delta = h->delta.as<double>() ? h->delta.as<double>() + off * d.n_ld : nullptr;
   d2* bao_nodes = h->bao_nodes.as<d2>() ? h->bao_nodes.as<d2>() + off * d.n_aux * CF_BAO_NODES : nullptr;
   if (ev) HIP_TRY(hipEventRecord(ev[0], st));
+  if (ev && !(h->d.n_sn > 0 || h->has_small_blocks || h->has_growth)) HIP_TRY(hipEventRecord(ev[1], st));
   const bool walker_work = d.n_sn > 0 || h->has_small_blocks || h->has_growth;
   double* extra = (h->has_small_blocks || h->has_growth) ? h->chi2_extra.as<double>() + off : nullptr;
   if (walker_work) {
     // skewed {cum, dh} table: one spare 16-byte slot per 2^chunk_shift nodes
     const size_t lds = ((size_t)d.n_grid + (d.n_grid >> d.chunk_shift) + 2) * 16;
-    hipLaunchKernelGGL(pick_walker(d.ez_model, d.fde), dim3((unsigned)Wc), dim3(512), lds, st, d, th, Wc, delta, dm_out, mucorr_out,
-                       bao_nodes, (d2*)nullptr);
+    if (!dm_out && !mucorr_out && walker_fast_ok(d))  // the production form: lean kernel arguments, theta row across the lanes
+      hipLaunchKernelGGL(pick_walker_fast(d.ez_model, d.fde), dim3((unsigned)Wc), dim3(512), lds, st, walker_args_of(d), th, Wc, delta,
+                         bao_nodes);
+    else
+      hipLaunchKernelGGL(pick_walker(d.ez_model, d.fde), dim3((unsigned)Wc), dim3(512), lds, st, d, th, Wc, delta, dm_out, mucorr_out,
+                         bao_nodes, (d2*)nullptr);
+    if (ev) HIP_TRY(hipEventRecord(ev[1], st));  // between walker_kernel and the small-block / growth kernels
     if (h->has_small_blocks)  // sixteen lanes per walker, sixteen walkers per workgroup
       hipLaunchKernelGGL(pick_small_blocks(d.ez_model, d.fde), dim3((unsigned)((Wc + 15) / 16)), dim3(256), 0, st, d, th, Wc,
                          (const d2*)bao_nodes, extra, blocks_out, bao_out);
@@ -1114,10 +1225,12 @@ static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_
                          h->has_small_blocks ? 1 : 0, fs8_block_out, fs8_theory_out);
   }
   if (ev_walker_done) HIP_TRY(hipEventRecord(ev_walker_done, st));
-  if (ev) HIP_TRY(hipEventRecord(ev[1], st));
+  if (ev) HIP_TRY(hipEventRecord(ev[2], st));
   if (d.n_sn > 0 && h->solve_mode == CF_SOLVE_INVERSE_GEMM) {
     const TriGemmArgs a{&d, &h->ipack.dev, th, Wc, delta, h->max_walkers, h->partial.as<double>() + off,
-                        h->arrivals.as<unsigned int>() + off / 16, extra, out, out_kind, nf, chi2_sn_out};
+                        h->arrivals.as<unsigned int>() + off / 16, extra, out, out_kind, nf, chi2_sn_out,
+                        ev_walker_done ? nullptr : h->partial4.as<double>()};  // sub-batches run side by side: one partial4
+
     int rc = launch_tri_gemm(a, st);
     if (rc) return rc;
   } else if (d.n_sn > 0) {
@@ -1128,7 +1241,7 @@ static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((Wc + 255) / 256)), dim3(256), 0, st, d, th, Wc, (const double*)extra, out,
                        out_kind, nf);
   }
-  if (ev) HIP_TRY(hipEventRecord(ev[2], st));
+  if (ev) HIP_TRY(hipEventRecord(ev[3], st));
   return 0;
 }
 
@@ -1138,8 +1251,10 @@ static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_
 static int launch_path(cf_handle* h, const double* d_theta, int64_t W, double* d_out, int out_kind, hipStream_t st,
                        double* dm_out, double* mucorr_out, double* blocks_out, double* bao_out,
                        double* chi2_sn_out = nullptr, double* fs8_block_out = nullptr, double* fs8_theory_out = nullptr) {
-  // the workspace is shared: order this evaluation behind the previous one if that ran on another stream
-  if (h->has_last && h->last_stream != st) HIP_TRY(hipStreamWaitEvent(st, h->ev_last, 0));
+  // the workspace is shared: an evaluation on another stream than the previous one first waits for that stream (a rare
+  // switch -- host calls run on the handle's stream, a device-resident sampler on its own -- so the wait is a host-side
+  // synchronise at the switch instead of an event record on every evaluation: ~2 us of each small-batch call)
+  if (h->has_last && h->last_stream != st) HIP_TRY(hipStreamSynchronize(h->last_stream));
   const bool parts = dm_out || mucorr_out || blocks_out || bao_out || chi2_sn_out;
   int64_t offs[CF_MAX_CHUNKS + 1];
   int n_chunks = 1;
@@ -1157,7 +1272,7 @@ static int launch_path(cf_handle* h, const double* d_theta, int64_t W, double* d
   offs[n_chunks] = W;
   const bool timed = h->timing_slots && (h->eval_calls++ % h->timing_stride) == 0;
   const int slot = timed ? (int)(h->timed_calls % h->timing_slots) : 0;
-  hipEvent_t* ev = timed ? &h->ev[3 * slot * CF_MAX_CHUNKS] : nullptr;
+  hipEvent_t* ev = timed ? &h->ev[4 * slot * h->ev_per_slot] : nullptr;
   if (n_chunks == 1) {
     int rc = launch_chunk(h, d_theta, 0, W, d_out, out_kind, st, dm_out, mucorr_out, blocks_out, bao_out, chi2_sn_out, ev, nullptr,
                           fs8_block_out, fs8_theory_out);
@@ -1169,7 +1284,7 @@ static int launch_path(cf_handle* h, const double* d_theta, int64_t W, double* d
       hipStream_t sc = (c & 1) ? h->aux : st;
       if (c > 0) HIP_TRY(hipStreamWaitEvent(sc, h->ev_walker[(c - 1) & 1], 0));  // walker kernels one after the other
       int rc = launch_chunk(h, d_theta, offs[c], offs[c + 1] - offs[c], d_out, out_kind, sc, nullptr, nullptr, nullptr, nullptr,
-                            nullptr, ev ? ev + 3 * c : nullptr, h->ev_walker[c & 1]);
+                            nullptr, ev ? ev + 4 * c : nullptr, h->ev_walker[c & 1]);
       if (rc) return rc;
     }
     HIP_TRY(hipEventRecord(h->ev_join, h->aux));
@@ -1179,7 +1294,6 @@ static int launch_path(cf_handle* h, const double* d_theta, int64_t W, double* d
     h->ev_chunks[slot] = n_chunks;
     h->timed_calls++;
   }
-  HIP_TRY(hipEventRecord(h->ev_last, st));
   h->last_stream = st;
   h->has_last = true;
   HIP_TRY(hipGetLastError());
@@ -1365,7 +1479,7 @@ extern "C" int cf_eval_table(cf_handle* h, const double* theta, int64_t W, doubl
   HIP_TRY(hipSetDevice(h->device));
   int rc;
   if ((rc = ensure_workspace(h, W))) return rc;
-  if (h->has_last && h->last_stream != h->stream) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_last, 0));
+  if (h->has_last && h->last_stream != h->stream) HIP_TRY(hipStreamSynchronize(h->last_stream));
   cf_dev_desc d = h->d;  // a copy without the SN / BAO consumers of the table: only the build runs
   const int G = d.n_grid;
   d.n_sn = 0;
@@ -1402,7 +1516,7 @@ extern "C" int cf_eval_fs8_at(cf_handle* h, const double* theta, const double* z
   HIP_TRY(hipSetDevice(h->device));
   int rc;
   if ((rc = ensure_workspace(h, 1))) return rc;
-  if (h->has_last && h->last_stream != h->stream) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_last, 0));
+  if (h->has_last && h->last_stream != h->stream) HIP_TRY(hipStreamSynchronize(h->last_stream));
   HIP_TRY(hipMemcpyAsync(h->theta.p, theta, (size_t)h->d.ndim * 8, hipMemcpyHostToDevice, h->stream));
   const int B = CF_MAX_FS8;
   DevBuf dz, dbase, dstep, dorder, dpts, dval, dinv, dfid, nodes, dout, extra;
@@ -1454,7 +1568,7 @@ extern "C" int cf_eval_hz(cf_handle* h, const double* theta, const double* z, in
   HIP_TRY(hipSetDevice(h->device));
   int rc;
   if ((rc = ensure_workspace(h, 1))) return rc;
-  if (h->has_last && h->last_stream != h->stream) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_last, 0));
+  if (h->has_last && h->last_stream != h->stream) HIP_TRY(hipStreamSynchronize(h->last_stream));
   DevBuf dz, dout;
   if (dz.ensure((size_t)n * 8) || dout.ensure((size_t)n * 8)) return CF_ERR_HIP;
   HIP_TRY(hipMemcpyAsync(h->theta.p, theta, (size_t)h->d.ndim * 8, hipMemcpyHostToDevice, h->stream));
@@ -1479,7 +1593,7 @@ extern "C" int cf_eval_bao_at(cf_handle* h, const double* theta, const double* z
   HIP_TRY(hipSetDevice(h->device));
   int rc;
   if ((rc = ensure_workspace(h, 1))) return rc;
-  if (h->has_last && h->last_stream != h->stream) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_last, 0));
+  if (h->has_last && h->last_stream != h->stream) HIP_TRY(hipStreamSynchronize(h->last_stream));
   HIP_TRY(hipMemcpyAsync(h->theta.p, theta, (size_t)h->d.ndim * 8, hipMemcpyHostToDevice, h->stream));
   DevBuf dz, dq, dbase, dval, dinv, nodes, dout, extra;
   const int B = CF_MAX_BAO;
@@ -1608,7 +1722,11 @@ static int selftest_log10(const double* x, int64_t n, double* out, int mode, con
   DevBuf dx, dout, tab;
   if (dx.ensure((size_t)n * 8) || dout.ensure((size_t)n * 8)) return CF_ERR_HIP;
   int rc;
-  if ((rc = upload_log10_table(tab))) return rc;
+  if (mode == 2) {
+    if ((rc = upload_exp2_table(tab))) return rc;
+  } else if ((rc = upload_log10_table(tab))) {
+    return rc;
+  }
   HIP_TRY(hipMemcpy(dx.p, x, (size_t)n * 8, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(log10_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dx.as<const double>(), n,
                      dout.as<double>(), mode, tab.as<const cf_d2>());
@@ -1619,6 +1737,9 @@ static int selftest_log10(const double* x, int64_t n, double* out, int mode, con
 extern "C" int cf_selftest_log10(const double* x, int64_t n, double* out) { return selftest_log10(x, n, out, 0, "cf_selftest_log10"); }
 extern "C" int cf_selftest_log10_tab(const double* x, int64_t n, double* out) {
   return selftest_log10(x, n, out, 1, "cf_selftest_log10_tab");
+}
+extern "C" int cf_selftest_exp_tab(const double* x, int64_t n, double* out) {
+  return selftest_log10(x, n, out, 2, "cf_selftest_exp_tab");
 }
 
 // ------------------------------------------------------------------------------------------------

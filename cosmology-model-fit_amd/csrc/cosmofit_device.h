@@ -110,6 +110,7 @@ struct cf_dev_desc {
   // 64 cache lines; only for the register path of the table build (n_grid <= 4096), else null
   const double* nu_sw;
   const double* ln_sw;
+  const double* exp2_tab;   // [64] 2^(j/64): reduction table of the table build's exp (wCDM / CPL), or null
   // BAO block
   int32_t n_bao, bao_dh_exact, rd_from_fit, rd_wm_late;  // rd_wm_late: the r_drag fit takes wm = Omega_m h^2 (late-time flat model)
   const double* bao_z;
@@ -133,6 +134,26 @@ struct cf_dev_desc {
   double gauss_mean[CF_MAX_GAUSS], gauss_sigma[CF_MAX_GAUSS];
   int32_t chi2_gauss_idx[CF_MAX_GAUSS];
   double chi2_gauss_mean[CF_MAX_GAUSS], chi2_gauss_sigma[CF_MAX_GAUSS];
+};
+
+// What the PRODUCTION per-walker kernel (walker_fast_kernel) needs of the descriptor, and nothing else: ~0.5 KB of kernel
+// arguments instead of cf_dev_desc's 1.9 KB.  With the whole descriptor by value the kernel's prologue was a chain of
+// scalar loads of fields of code paths it never takes, each waited for and spilled (74 SGPR spills for the physical-density
+// CPL model).  Same field names as cf_dev_desc: the device helpers are templates over the descriptor type.
+struct cf_walker_args {
+  int32_t ndim, n_grid, ez_model, fde;
+  int32_t chunk_shift, om_mode;
+  int32_t n_sn, n_ld;
+  int32_t has_vstep, step_pm1, lin_in_rec, n_aux;
+  double z_max, step, c, inv_step, inv_last;
+  double or_h2, omnu_h2;
+  cf_dev_slot slot[CF_N_SLOTS];
+  const cf_d4* sn_rec;
+  const void* log10_tab;
+  const double* nu_sw;
+  const double* ln_sw;
+  const double* exp2_tab;
+  const int32_t* bao_base;
 };
 
 #ifdef __HIPCC__

@@ -32,6 +32,23 @@ __device__ __forceinline__ double slot_get(const cf_dev_desc& d, int s, const do
   return p.idx >= 0 ? p.scale * th[p.idx] : p.fixed;
 }
 
+// The walker's theta row held ACROSS THE LANES of a wave (lane k = theta[k], one coalesced load at the head of the kernel);
+// a slot is then a v_readlane at the slot's (wave-uniform) index.  Read through the pointer, every slot was its own basic
+// block -- load, wait for it, next slot: seven serialised round trips to the theta row at the head of walker_kernel for the
+// CPL joint likelihood, 7-9 k of its 23 k cycles per workgroup (in-kernel stamps, profiles/r03_walker_stamps_config3.txt).
+struct ThetaRow {
+  double v;
+};
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+template <class D>
+__device__ __forceinline__ double slot_get(const D& d, int s, const ThetaRow& th) {
+  const cf_dev_slot& p = d.slot[s];
+  const double v = readlane_f64(th.v, p.idx >= 0 ? p.idx : 0);
+  return p.idx >= 0 ? p.scale * v : p.fixed;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Expansion rate.  dh(z) = c / H(z).   Reference: sn/pantheon.py:28-31, bao/desi.py:26-35,
 // sn/pantheon_and_sh0es.py:26-28, bao/desi_fs_lya_cmb.py:19-22.  (1+z)^3 by multiplies (numba).
@@ -42,7 +59,9 @@ struct WalkerCosmo {
   int fde, model;
 };
 
-__device__ __forceinline__ WalkerCosmo make_cosmo(const cf_dev_desc& d, const double* __restrict__ th) {
+// D: cf_dev_desc or the lean cf_walker_args; TH: const double* (theta row in memory) or ThetaRow (across the lanes)
+template <class D, class TH>
+__device__ __forceinline__ WalkerCosmo make_cosmo(const D& d, const TH& th) {
   WalkerCosmo wc;
   wc.H0 = slot_get(d, CF_P_H0_D, th);
   wc.Om = slot_get(d, CF_P_OM_D, th);
@@ -82,21 +101,58 @@ extern "C" int cf_debug_walker_stamps(unsigned long long* out) {
 #define CF_WSTAMP(k)
 #endif
 
+// exp(x) for the dark-energy density of the table build: |x| < ~40 (x = 3 (1 + w0 + wa) ln(1 + z) - 3 wa z / (1 + z) inside any
+// prior box a sampler would draw from), so none of the library routine's overflow / underflow / NaN handling, and a
+// table-driven reduction instead of its long polynomial:  x = (64 k + j) ln2 / 64 + r,  |r| <= ln2 / 128,
+//   exp(x) = 2^k 2^(j/64) (1 + r + r^2/2 + ... + r^6/720)         (next term 1.5e-19 relative)
+// tab[j] = 2^(j/64) correctly rounded from extended precision (cf_create), 512 B staged in LDS; ln2 / 64 as a hi + lo pair.
+// <= 1.5 ulp; 17 instructions where the library's exp takes ~60 -- the table build of the CPL model was 90 instructions per
+// grid node against 19 for LambdaCDM (profiles/r03_cpl_exp_ab.txt).
+__device__ __forceinline__ double exp_tab(double x, const double* __restrict__ tab) {
+#ifdef CF_LIB_EXP  // A/B build: the library's exp in the table build (round 2)
+  return exp(x);
+#endif
+  const double n = __builtin_rint(x * 0x1.71547652b82fep+6);  // 64 / ln 2
+  double r = fma(-n, 0x1.62e42fefa39efp-7, x);
+  r = fma(-n, 0x1.abc9e3b39803fp-62, r);
+  const int ni = (int)n;
+  const double t = tab[ni & 63];
+  double p = fma(r, 1.0 / 720, 1.0 / 120);
+  p = fma(p, r, 1.0 / 24);
+  p = fma(p, r, 1.0 / 6);
+  p = fma(p, r, 0.5);
+  p = fma(p * r, r, r);  // expm1(r)
+  return ldexp(fma(t, p, t), ni >> 6);
+}
+
 // `lnzp1` >= 0: ln(1 + z) of a grid node, tabulated at cf_create (theta-independent): the power of the wCDM / CPL forms
 // becomes ONE exp of a product instead of pow (+ exp): zp1^a = exp(a ln zp1), a few ulp from the library pow and a third
 // of its instructions -- the table build of the CPL model was 2.3x the LCDM one.  Absent (< 0): the reference's expression.
-// TAB: `lnzp1` is known to be a tabulated value at compile time (the table build): the pow fallback is not even compiled in --
-// inlined eight times per thread it put ~1500 cold instructions into the hot loop.
+// TAB: `lnzp1` is known to be a tabulated value at compile time (the table build): the pow fallback is
+// not even compiled in -- inlined eight times per thread it put ~1500 cold instructions into the hot loop -- and the exp is the
+// table-driven exp_tab on `etab` (LDS).
 template <int FDE, bool TAB = false>
-__device__ __forceinline__ double f_de(const WalkerCosmo& wc, double z, double zp1, double cubed, double lnzp1 = -1.0) {
+__device__ __forceinline__ double f_de(const WalkerCosmo& wc, double z, double zp1, double cubed, double lnzp1 = -1.0,
+                                       const double* __restrict__ etab = nullptr) {
   if (FDE == CF_FDE_LCDM_D) return 1.0;
-  if (FDE == CF_FDE_WCDM_D) return (TAB || lnzp1 >= 0.0) ? exp(3 * (1 + wc.w0) * lnzp1) : pow(zp1, 3 * (1 + wc.w0));
+  if (FDE == CF_FDE_WCDM_D) {
+    if (TAB) return exp_tab(3 * (1 + wc.w0) * lnzp1, etab);
+    return exp(3 * (1 + wc.w0) * (lnzp1 >= 0.0 ? lnzp1 : log(zp1)));  // zp1^a = exp(a ln zp1): log + exp, half of pow's instructions
+  }
   if (FDE == CF_FDE_THAWING_D) {
     double r = 2 * cubed / ((1.0 + wc.w0) + (1.0 - wc.w0) * cubed);
     return r * r;
   }
-  if (TAB || lnzp1 >= 0.0) return exp(fma(3 * (1 + wc.w0 + wc.wa), lnzp1, -3 * wc.wa * z / zp1));
-  return pow(zp1, 3 * (1 + wc.w0 + wc.wa)) * exp(-3 * wc.wa * z / zp1);
+  if (TAB) {  // z / (1 + z) through a refined reciprocal (1 + z in [1, 1 + z_max]: no special cases), <= 1 ulp from the quotient
+    double r = __builtin_amdgcn_rcp(zp1);
+    r = fma(fma(-zp1, r, 1.0), r, r);
+    return exp_tab(fma(3 * (1 + wc.w0 + wc.wa), lnzp1, (-3 * wc.wa) * (z * r)), etab);
+  }
+  // the reference's pow(zp1, a) * exp(b) (bao/desi_fs_lya_cmb.py:19-22) as ONE exp: a ln zp1 + b carries |a ln zp1| ulps of the
+  // logarithm's rounding into the result, <= 2e-14 relative at the Gauss-Legendre nodes of the sound horizon (z ~ 1e6) where the
+  // dark-energy term is negligible anyway; 110 instructions instead of pow + exp's 180 (small_blocks_kernel evaluates it 400 times
+  // per walker for the compressed-CMB block)
+  return exp(fma(3 * (1 + wc.w0 + wc.wa), lnzp1 >= 0.0 ? lnzp1 : log(zp1), -3 * wc.wa * z / zp1));
 }
 
 // 5-node massive-neutrino density, cmb/data_planck_act_compression.py:53-66
@@ -113,15 +169,18 @@ __device__ __forceinline__ double omnu_z(const cf_dev_desc& d, double zp1) {
 // value tabulated at cf_create for this grid node (it does not depend on theta: 5 sqrt + 2 divides saved
 // per node and per walker, and the tabulated value is the reference's own arithmetic).
 // TAB (the table build's register path): `nu` and `lnzp1` ARE tabulated values, the fallbacks are compiled out.
-template <int MODEL, int FDE, bool TAB = false>
-__device__ __forceinline__ double e2_of_z(const cf_dev_desc& d, const WalkerCosmo& wc, double z, double nu = -1.0, double lnzp1 = -1.0) {
+template <int MODEL, int FDE, bool TAB = false, class D = cf_dev_desc>
+__device__ __forceinline__ double e2_of_z(const D& d, const WalkerCosmo& wc, double z, double nu = -1.0, double lnzp1 = -1.0,
+                                          const double* __restrict__ etab = nullptr) {
   const double zp1 = 1.0 + z;
   const double cubed = zp1 * zp1 * zp1;
   if (MODEL == CF_EZ_LATE_FLAT_D)
     return (FDE == CF_FDE_LCDM_D) ? wc.Om * cubed + (1.0 - wc.Om)
-                                  : wc.Om * cubed + (1.0 - wc.Om) * f_de<FDE, TAB>(wc, z, zp1, cubed, lnzp1);
-  const double de = (FDE == CF_FDE_LCDM_D) ? wc.Ode : wc.Ode * f_de<FDE, TAB>(wc, z, zp1, cubed, lnzp1);
-  if (!TAB && nu < 0.0) nu = omnu_z(d, zp1);
+                                  : wc.Om * cubed + (1.0 - wc.Om) * f_de<FDE, TAB>(wc, z, zp1, cubed, lnzp1, etab);
+  const double de = (FDE == CF_FDE_LCDM_D) ? wc.Ode : wc.Ode * f_de<FDE, TAB>(wc, z, zp1, cubed, lnzp1, etab);
+  if constexpr (!TAB) {
+    if (nu < 0.0) nu = omnu_z(d, zp1);
+  }
   return wc.Or * (cubed * zp1) + wc.Obc * cubed + de + wc.Onu * nu;  // bao/desi_cmb_des5y.py:43-48
 }
 
@@ -362,9 +421,10 @@ __device__ __forceinline__ double wave_inclusive_scan(double v) {
 // The interval in front of a chunk belongs to it, with dh of the node before taken from the neighbouring lane
 // (DPP wave_shr:1); lane 0 leaves its first interval out -- build_distance_table_regs adds the eight
 // wave-boundary intervals with the carries.
-template <int MODEL, int FDE, int CH, bool LAST>
-__device__ __forceinline__ double chunk_eval(const cf_dev_desc& d, const WalkerCosmo& wc, double c_over_H0, int g0, int lane,
-                                             const double (&nu_pre)[CH], const double (&ln)[CH], double (&dh)[CH], double (&loc)[CH]) {
+template <int MODEL, int FDE, int CH, bool LAST, class D>
+__device__ __forceinline__ double chunk_eval(const D& d, const WalkerCosmo& wc, double c_over_H0, int g0, int lane,
+                                             const double (&nu_pre)[CH], const double (&ln)[CH], const double* __restrict__ etab,
+                                             double (&dh)[CH], double (&loc)[CH]) {
   const int G = d.n_grid;
   // nu_pre / ln: the tabulated neutrino density and ln(1 + z) of the nodes (theta-independent tables, fetched by the kernel
   // before anything else); the tables exist whenever the model needs them (cf_create), so no fallback is compiled in
@@ -373,7 +433,7 @@ __device__ __forceinline__ double chunk_eval(const cf_dev_desc& d, const WalkerC
     const int g = g0 + k;
     double z = (double)g * d.step;
     if (LAST) z = g >= G - 1 ? d.z_max : z;
-    const double v = c_over_H0 * rsqrt_pos(e2_of_z<MODEL, FDE, true>(d, wc, z, nu_pre[k], ln[k]));
+    const double v = c_over_H0 * rsqrt_pos(e2_of_z<MODEL, FDE, true, D>(d, wc, z, nu_pre[k], ln[k], etab));
     dh[k] = (LAST && g >= G) ? 0.0 : v;
   }
   double prev = dpp_move<0x138, 0xF>(dh[CH - 1]);  // wave_shr:1; lane 0 gets 0 and skips its first interval
@@ -389,9 +449,10 @@ __device__ __forceinline__ double chunk_eval(const cf_dev_desc& d, const WalkerC
   return run;
 }
 
-template <int MODEL, int FDE, int CH>
-__device__ __forceinline__ void build_distance_table_regs(const cf_dev_desc& d, const WalkerCosmo& wc, d2* tab,
-                                                          d4* wave_pub, const double (&nu_pre)[CH], const double (&ln_pre)[CH]) {
+template <int MODEL, int FDE, int CH, class D>
+__device__ __forceinline__ void build_distance_table_regs(const D& d, const WalkerCosmo& wc, d2* tab,
+                                                          d4* wave_pub, const double (&nu_pre)[CH], const double (&ln_pre)[CH],
+                                                          const double* __restrict__ etab) {
   const int G = d.n_grid;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g0 = tid * CH;
@@ -399,8 +460,8 @@ __device__ __forceinline__ void build_distance_table_regs(const cf_dev_desc& d, 
   const double c_over_H0 = wc.c / wc.H0;
   double dh[CH], loc[CH];
   const int wave_last = (tid - lane) * CH + 64 * CH - 1;  // last node of this wave
-  const double run = wave_last < G - 1 ? chunk_eval<MODEL, FDE, CH, false>(d, wc, c_over_H0, g0, lane, nu_pre, ln_pre, dh, loc)
-                                       : chunk_eval<MODEL, FDE, CH, true>(d, wc, c_over_H0, g0, lane, nu_pre, ln_pre, dh, loc);
+  const double run = wave_last < G - 1 ? chunk_eval<MODEL, FDE, CH, false>(d, wc, c_over_H0, g0, lane, nu_pre, ln_pre, etab, dh, loc)
+                                       : chunk_eval<MODEL, FDE, CH, true>(d, wc, c_over_H0, g0, lane, nu_pre, ln_pre, etab, dh, loc);
   CF_WSTAMP(2);
   const double incl = wave_inclusive_scan(run);
   // per wave: {sum of its intervals, dh of its first node, dh of its last node}
@@ -470,9 +531,10 @@ __device__ __forceinline__ void build_distance_table_lds(const cf_dev_desc& d, c
 
 template <int MODEL, int FDE>
 __device__ __forceinline__ void build_distance_table(const cf_dev_desc& d, const WalkerCosmo& wc, d2* tab,
-                                                     d4* wave_pub, const double (&nu_pre)[8], const double (&ln_pre)[8]) {
+                                                     d4* wave_pub, const double (&nu_pre)[8], const double (&ln_pre)[8],
+                                                     const double* __restrict__ etab) {
   // grids up to 4096 nodes (the reference uses 4000) take the register path, 8 nodes per thread
-  if (d.chunk_shift == 3) build_distance_table_regs<MODEL, FDE, 8>(d, wc, tab, wave_pub, nu_pre, ln_pre);
+  if (d.chunk_shift == 3) build_distance_table_regs<MODEL, FDE, 8>(d, wc, tab, wave_pub, nu_pre, ln_pre, etab);
   else build_distance_table_lds<MODEL, FDE>(d, wc, tab, wave_pub);
 }
 
@@ -552,8 +614,8 @@ __device__ double r_drag_fit(const double* f, double wb, double wm) {
 // ------------------------------------------------------------------------------------------------
 // LIN: the record's second field carries the coefficient of the linear magnitude term instead of a step weight (only
 // likelihoods without a velocity step): offset_i = offset + lin * coef_i    bao/desi_cmb_pantheon_H0trgb.py:102-106
-template <bool PM1, bool LIN = false>
-__device__ __forceinline__ void sn_fast_loop(const cf_dev_desc& d, const DistTable& T, const d2* __restrict__ log_tab,
+template <bool PM1, bool LIN = false, class D = cf_dev_desc>
+__device__ __forceinline__ void sn_fast_loop(const D& d, const DistTable& T, const d2* __restrict__ log_tab,
                                              double* __restrict__ out, double off, double v100, int tid, double lin = 0.0) {
   const int n_sn = d.n_sn;
   double r_pos = 1.0, r_neg = 1.0;
@@ -616,6 +678,7 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
   extern __shared__ __align__(16) d2 lds_tab[];
   __shared__ __align__(16) d4 wave_pub[CF_TPB_A / 64];  // per-wave {interval sum, first dh, last dh} of the table build
   __shared__ __align__(16) d2 log_tab[64];  // log10_tab's reduction table; the table build's barriers order the fill
+  __shared__ double exp2_tab[64];           // exp_tab's 2^(j/64) (wCDM / CPL table build)
 
   const int64_t w = blockIdx.x;
   if (w >= W) return;
@@ -634,6 +697,10 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
     nu_pre[k] = (MODEL == CF_EZ_PHYSICAL_D && d.chunk_shift == 3) ? d.nu_sw[k * CF_TPB_A + tid] : -1.0;
     ln_pre[k] = (POWER_LAW && d.chunk_shift == 3) ? d.ln_sw[k * CF_TPB_A + tid] : -1.0;
   }
+  // (only the register path of the table build uses it; longer grids take build_distance_table_lds and the library exp,
+  // and their descriptor carries no table)
+  if (POWER_LAW && d.chunk_shift == 3 && tid >= 64 && tid < 128) exp2_tab[tid - 64] = d.exp2_tab[tid - 64];
+  if (POWER_LAW && d.chunk_shift == 3) __syncthreads();  // the table build reads exp2_tab before its own first barrier
   const WalkerCosmo wc = make_cosmo(d, th);
   DistTable T;
   T.tab = lds_tab;
@@ -645,7 +712,7 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
   T.z_max = d.z_max;
 
   CF_WSTAMP(1);
-  if (d.n_sn > 0 || d.n_aux > 0 || table_out) build_distance_table<MODEL, FDE>(d, wc, lds_tab, wave_pub, nu_pre, ln_pre);
+  if (d.n_sn > 0 || d.n_aux > 0 || table_out) build_distance_table<MODEL, FDE>(d, wc, lds_tab, wave_pub, nu_pre, ln_pre, exp2_tab);
   CF_WSTAMP(4);
   if (table_out)  // accessor path (cf_eval_table): the walker's whole {cum_dm, dh} table, node order
     for (int g = tid; g < d.n_grid; g += CF_TPB_A) table_out[w * d.n_grid + g] = T.at(g);
@@ -705,6 +772,70 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
         out[i] = res;  // rows >= n_sn are zero padding for the 16-row MFMA tiles
       }
     }
+  }
+  CF_WSTAMP(5);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The PRODUCTION form of Kernel A: the same table build and SN loop for the evaluations that take none of the accessor /
+// calibrator / direction-dependent paths (cf_eval, cf_eval_device of every likelihood whose SN block fits sn_fast_loop) and a
+// grid of at most 4096 nodes.  Lean kernel arguments (cf_walker_args), the walker's theta row across the lanes (ThetaRow):
+// the prologue is one theta load + the scalar loads of the fields this path uses, instead of ~60 serialised scalar loads.
+// ------------------------------------------------------------------------------------------------
+template <int MODEL, int FDE>
+__global__ void __launch_bounds__(CF_TPB_A, 4)
+walker_fast_kernel(cf_walker_args d, const double* __restrict__ theta, int64_t W, double* __restrict__ delta,
+                   d2* __restrict__ bao_nodes) {
+  extern __shared__ __align__(16) d2 lds_tab[];
+  __shared__ __align__(16) d4 wave_pub[CF_TPB_A / 64];
+  __shared__ __align__(16) d2 log_tab[64];
+  __shared__ double exp2_tab[64];
+
+  const int64_t w = blockIdx.x;
+  if (w >= W) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  CF_WSTAMP(0);
+  // loads in the order their values are needed: the theta row (the cosmology scalars wait for nothing else), the two small
+  // reduction tables, then the theta-independent node tables of the table build
+  const ThetaRow th{theta[w * d.ndim + (lane < d.ndim ? lane : 0)]};
+  constexpr bool POWER_LAW = FDE == CF_FDE_WCDM_D || FDE == CF_FDE_CPL_D;
+  d2 lt = (d2){0.0, 0.0};
+  double et = 0.0;
+  if (tid < 64 && d.n_sn > 0) lt = reinterpret_cast<const d2*>(d.log10_tab)[tid];
+  if (POWER_LAW && tid >= 64 && tid < 128) et = d.exp2_tab[tid - 64];
+  double nu_pre[8], ln_pre[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    nu_pre[k] = MODEL == CF_EZ_PHYSICAL_D ? d.nu_sw[k * CF_TPB_A + tid] : -1.0;
+    ln_pre[k] = POWER_LAW ? d.ln_sw[k * CF_TPB_A + tid] : -1.0;
+  }
+  if (tid < 64 && d.n_sn > 0) log_tab[tid] = lt;
+  if (POWER_LAW && tid >= 64 && tid < 128) exp2_tab[tid - 64] = et;
+  if (POWER_LAW) __syncthreads();  // the table build reads exp2_tab before its own first barrier
+  const WalkerCosmo wc = make_cosmo(d, th);
+  const double off = slot_get(d, CF_P_OFFSET_D, th);
+  const double v100 = 100 * slot_get(d, CF_P_V_D, th);
+  const double lin = d.lin_in_rec ? slot_get(d, CF_P_LIN_D, th) : 0.0;
+  DistTable T;
+  T.tab = lds_tab;
+  T.G = d.n_grid;
+  T.chs = 3;
+  T.step = d.step;
+  T.inv_step = d.inv_step;
+  T.inv_last = d.inv_last;
+  T.z_max = d.z_max;
+  CF_WSTAMP(1);
+  build_distance_table_regs<MODEL, FDE, 8>(d, wc, lds_tab, wave_pub, nu_pre, ln_pre, exp2_tab);
+  CF_WSTAMP(4);
+  for (int e = CF_TPB_A - 1 - tid; e < CF_BAO_NODES * d.n_aux; e += CF_TPB_A) {
+    const int k = e / CF_BAO_NODES, o = e % CF_BAO_NODES;
+    bao_nodes[(w * d.n_aux + k) * CF_BAO_NODES + o] = T.at(d.bao_base[k] + o);
+  }
+  if (d.n_sn > 0) {
+    double* out = delta + w * d.n_ld;
+    if (d.lin_in_rec) sn_fast_loop<false, true>(d, T, log_tab, out, off, v100, tid, lin);
+    else if (d.step_pm1) sn_fast_loop<true>(d, T, log_tab, out, off, v100, tid);
+    else sn_fast_loop<false>(d, T, log_tab, out, off, v100, tid);
   }
   CF_WSTAMP(5);
 }
@@ -1116,6 +1247,7 @@ __global__ void hz_kernel(cf_dev_desc d, const double* __restrict__ theta, const
   template __global__ void growth_kernel<M, F, C>(cf_dev_desc, const double*, int64_t, const d2*, double*, int, double*, double*);
 #define CF_INSTANTIATE_WALKER(M, F)                                                                              \
   template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*, d2*); \
+  template __global__ void walker_fast_kernel<M, F>(cf_walker_args, const double*, int64_t, double*, d2*);              \
   template __global__ void small_blocks_kernel<M, F>(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, \
                                                      double*);                                                      \
   template __global__ void hz_kernel<M, F>(cf_dev_desc, const double*, const double*, int64_t, double*);                     \
@@ -1427,6 +1559,20 @@ extern "C" int cf_debug_gemm_stamps(unsigned long long* out) {
 // have nothing to do with the exchange.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// One 16 x 16 tile of Y = X Delta from the four K quarters' partial tiles (C layout: register r of lane l is row (l >> 4) + 4 r,
+// column l & 15), and its share of chi^2 per walker column: the sum of squares over the tile's 16 rows -- four in registers,
+// then across the four lane groups.  ONE function for the throughput kernel and the small-batch kernel: the same expression,
+// hence the same FMA contraction, hence bit-identical shares.
+__device__ __forceinline__ double tile_chi2_share(const d4& p0, const d4& p1, const d4& p2, const d4& p3) {
+  const d4 y = ((p0 + p1) + p2) + p3;
+  double v = y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
+  v += __shfl_xor(v, 16, CF_WAVE);
+  v += __shfl_xor(v, 32, CF_WAVE);
+  return v;
+}
+// a row block's share from its four tiles' shares, in tile order
+__device__ __forceinline__ double rowblock_share(double t0, double t1, double t2, double t3) { return ((t0 + t1) + t2) + t3; }
+
 template <int NP, int PF>
 __global__ void __launch_bounds__(256)
 tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict__ theta, int64_t W,
@@ -1534,10 +1680,7 @@ tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict_
 #pragma unroll
     for (int j = 0; j < 4; ++j) part[g][j][lane] = acc[c][j];
     lds_barrier();
-    const d4 y = ((part[0][g][lane] + part[1][g][lane]) + part[2][g][lane]) + part[3][g][lane];
-    double v = y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
-    v += __shfl_xor(v, 16, CF_WAVE);
-    v += __shfl_xor(v, 32, CF_WAVE);
+    const double v = tile_chi2_share(part[0][g][lane], part[1][g][lane], part[2][g][lane], part[3][g][lane]);
     if (lane < 16) chi_tile[g][c * 16 + lane] = v;
   }
   lds_barrier();
@@ -1560,7 +1703,7 @@ tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict_
   if (g == 0) {
     if (lane < 16 * NP)
       __hip_atomic_store(&partial[(int64_t)rb * w_pad + w0 + lane],
-                         ((chi_tile[0][lane] + chi_tile[1][lane]) + chi_tile[2][lane]) + chi_tile[3][lane], __ATOMIC_RELAXED,
+                         rowblock_share(chi_tile[0][lane], chi_tile[1][lane], chi_tile[2][lane], chi_tile[3][lane]), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of every lane of this wave have reached memory
     if (lane == 0)
@@ -1611,6 +1754,154 @@ CF_INSTANTIATE_TRIGEMM(2, 2)
 CF_INSTANTIATE_TRIGEMM(2, 3)
 CF_INSTANTIATE_TRIGEMM(2, 4)
 CF_INSTANTIATE_TRIGEMM(4, 2)
+
+// ------------------------------------------------------------------------------------------------
+// The same solve for SMALL batches (W <= a few panels of 16 walkers: emcee's 16-walker half-steps of BASELINE configs[0],
+// sn/pantheon.py:108-123; the serial callers of log_evidence.py:20-46).  With one panel the throughput kernel above is 27
+// workgroups; the longest (row block 26) chains 4 tiles x 108 K-steps = 432 MFMAs of 64 cycles per wave, 13 us, while 229 CUs idle.
+// Here the unit of work is ONE 16-row tile: a 256-thread workgroup per (panel, row block, tile), its four waves the four K
+// quarters of the row block exactly as above -- 4 x 27 = 108 workgroups per panel, every wave alone on its SIMD with a chain of
+// at most 108 dependent MFMAs, and a PF-deep prefetch of the wave's factor and residual fragments (one 1 KiB load each per
+// K-step pair; the streams are short, so the loads in flight, not the matrix pipe, set the time).
+// Every y element is accumulated in the throughput kernel's order (K quarters sequentially in the MFMA accumulator, quarters
+// added in LDS, tile_chi2_share), the tile shares go to `partial4[panel][row block][tile][walker]`, and the workgroup that
+// arrives last for a panel adds tiles, then row blocks, in the fixed order of rowblock_share + the row-block loop above: a walker's
+// result is BIT-IDENTICAL to the throughput kernel's (tests/test_gpu_parity.py::test_config2_batch_invariance).
+// Grid: blockIdx.x = panel * units_pad + unit, units_pad a multiple of 8 so that the panels of one (row block, tile) land on the
+// same XCD and share its factor fragments in that L2; units in descending row-block order (longest chains first); over a
+// sequence of small calls unit u stays on XCD u % 8, whose 4 MB L2 keeps its eighth of the 11.8 MB factor.
+// ------------------------------------------------------------------------------------------------
+#ifdef CF_TRSM_STAMPS
+__device__ unsigned long long cf_small_stamps[128 * 4 * 8];  // [unit][wave][phase] of panel 0; phase 6, 7: wall_clock64 at entry / exit
+extern "C" int cf_debug_small_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cf_small_stamps), sizeof(cf_small_stamps));
+}
+#define CF_SSTAMP(k) \
+  if (px == 0 && lane == 0 && unit < 128) cf_small_stamps[(unit * 4 + g) * 8 + (k)] = __builtin_amdgcn_s_memtime()
+#define CF_SWALL(k) \
+  if (px == 0 && lane == 0 && unit < 128) cf_small_stamps[(unit * 4 + g) * 8 + (k)] = wall_clock64()
+#else
+#define CF_SSTAMP(k)
+#define CF_SWALL(k)
+#endif
+
+template <int PF>
+__global__ void __launch_bounds__(256)
+tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict__ theta, int64_t W,
+                      const double* __restrict__ delta, double* partial4, unsigned int* arrivals,
+                      const double* __restrict__ chi2_extra, double* __restrict__ out, int out_kind,
+                      unsigned long long* nonfinite, double* __restrict__ chi2_sn_out, int units_pad) {
+  __shared__ __align__(16) d4 part[4][64];  // [K quarter][lane] partial tile: 8 KB
+  __shared__ double sh[4096];               // the panel's shares in the last arriver: [row block][tile][walker]
+  __shared__ unsigned int arrived_before;
+  const int n_ld = d.n_ld, n_rb = pk.n_rowblocks;
+  const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+  const int col = lane & 15, kq = lane >> 4;
+  const int unit = (int)blockIdx.x % units_pad, px = (int)blockIdx.x / units_pad;
+  if (unit >= 4 * n_rb) return;
+  const int rb = n_rb - 1 - (unit >> 2), j = unit & 3;
+  const int64_t w0 = (int64_t)px * 16;
+  if (w0 >= W) return;
+  const int nq = 2 * (rb + 1);  // K-step pairs per wave
+  CF_SSTAMP(0);
+  CF_SWALL(6);
+  // K-step pair q of this wave's quarter: factor fragment of tile j (1 KiB, stride 4 KiB), residual fragment (16 B per lane)
+  const d2* A = pk.frags + pk.off[rb * 4 + g] * 64 + j * 64 + lane;
+  const d2* Bq = reinterpret_cast<const d2*>(delta) + ((w0 + col) * (int64_t)n_ld + 8 * (int64_t)g * nq + 2 * kq) / 2;
+  d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+  d2 a[PF], bf[PF];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int p = 0; p < PF; ++p) {  // a short stream (nq < PF) re-reads its last pair: nothing outside the wave's range is touched
+    const int q = p < nq ? p : nq - 1;
+    a[p] = A[q * 256];
+    bf[p] = Bq[q * 4];
+    __builtin_amdgcn_sched_barrier(0);  // stage 0 must be the oldest load
+  }
+  A += PF * 256;
+  Bq += PF * 4;
+  const int n_groups = nq / PF, rem = nq - n_groups * PF;
+  for (int grp = 0; grp + 1 < n_groups; ++grp) {  // branch-free body, as in the throughput kernel
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      acc = mfma_f64(a[p].x, bf[p].x, acc);
+      acc = mfma_f64(a[p].y, bf[p].y, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      a[p] = A[p * 256];
+      bf[p] = Bq[p * 4];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    A += PF * 256;
+    Bq += PF * 4;
+  }
+  if (n_groups > 0) {  // last full group: only the nq % PF pairs of the tail are still to be fetched
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      acc = mfma_f64(a[p].x, bf[p].x, acc);
+      acc = mfma_f64(a[p].y, bf[p].y, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      if (p < rem) {
+        a[p] = A[p * 256];
+        bf[p] = Bq[p * 4];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < PF - 1; ++p)
+    if (p < rem) {
+      acc = mfma_f64(a[p].x, bf[p].x, acc);
+      acc = mfma_f64(a[p].y, bf[p].y, acc);
+    }
+  CF_SSTAMP(1);
+  part[g][lane] = acc;
+  lds_barrier();
+  CF_SSTAMP(2);
+  // hand-off as in the throughput kernel (agent-scope write-through stores, vmcnt(0), one relaxed agent-scope add, the last
+  // arriver's acquire fence); one counter per panel counts the 4 n_rb (row block, tile) workgroups
+  double* mine = partial4 + (int64_t)px * (4 * n_rb * 16);
+  if (g == 0) {
+    const double v = tile_chi2_share(part[0][lane], part[1][lane], part[2][lane], part[3][lane]);
+    if (lane < 16) __hip_atomic_store(&mine[(rb * 4 + j) * 16 + lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0)
+      arrived_before = __hip_atomic_fetch_add(&arrivals[px], 1u, CF_ARRIVE_ORDER, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  lds_barrier();
+  CF_SSTAMP(3);
+  CF_SWALL(7);
+  if (arrived_before != 4u * (unsigned)n_rb - 1u) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (tid == 0) __hip_atomic_store(&arrivals[px], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int n_sh = 4 * n_rb * 16;
+  const bool via_lds = n_sh <= 4096;
+  if (via_lds) {
+    for (int idx = tid; idx < n_sh; idx += 256) sh[idx] = __hip_atomic_load(&mine[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    lds_barrier();
+  }
+  if (tid < 16 && w0 + tid < W) {
+    const int64_t w = w0 + tid;
+    double c2 = 0.0;
+    for (int r = 0; r < n_rb; ++r) {
+      double t[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        t[k] = via_lds ? sh[(r * 4 + k) * 16 + tid]
+                       : __hip_atomic_load(&mine[(r * 4 + k) * 16 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      c2 += rowblock_share(t[0], t[1], t[2], t[3]);
+    }
+    if (chi2_sn_out) chi2_sn_out[w] = c2;  // the SN block alone (cf_eval_parts)
+    if (chi2_extra) c2 += chi2_extra[w];
+    out[w] = finalize_value(d, theta + w * d.ndim, c2, out_kind, nonfinite);
+  }
+  CF_SSTAMP(4);
+}
+#define CF_INSTANTIATE_TRIGEMM_SMALL(PF)                                                                                     \
+  template __global__ void tri_gemm_small_kernel<PF>(cf_dev_desc, cf_dev_invpack, const double*, int64_t, const double*, double*, \
+                                                     unsigned int*, const double*, double*, int, unsigned long long*, double*, int);
+CF_INSTANTIATE_TRIGEMM_SMALL(4)
+CF_INSTANTIATE_TRIGEMM_SMALL(8)
+CF_INSTANTIATE_TRIGEMM_SMALL(16)
 
 // ------------------------------------------------------------------------------------------------
 // Likelihoods without an SN block: only the epilogue.
@@ -1690,11 +1981,13 @@ extern "C" __global__ void interp_kernel(const double* __restrict__ xq, int64_t 
 }
 
 // Self-test hook: the in-kernel log10 on arbitrary inputs (tests/test_gpu_parity.py checks its ulp error).
-// mode 0: log10_pos; mode 1: log10_tab with the table at `tab`
+// mode 0: log10_pos; mode 1: log10_tab with the table at `tab`; mode 2: exp_tab with the 2^(j/64) table at `tab`
 extern "C" __global__ void log10_selftest_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ out, int mode,
                                                  const cf_d2* __restrict__ tab) {
   const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (k < n) out[k] = mode == 0 ? log10_pos(x[k]) : log10_tab(x[k], reinterpret_cast<const d2*>(tab));
+  if (k >= n) return;
+  if (mode == 2) out[k] = exp_tab(x[k], reinterpret_cast<const double*>(tab));
+  else out[k] = mode == 0 ? log10_pos(x[k]) : log10_tab(x[k], reinterpret_cast<const d2*>(tab));
 }
 
 // Copy right-hand sides b[nrhs][n] into the padded residual layout Delta[nrhs_pad][n_pad].

@@ -346,6 +346,16 @@ class LikelihoodEngine:
                 out.append((float(t[0]), float(t[1])))
         return out
 
+    def kernel_ms3(self):
+        """[(walker_kernel_ms, small_blocks_ms, solve_ms), ...] for every evaluation still in the timing ring."""
+        lib = L.lib()
+        out = []
+        t = (C.c_float * 3)()
+        for call in range(lib.cf_timed_calls(self._h)):
+            if lib.cf_kernel_ms3(self._h, call, C.byref(t)) == 0:
+                out.append((float(t[0]), float(t[1]), float(t[2])))
+        return out
+
     def last_kernel_ms(self):
         t = (C.c_float * 2)()
         L.check(L.lib().cf_last_kernel_ms(self._h, C.byref(t)))

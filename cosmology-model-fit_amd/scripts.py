@@ -29,6 +29,7 @@ class Recipe:
     physical: bool = False               # E(z) from physical densities + radiation + massive neutrinos (needs `comp`)
     fde: str = "lcdm"                    # "lcdm" | "wcdm" | "thawing" | "cpl"
     comp: Optional[str] = None           # cmb_data compression: "PLANCK_ACT" | "EARLY_LCDM" | "PLANCK"
+    omh2: bool = False                   # the "Om" slot holds omega_m = Omega_m h^2 (bao/desi_des5y_omh2.py:31-32)
     scale: dict = field(default_factory=dict)    # slot -> factor (sampler parameter h: {"H0": 100})
     fixed: dict = field(default_factory=dict)    # slot -> constant (r_d = 147.09)
     # SN: z_turn of the velocity step (None: no "v" slot or all weights +1), vel_mult: the multiplicative z_cosmo form
@@ -103,6 +104,19 @@ RECIPES = {
     "bao/desi_union3_obh2_theta_star.py": Recipe(
         _T5, physical=True, comp="PLANCK_ACT", sn=dict(z_turn=0.2), bao=dict(dh_exact=True, rd="fit"),
         cmb=dict(components=(1, 2), sub="cov"), cite="(l_A, omega_b) with inv(covariance[1:, 1:]) (:17,128)"),
+    "bao/desi_des5y_omh2.py": Recipe(
+        ("offset", "rd", "H0", "Om", "v"), omh2=True, sn=dict(z_turn=0.10563), bao=dict(dh_exact=True, rd="free"),
+        cite="Om = omega_m / h^2 (:31-32), D_H = c / H (:41-42), step at z = 0.10563 (:88); theta :130-134"),
+    "bao/desi_pantheon_rd.py": Recipe(
+        ("offset", "H0", "Om", "rd", "w0"), fde="thawing", sn=dict(z_turn=None), bao=dict(dh_exact=True, rd="free"),
+        bounds=[(-20.0, -19.0), (50.0, 100.0), (0.2, 0.7), (144.0, 150.0), (-1.0, -1 / 3)], gauss=[("rd", 147.14, 0.29)],
+        cite="theta = (M, H0, Om, rd, w0), no velocity term (:74-76), bounds :79-87, Planck + ACT prior on r_d (:117)"),
+    "bao/desi_union3_omh2.py": Recipe(
+        ("offset", "rd", "H0", "Om", "v"), omh2=True, sn=dict(z_turn=0.2), bao=dict(dh_exact=True, rd="free"),
+        cite="Om = omega_m / (H0 / 100)^2 (:29-31), step at z = 0.2 (:73), explicit inverse of the 22-bin covariance (:11)"),
+    "bao/desi_union3_rd.py": Recipe(
+        ("offset", "rd", "H0", "Om", "v"), sn=dict(z_turn=0.2), bao=dict(dh_exact=False, rd="free"),
+        cite="PCHIP D_H (:48-49), step at z = 0.2 (:78)"),
     "ohd/cc_cmb.py": Recipe(
         ("H0", "obh2", "och2", "fcc"), physical=True, comp="PLANCK_ACT", cmb=dict(), cc=dict(), z_max_of=("cc",),
         bounds=[(63.0, 73.0), (0.0210, 0.0235), (0.05, 0.30), (0.30, 2.75)], prior_normalised=False,
@@ -169,7 +183,7 @@ class Joint(_Base):
         self.z_max = max(z_tops[b] for b in r.z_max_of) + r.z_pad
         self.engine = LikelihoodEngine(
             ndim=self.ndim, z_max=self.z_max, n_grid=N_GRID, ez_model=L.CF_EZ_PHYSICAL if r.physical else L.CF_EZ_LATE_FLAT,
-            fde=FDE_BY_NAME[r.fde], params=params, bounds=self.bounds, prior_normalised=r.prior_normalised,
+            fde=FDE_BY_NAME[r.fde], params=params, bounds=self.bounds, prior_normalised=r.prior_normalised, om_mode=int(r.omh2),
             gauss=[(idx[s], m, sg) for s, m, sg in r.gauss], chi2_gauss=[(idx[s], m, sg) for s, m, sg in r.chi2_gauss],
             device=device, devices=devices, solve_mode=solve_mode_of(solve), **kw)
 

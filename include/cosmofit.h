@@ -375,6 +375,8 @@ int cf_enable_timing(cf_handle* h, int slots);
 int cf_set_timing_stride(cf_handle* h, int stride);
 int64_t cf_timed_calls(cf_handle* h);
 int cf_kernel_ms(cf_handle* h, int64_t call, float t[2]);
+/* the same with the per-walker stage split: t[0] = walker_kernel, t[1] = small-block (+ growth) kernels, t[2] = solve kernel */
+int cf_kernel_ms3(cf_handle* h, int64_t call, float t[3]);
 int cf_last_kernel_ms(cf_handle* h, float t[2]);
 
 /* ---- stand-alone operators with the reference's signatures (host buffers) ---- */
@@ -404,6 +406,8 @@ int cf_selftest_invpack_host(const double* L, int64_t n, int64_t ld, const doubl
  * table-driven routine of the production SN loop (absolute error ~2e-16 max(1, |log10 x|)). */
 int cf_selftest_log10(const double* x, int64_t n, double* out);
 int cf_selftest_log10_tab(const double* x, int64_t n, double* out);
+/* The table-driven exp of the wCDM / CPL table build (|x| < ~700, no special cases): out[k] = exp(x[k]), <= 1.5 ulp. */
+int cf_selftest_exp_tab(const double* x, int64_t n, double* out);
 
 /* ---- Device-resident ensemble moves (the sampler side of sn/pantheon.py:108-125: emcee with KDEMove 30 % +
  * DEMove 70 %, StretchMove by default elsewhere).  All pointers are device pointers on the current device, all

@@ -951,6 +951,18 @@ GENERIC = {
     "ohd_cc_union3": ("ohd.cc_union3", None, ("z_cmb", "z_hel", "mu_vals", "cov_matrix_sn"), None,
                       ("z_cc_vals", "H_cc_vals", "cov_matrix_cc"),
                       [(0.05, 3.35), (-1.0, 1.0), (40.0, 95.0), (0.1, 0.7), (-900, 900)], [1.0, 0.0, 68.0, 0.31, -100.0]),
+    # the four members of the free-r_d / omega_m family that round 2 served on the strength of bao_desi_des5y_rd.npz alone
+    "bao_desi_des5y_omh2": ("bao.desi_des5y_omh2", "dovekie", ("z_cmb", "z_hel", "mu_values", "cov_matrix_sn"),
+                            lambda m: (m.bao, m.cov_matrix_bao), None,
+                            [(-0.5, 0.5), (120.0, 165.0), (50.0, 90.0), (0.138, 0.148), (-5.5, 2.5)], [0.0, 147.09, 68.0, 0.1430, 0.5]),
+    "bao_desi_pantheon_rd": ("bao.desi_pantheon_rd", "pantheon", ("z_cmb", "z_hel", "mb_vals", "cov_matrix_sn"),
+                             lambda m: (m.data, m.bao_cov_matrix), None, "bounds", [-19.4, 68.0, 0.31, 147.14, -0.85]),
+    "bao_desi_union3_omh2": ("bao.desi_union3_omh2", None, ("z_cmb", "z_hel", "mu_vals", "sn_cov_matrix"),
+                             lambda m: (m.bao_data, m.bao_cov_matrix), None,
+                             [(-1.0, 1.0), (120.0, 160.0), (50.0, 85.0), (0.138, 0.148), (-12.0, 5.0)], [0.0, 147.09, 68.0, 0.1430, -1.0]),
+    "bao_desi_union3_rd": ("bao.desi_union3_rd", None, ("z_cmb", "z_hel", "mu_vals", "cov_matrix_sn"),
+                           lambda m: (m.bao, m.bao_cov_matrix), None,
+                           [(-1.0, 1.0), (144.0, 150.0), (50.0, 85.0), (0.1, 0.6), (-12.0, 5.0)], [0.0, 147.09, 68.0, 0.31, -1.0]),
     "sn_union3_1_cmb": ("sn.union3_1_cmb", None, ("z_cmb", "z_hel", "mu_vals", "cov_matrix_sn"), None, None,
                         [(-1, 1), (60, 75), (0.01, 0.03), (0.01, 0.25), (-9, 9)], [0.0, 67.5, 0.0224, 0.119, 0.5]),
 }
@@ -996,7 +1008,11 @@ def case_generic(name):
             try:
                 out["theory"] = np.array([m.bao_theory(data["z"], _qty_codes(data), t) for t in thetas[-3:]])
             except TypeError:  # (z, qty, params, DM_interp) signature
-                out["theory"] = np.array([m.bao_theory(data["z"], _qty_codes(data), t, m.DM_grid(t)) for t in thetas[-3:]])
+                try:
+                    out["theory"] = np.array([m.bao_theory(data["z"], _qty_codes(data), t, m.DM_grid(t)) for t in thetas[-3:]])
+                except TypeError:  # (z, qty, params, DM at the BAO redshifts): bao/desi_pantheon_rd.py:57-66,100
+                    out["theory"] = np.array([m.bao_theory(data["z"], _qty_codes(data), t,
+                                                           m.interp_hermite(data["z"], m.z_grid, *m.DM_grid(t))) for t in thetas[-3:]])
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(name + ".npz chi2[-3:] =", out["chi2"][-3:], "logl[-1] =", out["logl"][-1])
 

@@ -190,6 +190,8 @@ def test_config3_full_batch_vs_c_oracle(gpu, des5y):
     rel = np.abs(got - want) / np.abs(want)
     assert rel.max() < RTOL, f"max rel diff {rel.max():.3e}"
     np.testing.assert_array_equal(lk.log_likelihood(theta[:777]), got[:777])  # batch-size invariance
+    for W in (1, 16, 20, 64):  # the small-batch solve kernel: the same bits as inside the large batch
+        np.testing.assert_array_equal(lk.log_likelihood(theta[:W]), got[:W])
 
 
 def test_config3_latency_mode_agrees_with_blocked_solve(gpu, des5y):

@@ -168,7 +168,7 @@ def test_config2_batch_invariance(config2):
     np.testing.assert_array_equal(lk.chi_squared(theta[perm]), full[perm])
     halves = np.concatenate([lk.chi_squared(theta[:2048]), lk.chi_squared(theta[2048:])])
     np.testing.assert_array_equal(halves, full)
-    for W in (1, 2, 15, 16, 17, 31, 33):  # ragged panels
+    for W in (1, 2, 15, 16, 17, 31, 33, 48, 63, 64, 65, 100, 256, 257):  # ragged panels; the small-batch solve kernel (<= 64) and the throughput kernel
         np.testing.assert_array_equal(lk.chi_squared(theta[:W]), full[:W])
     assert lk.chi_squared(theta[:0]).shape == (0,)
 
@@ -370,6 +370,22 @@ def test_in_kernel_log10_is_within_one_ulp(gpu):
     assert ulp.max() <= 1.0, f"max error {ulp.max()} ulp"
     assert out[x == 1.0][0] == 0.0 and out[x == 10.0][0] == 1.0
     assert out[-5] == -np.inf and np.isnan(out[-4]) and out[-3] == np.inf and np.isnan(out[-2])
+
+
+def test_table_build_exp_is_within_two_ulp(gpu):
+    """exp_tab: the table-driven exp of the wCDM / CPL dark-energy density in walker_kernel's table build; its argument is
+    3 (1 + w0 + wa) ln(1 + z) - 3 wa z / (1 + z), |x| < 40 for any prior box of the reference's scripts."""
+    import ctypes as C
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(-40, 40, 400000), rng.uniform(-1e-3, 1e-3, 50000), rng.uniform(-700, 700, 50000),
+                        [0.0, np.log(2) / 64, -np.log(2) / 128, 1.0, -1.0, 25.0]])
+    out = np.empty_like(x)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    gpu._lib.check(gpu.lib().cf_selftest_exp_tab(p(x), x.size, p(out)))
+    ref = np.exp(x.astype(np.longdouble))
+    ulp = np.abs(out - ref) / np.spacing(np.exp(x))
+    assert float(ulp.max()) <= 2.0, f"max error {float(ulp.max())} ulp"
+    assert out[x == 0.0][0] == 1.0
 
 
 def test_production_loop_log10_absolute_error(gpu):

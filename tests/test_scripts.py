@@ -1,5 +1,5 @@
 """
-The recipe-driven mirrors (cosmology-model-fit_amd/scripts.py): 19 further reference scripts that are plain combinations of the SN /
+The recipe-driven mirrors (cosmology-model-fit_amd/scripts.py): 23 further reference scripts that are plain combinations of the SN /
 BAO / compressed-CMB / cosmic-chronometer blocks, each against the fixture the script itself produced
 (tests/golden/generate_golden.py, GENERIC table).
 
@@ -30,6 +30,10 @@ FIXTURE_OF = {
     "bao/desi_des5y_obh2_theta_star.py": "bao_desi_des5y_obh2_theta_star",
     "bao/desi_pantheon_obh2_theta_star.py": "bao_desi_pantheon_obh2_theta_star",
     "bao/desi_union3_obh2_theta_star.py": "bao_desi_union3_obh2_theta_star",
+    "bao/desi_des5y_omh2.py": "bao_desi_des5y_omh2",
+    "bao/desi_pantheon_rd.py": "bao_desi_pantheon_rd",
+    "bao/desi_union3_omh2.py": "bao_desi_union3_omh2",
+    "bao/desi_union3_rd.py": "bao_desi_union3_rd",
     "ohd/cc_cmb.py": "ohd_cc_cmb",
     "ohd/cc_pantheon.py": "ohd_cc_pantheon",
     "ohd/cc_union3.py": "ohd_cc_union3",
@@ -94,7 +98,7 @@ def oracle_of(recipe, g):
     if "z_max" in g:
         assert z_max == float(g["z_max"])  # the script's own grid end
     return onp.Likelihood(ndim=len(recipe.theta), z_max=z_max, ez_model=onp.EZ_PHYSICAL if recipe.physical else onp.EZ_LATE_FLAT,
-                          fde=FDE[recipe.fde], bounds=None if recipe.bounds is None else np.asarray(recipe.bounds, float),
+                          fde=FDE[recipe.fde], om_mode=int(recipe.omh2), bounds=None if recipe.bounds is None else np.asarray(recipe.bounds, float),
                           prior_normalised=recipe.prior_normalised, gauss=[(idx[s], m, sg) for s, m, sg in recipe.gauss],
                           chi2_gauss=[(idx[s], m, sg) for s, m, sg in recipe.chi2_gauss], **kw)
 

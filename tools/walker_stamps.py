@@ -20,8 +20,11 @@ else:  # the joint likelihood of bao/desi_cmb_des5y.py on the committed fixture 
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "bao_desi_cmb_des5y.npz"))
     A = 0.01 * np.random.default_rng(0).standard_normal((g["sigma"].size, 40))
     chol = np.linalg.cholesky(np.diag(g["sigma"] ** 2) + A @ A.T)
-    lk = amd.likelihoods.DesiCmbDes5y(g["z_cmb"], g["z_hel"], g["obs"], None, g["bao_z"], g["bao_val"], g["bao_qty"], g["bao_inv_cov"], chol=chol)
-    box = np.array([(-0.5, 0.5), (60.0, 75.0), (0.010, 0.030), (0.01, 0.25), (-4.5, 4.5)])
+    fde = os.environ.get("FDE", "lcdm")
+    lk = amd.likelihoods.DesiCmbDes5y(g["z_cmb"], g["z_hel"], g["obs"], None, g["bao_z"], g["bao_val"], g["bao_qty"], g["bao_inv_cov"], chol=chol,
+                                      fde=fde)
+    box = [(-0.5, 0.5), (60.0, 75.0), (0.010, 0.030), (0.01, 0.25), (-4.5, 4.5)] + ([(-3.0, 1.0), (-3.0, 2.0)] if fde == "cpl" else [])
+    box = np.array(box)
     th = syn.walkers(box, 4096, seed=1)
     for _ in range(3):
         lk.log_likelihood(th)
