@@ -79,7 +79,7 @@ class cf_desc(C.Structure):
         ("n_fs8", C.c_int32), ("fs8_steps", C.c_int32),
         ("fs8_z", C.c_void_p), ("fs8_val", C.c_void_p), ("fs8_inv_cov", C.c_void_p), ("fs8_fid", C.c_void_p),
         ("logl_const", C.c_double), ("fs8_a_init", C.c_double),
-        ("sn_vel_mode", C.c_int32), ("cc_f_mode", C.c_int32), ("prior_norm_mode", C.c_int32), ("_pad6", C.c_int32),
+        ("sn_vel_mode", C.c_int32), ("cc_f_mode", C.c_int32), ("prior_norm_mode", C.c_int32), ("fs8_n_agrid", C.c_int32),
     ]
 
 

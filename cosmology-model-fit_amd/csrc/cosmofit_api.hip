@@ -34,7 +34,7 @@ template <int MODEL, int FDE>
 __global__ void walker_kernel(cf_dev_desc d, const double* theta, int64_t W, double* delta, double* dm_out, double* mucorr_out,
                               d2* bao_nodes, d2* table_out);
 template <int MODEL, int FDE>
-__global__ void walker_fast_kernel(cf_walker_args d, const double* theta, int64_t W, double* delta, d2* bao_nodes);
+__global__ void walker_fast_kernel(cf_walker_args d, const double* theta, int64_t W, double* delta, d2* bao_nodes, double* theta_copy);
 template <int MODEL, int FDE>
 __global__ void small_blocks_kernel(cf_dev_desc d, const double* theta, int64_t W, const d2* bao_nodes, double* chi2_extra,
                                     double* blocks_out, double* bao_out);
@@ -47,7 +47,7 @@ __global__ void hz_kernel(cf_dev_desc d, const double* theta, const double* z, i
   extern template __global__ void growth_kernel<M, F, C>(cf_dev_desc, const double*, int64_t, const d2*, double*, int, double*, double*);
 #define CF_DECLARE_WALKER(M, F)                                                                                            \
   extern template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*, d2*); \
-  extern template __global__ void walker_fast_kernel<M, F>(cf_walker_args, const double*, int64_t, double*, d2*);         \
+  extern template __global__ void walker_fast_kernel<M, F>(cf_walker_args, const double*, int64_t, double*, d2*, double*);         \
   extern template __global__ void small_blocks_kernel<M, F>(cf_dev_desc, const double*, int64_t, const d2*, double*,       \
                                                             double*, double*);                                            \
   extern template __global__ void hz_kernel<M, F>(cf_dev_desc, const double*, const double*, int64_t, double*);             \
@@ -62,7 +62,7 @@ static walker_fn pick_walker(int model, int fde) {
       {walker_kernel<1, 0>, walker_kernel<1, 1>, walker_kernel<1, 2>, walker_kernel<1, 3>}};
   return table[model][fde];
 }
-typedef void (*walker_fast_fn)(cf_walker_args, const double*, int64_t, double*, d2*);
+typedef void (*walker_fast_fn)(cf_walker_args, const double*, int64_t, double*, d2*, double*);
 static walker_fast_fn pick_walker_fast(int model, int fde) {
   static const walker_fast_fn table[2][4] = {
       {walker_fast_kernel<0, 0>, walker_fast_kernel<0, 1>, walker_fast_kernel<0, 2>, walker_fast_kernel<0, 3>},
@@ -282,7 +282,7 @@ struct PinnedBuf {
 };
 
 #ifndef CF_ZEROCOPY_DEFAULT
-#define CF_ZEROCOPY_DEFAULT 16384
+#define CF_ZEROCOPY_DEFAULT 4096  // walkers; beyond, in-place access to the pinned block is no faster than two copy commands (profiles/r03_zerocopy_threshold.txt)
 #endif
 #define CF_SMALL_MAX_PANELS 16  // largest batch of the small-batch solve kernel: 256 walkers (the default switch is lower)
 #ifndef CF_SMALL_DEFAULT
@@ -330,6 +330,7 @@ struct cf_handle {
   DevBuf theta, out, delta, ypk, chi2_extra, nonfinite;
   DevBuf fs8_z, fs8_val, fs8_inv_cov, fs8_fid, fs8_step_of, fs8_order, fs8_tab, fs8_pts;
   DevBuf bao_nodes, bao_base;  // [max_walkers][n_bao][CF_BAO_NODES] table nodes for small_blocks_kernel; first node per datum
+  bool theta_on_host = false;     // set around a zero-copy evaluation: theta is the pinned staging block (reads cross the host link)
   bool has_small_blocks = false;  // BAO and / or CMB block present
   bool has_growth = false;        // growth-rate block present
   int64_t max_walkers = 0;
@@ -489,6 +490,8 @@ static int validate_desc(const cf_desc* c) {
     if (!c->fs8_z || !c->fs8_val || !c->fs8_inv_cov || !c->fs8_fid) return fail(CF_ERR_INVALID, "cf_create: growth-rate arrays must not be null");
     if (!(c->fs8_a_init > 0.0 && c->fs8_a_init < 1.0)) return fail(CF_ERR_INVALID, "cf_create: fs8_a_init must be in (0, 1)");
     if (c->fs8_steps < 0 || c->fs8_steps > 2048) return fail(CF_ERR_INVALID, "cf_create: fs8_steps must be in 0..2048");
+    if (c->fs8_n_agrid != 0 && (c->fs8_n_agrid < 4 || c->fs8_n_agrid > (1 << 20)))
+      return fail(CF_ERR_INVALID, "cf_create: fs8_n_agrid must be 0 (direct read-out) or the number (>= 4) of points of the scripts' a-grid");
     if (c->n_grid < CF_BAO_NODES) return fail(CF_ERR_INVALID, "cf_create: a growth-rate block needs n_grid >= 6");
     for (int k = 0; k < c->n_fs8; ++k)
       if (!(1.0 / (1.0 + c->fs8_z[k]) >= c->fs8_a_init) || c->fs8_z[k] < 0.0)
@@ -518,7 +521,27 @@ struct HostPrep {
 };
 
 // Growth-rate data points for growth_kernel: the RK4 step that contains ln a_k, the data in step order (ascending a), and per
-// datum in that order the cubic-Hermite weights of ln a_k inside its step, a_k and the massive-neutrino density at z_k.
+// datum in that order a record of CF_FS8_REC doubles:
+//   [0..3]  cubic-Hermite weights {h00, h h10, h01, h h11} of ln a_k inside its RK4 step (direct read-out, fs8_n_agrid = 0)
+//   [4] a_k   [5] massive-neutrino density at z_k   [6] li   [7] flags (1: the window starts at the grid's first node, 2: ends at its last)
+//   [8..23] the same Hermite weights for the FOUR nodes x_0..x_3 of the scripts' logarithmic a-grid around a_k
+//   [24..27] x_0..x_3   [28..31] the RK4 steps that contain ln x_0 .. ln x_3
+// The scripts do not read delta' at a_k from the ODE solution directly: they sample it on a_span = np.logspace(log10 a_init, 0,
+// fs8_n_agrid) and interpolate with interp_pchip (fs8/fs8.py:79-98).  With fs8_n_agrid > 0 the kernel does the same: delta' at
+// the four grid nodes around a_k (nodes i - 1 .. i + 2 of the interval x_i < a_k <= x_{i+1}, shifted inside the grid at its
+// ends; li = index of x_i in the window), then the Fritsch-Carlson slopes at x_i, x_{i+1} and the cubic of interpolator.py:5-108.
+#define CF_FS8_REC 32
+static void fs8_hermite_weights(double x0, double hstep, int steps, double ln_a, int& step, double* w) {
+  int i = (int)((ln_a - x0) / hstep);
+  i = i < 0 ? 0 : (i > steps - 1 ? steps - 1 : i);
+  const double t = (ln_a - (x0 + i * hstep)) / hstep, t2 = t * t, t3 = t2 * t;
+  step = i;
+  w[0] = 2 * t3 - 3 * t2 + 1;
+  w[1] = (t3 - 2 * t2 + t) * hstep;
+  w[2] = -2 * t3 + 3 * t2;
+  w[3] = (t3 - t2) * hstep;
+}
+
 static void fs8_points(const cf_dev_desc& d, const double* zs, int n, std::vector<int32_t>& step_of, std::vector<int32_t>& order,
                        std::vector<double>& pts) {
   const double x0 = std::log(d.fs8_a_init), hstep = -x0 / d.fs8_steps;
@@ -531,22 +554,42 @@ static void fs8_points(const cf_dev_desc& d, const double* zs, int n, std::vecto
   std::sort(so.begin(), so.end());
   step_of.resize((size_t)n);
   order.resize((size_t)n);
-  pts.assign((size_t)n * 8, 0.0);
+  pts.assign((size_t)n * CF_FS8_REC, 0.0);
+  // np.logspace(lo, 0, na) = 10 ** np.linspace(lo, 0, na): node k at 10 ** (lo + k * (-lo / (na - 1))), the last one at 10 ** 0
+  const int na = d.fs8_n_agrid;
+  const double lo = std::log10(d.fs8_a_init), dl = na > 1 ? -lo / (na - 1) : 0.0;
+  auto node = [&](int k) { return k >= na - 1 ? 1.0 : std::pow(10.0, lo + k * dl); };
   for (int s = 0; s < n; ++s) {
-    const int i = step_of[s] = so[s].first, k = order[s] = so[s].second;
+    const int k = order[s] = so[s].second;
     const double zp1 = 1.0 + zs[k], a = 1.0 / zp1;
-    const double t = (std::log(a) - (x0 + i * hstep)) / hstep, t2 = t * t, t3 = t2 * t;
-    double* p = &pts[(size_t)s * 8];
-    p[0] = 2 * t3 - 3 * t2 + 1;
-    p[1] = (t3 - 2 * t2 + t) * hstep;
-    p[2] = -2 * t3 + 3 * t2;
-    p[3] = (t3 - t2) * hstep;
+    double* p = &pts[(size_t)s * CF_FS8_REC];
+    int st;
+    fs8_hermite_weights(x0, hstep, d.fs8_steps, std::log(a), st, p);
+    step_of[s] = st;
     p[4] = a;
     if (d.ez_model == CF_EZ_PHYSICAL) {  // cmb/data_planck_act_compression.py:53-66
       const double r = d.nu_m0 / zp1, mz_sq = r * r;
       double ws = 0.0;
       for (int q = 0; q < 5; ++q) ws += std::sqrt(d.nu_qs_sq[q] + mz_sq) * d.nu_ws[q];
       p[5] = zp1 * zp1 * zp1 * zp1 * ws / d.nu_rho0;
+    }
+    if (na >= 4) {
+      // interval of interp_pchip: i = searchsorted_left(x, a) - 1, clamped into the grid (outside it the interpolant is the end value,
+      // which the cubic also returns at t = 0 / t = 1)                                   interpolator.py:80-94
+      int i = (int)((std::log10(a) - lo) / dl);
+      i = i < 0 ? 0 : (i > na - 2 ? na - 2 : i);
+      while (i > 0 && node(i) >= a) --i;
+      while (i < na - 2 && node(i + 1) < a) ++i;
+      const int j0 = i - 1 < 0 ? 0 : (i - 1 > na - 4 ? na - 4 : i - 1);
+      p[6] = (double)(i - j0);
+      p[7] = (double)((j0 == 0 ? 1 : 0) | (j0 + 3 == na - 1 ? 2 : 0));
+      for (int m = 0; m < 4; ++m) {
+        const double x = node(j0 + m);
+        int sm;
+        fs8_hermite_weights(x0, hstep, d.fs8_steps, x >= 1.0 ? 0.0 : std::log(x), sm, p + 8 + 4 * m);
+        p[24 + m] = x;
+        p[28 + m] = (double)sm;
+      }
     }
   }
 }
@@ -633,9 +676,13 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
   h->has_small_blocks = c->n_bao > 0 || c->cmb_mode != CF_CMB_NONE || c->n_cc > 0;
   h->has_growth = c->n_fs8 > 0;
   d.n_fs8 = c->n_fs8;
-  d.fs8_steps = 256;  // 256 lanes per walker, 1 / 2 / 4 / 8 steps per lane: the request rounded up to 256, 512 (default), 1024, 2048
-  while (d.fs8_steps < (c->fs8_steps > 0 ? c->fs8_steps : 512)) d.fs8_steps *= 2;
+  // 256 lanes per walker, 1 / 2 / 4 / 8 steps per lane: the request rounded up to 256, 512, 1024 (default), 2048.  Measured against
+  // the scripts' own equation integrated to 1e-12 (tools/fs8_parity_probe.py, profiles/r03_fs8_parity.txt): 512 steps leave 4e-9 on
+  // the theory and 1e-8 on chi^2, 2048 steps 5e-11 / 5e-11; the error goes as steps^-4
+  d.fs8_steps = 256;
+  while (d.fs8_steps < (c->fs8_steps > 0 ? c->fs8_steps : 1024)) d.fs8_steps *= 2;
   d.fs8_a_init = c->fs8_a_init;
+  d.fs8_n_agrid = c->fs8_n_agrid;
   d.n_aux = c->n_bao + c->n_fs8;
   d.cpl_wall = c->cpl_wall;
   d.logl_const = c->logl_const;
@@ -1209,10 +1256,15 @@ static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_
   if (walker_work) {
     // skewed {cum, dh} table: one spare 16-byte slot per 2^chunk_shift nodes
     const size_t lds = ((size_t)d.n_grid + (d.n_grid >> d.chunk_shift) + 2) * 16;
-    if (!dm_out && !mucorr_out && walker_fast_ok(d))  // the production form: lean kernel arguments, theta row across the lanes
+    if (!dm_out && !mucorr_out && walker_fast_ok(d)) {  // the production form: lean kernel arguments, theta row across the lanes
+      // a zero-copy evaluation reads theta from the pinned host block: the walker kernel leaves a copy of each row in device
+      // memory and every later kernel of the evaluation (small blocks, growth, the solve's prior / output epilogue) reads THAT --
+      // the epilogue's dependent theta reads were microseconds each across the host link
+      double* th_copy = h->theta_on_host ? h->theta.as<double>() + off * d.ndim : nullptr;
       hipLaunchKernelGGL(pick_walker_fast(d.ez_model, d.fde), dim3((unsigned)Wc), dim3(512), lds, st, walker_args_of(d), th, Wc, delta,
-                         bao_nodes);
-    else
+                         bao_nodes, th_copy);
+      if (th_copy) th = th_copy;
+    } else
       hipLaunchKernelGGL(pick_walker(d.ez_model, d.fde), dim3((unsigned)Wc), dim3(512), lds, st, d, th, Wc, delta, dm_out, mucorr_out,
                          bao_nodes, (d2*)nullptr);
     if (ev) HIP_TRY(hipEventRecord(ev[1], st));  // between walker_kernel and the small-block / growth kernels
@@ -1353,9 +1405,10 @@ static int eval_host_single(cf_handle* h, const double* theta, int64_t W, double
   // path.  CF_ZEROCOPY_MAX = largest such batch (walkers; 0 = always copy).
   static const int64_t zc_max = [] { const char* e = getenv("CF_ZEROCOPY_MAX"); return e ? atoll(e) : (long long)CF_ZEROCOPY_DEFAULT; }();
   if (W <= zc_max) {
-    if ((rc = launch_path(h, (const double*)h->stage_in.p, W, (double*)h->stage_out.p, out_kind, h->stream, nullptr, nullptr,
-                          nullptr, nullptr)))
-      return rc;
+    h->theta_on_host = true;
+    rc = launch_path(h, (const double*)h->stage_in.p, W, (double*)h->stage_out.p, out_kind, h->stream, nullptr, nullptr, nullptr, nullptr);
+    h->theta_on_host = false;
+    if (rc) return rc;
   } else {
     HIP_TRY(hipMemcpyAsync(h->theta.p, h->stage_in.p, (size_t)W * h->d.ndim * 8, hipMemcpyHostToDevice, h->stream));
     if ((rc = launch_path(h, h->theta.as<const double>(), W, h->out.as<double>(), out_kind, h->stream, nullptr, nullptr,
@@ -1520,7 +1573,7 @@ extern "C" int cf_eval_fs8_at(cf_handle* h, const double* theta, const double* z
   HIP_TRY(hipMemcpyAsync(h->theta.p, theta, (size_t)h->d.ndim * 8, hipMemcpyHostToDevice, h->stream));
   const int B = CF_MAX_FS8;
   DevBuf dz, dbase, dstep, dorder, dpts, dval, dinv, dfid, nodes, dout, extra;
-  if (dz.ensure(B * 8) || dbase.ensure(B * 4) || dstep.ensure(B * 4) || dorder.ensure(B * 4) || dpts.ensure(B * 64) ||
+  if (dz.ensure(B * 8) || dbase.ensure(B * 4) || dstep.ensure(B * 4) || dorder.ensure(B * 4) || dpts.ensure(B * CF_FS8_REC * 8) ||
       dval.ensure(B * 8) || dinv.ensure((size_t)B * B * 8) || dfid.ensure(B * 8) ||
       nodes.ensure((size_t)B * CF_BAO_NODES * sizeof(d2)) || dout.ensure(B * 8) || extra.ensure(64))
     return CF_ERR_HIP;
@@ -1543,7 +1596,7 @@ extern "C" int cf_eval_fs8_at(cf_handle* h, const double* theta, const double* z
     HIP_TRY(hipMemcpyAsync(dbase.p, base.data(), (size_t)m * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(dstep.p, step_of.data(), (size_t)m * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(dorder.p, order.data(), (size_t)m * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(dpts.p, pts.data(), (size_t)m * 64, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(dpts.p, pts.data(), (size_t)m * CF_FS8_REC * 8, hipMemcpyHostToDevice, h->stream));
     d.fs8_z = dz.as<const double>(); d.bao_base = dbase.as<const int32_t>(); d.fs8_step_of = dstep.as<const int32_t>();
     d.fs8_order = dorder.as<const int32_t>(); d.fs8_pts = dpts.as<const double>(); d.fs8_val = dval.as<const double>();
     d.fs8_inv_cov = dinv.as<const double>(); d.fs8_fid = dfid.as<const double>();

@@ -97,9 +97,9 @@ struct cf_dev_desc {
   const int32_t* fs8_step_of;  // [n_fs8] RK4 step that contains ln a_k, data sorted by step (ascending a)
   const int32_t* fs8_order;    // [n_fs8] datum index of the k-th entry in that order
   double fs8_a_init;
-  const double* fs8_pts;       // [n_fs8][8] per datum in step order: Hermite weights {h00, h h10, h01, h h11} of ln a_k inside its step, {a_k, nu(z_k), 0, 0}
+  const double* fs8_pts;       // [n_fs8][32] per datum in step order: see fs8_points (cosmofit_api.hip)
   const double* fs8_tab;       // [2 fs8_steps + 1][4] {a, 1 + z, nu(z), nu 3 (1 + w_nu) / (1 + z)} at x = ln a_init (1 - m / (2 steps))
-  int32_t n_aux, pad_aux;       // table-node copies for small_blocks / growth kernels: n_bao BAO data then n_fs8 growth data
+  int32_t n_aux, fs8_n_agrid;   // fs8_n_agrid: points of the scripts' logarithmic a-grid (delta' by PCHIP on it), 0: direct read-out; table-node copies for small_blocks / growth kernels: n_bao BAO data then n_fs8 growth data
   // radiation + massive neutrinos (CF_EZ_PHYSICAL)   cmb/data_planck_act_compression.py:29-66
   double or_h2, omnu_h2, o_gamma_h2, nu_m0, nu_rho0;
   double nu_qs_sq[5], nu_ws[5];

@@ -785,7 +785,7 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
 template <int MODEL, int FDE>
 __global__ void __launch_bounds__(CF_TPB_A, 4)
 walker_fast_kernel(cf_walker_args d, const double* __restrict__ theta, int64_t W, double* __restrict__ delta,
-                   d2* __restrict__ bao_nodes) {
+                   d2* __restrict__ bao_nodes, double* __restrict__ theta_copy) {
   extern __shared__ __align__(16) d2 lds_tab[];
   __shared__ __align__(16) d4 wave_pub[CF_TPB_A / 64];
   __shared__ __align__(16) d2 log_tab[64];
@@ -798,6 +798,7 @@ walker_fast_kernel(cf_walker_args d, const double* __restrict__ theta, int64_t W
   // loads in the order their values are needed: the theta row (the cosmology scalars wait for nothing else), the two small
   // reduction tables, then the theta-independent node tables of the table build
   const ThetaRow th{theta[w * d.ndim + (lane < d.ndim ? lane : 0)]};
+  if (theta_copy && tid < d.ndim) theta_copy[w * d.ndim + tid] = th.v;  // for the later kernels of a zero-copy evaluation
   constexpr bool POWER_LAW = FDE == CF_FDE_WCDM_D || FDE == CF_FDE_CPL_D;
   d2 lt = (d2){0.0, 0.0};
   double et = 0.0;
@@ -1115,6 +1116,42 @@ __device__ __forceinline__ void growth_coef(const cf_dev_desc& d, const WalkerCo
   p = 3.0 - 0.5 * de2 * r;
 }
 
+// interp_pchip (interpolator.py:5-108, exact=False) on a window of four consecutive nodes x0 < x1 < x2 < x3 of a longer grid:
+// the query lies in the interval [x_li, x_{li+1}] (li = 0 only when the window starts at the grid's first node -- flags & 1 --
+// and li = 2 only when it ends at the last -- flags & 2), so the two Fritsch-Carlson slopes it needs are inside the window:
+// interior nodes by the weighted harmonic mean of the neighbouring secants (:25-40), the grid's end nodes by the three-point
+// formula with its sign / overshoot guards (:41-66).
+__device__ __forceinline__ double pchip_window4(double x0, double x1, double x2, double x3, double y0, double y1, double y2, double y3,
+                                                int li, int flags, double xq) {
+  const double x[4] = {x0, x1, x2, x3}, y[4] = {y0, y1, y2, y3};
+  auto interior = [&](int i) {
+    const double hl = x[i] - x[i - 1], hr = x[i + 1] - x[i];
+    const double dl = (y[i] - y[i - 1]) / hl, dr = (y[i + 1] - y[i]) / hr;
+    if (dl != 0.0 && dr != 0.0 && dl * dr > 0.0) {
+      const double w1 = 2.0 * hr + hl, w2 = hr + 2.0 * hl;
+      return (w1 + w2) / (w1 / dl + w2 / dr);
+    }
+    return 0.0;
+  };
+  auto end_point = [&](int i0, int i1, int i2) {  // slope at node i0 from (i0, i1, i2), i0 an end of the GRID
+    const double h0 = fabs(x[i1] - x[i0]), h1 = fabs(x[i2] - x[i1]);
+    const double d0 = (y[i1] - y[i0]) / (x[i1] - x[i0]), d1 = (y[i2] - y[i1]) / (x[i2] - x[i1]);
+    const double e = ((2 * h0 + h1) * d0 - h0 * d1) / (h0 + h1);
+    if (d0 == 0.0 || sgn_d(e) != sgn_d(d0)) return 0.0;
+    if (sgn_d(d0) != sgn_d(d1) && fabs(e) > fabs(3 * d0)) return 3 * d0;
+    return e;
+  };
+  li = li < 0 ? 0 : (li > 2 ? 2 : li);
+  const double s_lo = li == 0 ? ((flags & 1) ? end_point(0, 1, 2) : interior(1)) : interior(li);
+  const double s_hi = li == 2 ? ((flags & 2) ? end_point(3, 2, 1) : interior(2)) : interior(li + 1);
+  const double xa = x[li], h = x[li + 1] - xa;
+  if (xq <= x[0] && (flags & 1)) return y[0];  // clamped outside the grid (:80-85)
+  if (xq >= x[3] && (flags & 2)) return y[3];
+  const double t = (xq - xa) / h, t2 = t * t, t3 = t2 * t;
+  const double h00 = 2 * t3 - 3 * t2 + 1, h10 = t3 - 2 * t2 + t, h01 = -2 * t3 + 3 * t2, h11 = t3 - t2;
+  return h00 * y[li] + h10 * h * s_lo + h01 * y[li + 1] + h11 * h * s_hi;
+}
+
 #define CF_GROWTH_TPB 256
 template <int MODEL, int FDE, int C>
 __global__ void __launch_bounds__(CF_GROWTH_TPB)
@@ -1197,10 +1234,23 @@ growth_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, const 
   const double delta0 = resid[CF_MAX_FS8], s8 = slot_get(d, CF_P_S8_D, th), ferr = slot_get(d, CF_P_FS8ERR_D, th);
   if (wave == 0 && lane < n) {
     const int k = d.fs8_order[lane], i = d.fs8_step_of[lane];
-    const d4* pt = reinterpret_cast<const d4*>(d.fs8_pts) + 2 * lane;
-    const d4 hw = pt[0], aux = pt[1];  // Hermite weights {h00, h h10, h01, h h11}; {a_k, nu(z_k), -, -}
-    const d2 b0 = bnd[i], b1 = bnd[i + 1];
-    const double dprime = hw[0] * b0[0] + hw[1] * b0[1] + hw[2] * b1[0] + hw[3] * b1[1];
+    const d4* pt = reinterpret_cast<const d4*>(d.fs8_pts) + 8 * lane;  // the datum's record, see fs8_points (cosmofit_api.hip)
+    const d4 hw = pt[0], aux = pt[1];  // Hermite weights {h00, h h10, h01, h h11}; {a_k, nu(z_k), li, window flags}
+    auto read_out = [&](const d4& wgt, int step) {
+      const d2 b0 = bnd[step], b1 = bnd[step + 1];
+      return wgt[0] * b0[0] + wgt[1] * b0[1] + wgt[2] * b1[0] + wgt[3] * b1[1];
+    };
+    double dprime;
+    if (d.fs8_n_agrid > 0) {
+      // as the scripts: delta' sampled at the nodes of their logarithmic a-grid, then interp_pchip at a_k (fs8/fs8.py:79-98 ->
+      // interpolator.py:5-108) -- the four nodes around a_k are all the interpolant looks at
+      const d4 xs = pt[6], st = pt[7];
+      const double y0 = read_out(pt[2], (int)st[0]), y1 = read_out(pt[3], (int)st[1]), y2 = read_out(pt[4], (int)st[2]),
+                   y3 = read_out(pt[5], (int)st[3]);
+      dprime = pchip_window4(xs[0], xs[1], xs[2], xs[3], y0, y1, y2, y3, (int)aux[2], (int)aux[3], aux[0]);
+    } else {
+      dprime = read_out(hw, i);
+    }
     NodeView T;
     T.p = aux_nodes + (w * d.n_aux + d.n_bao + k) * CF_BAO_NODES;
     T.base = d.bao_base[d.n_bao + k];
@@ -1247,7 +1297,7 @@ __global__ void hz_kernel(cf_dev_desc d, const double* __restrict__ theta, const
   template __global__ void growth_kernel<M, F, C>(cf_dev_desc, const double*, int64_t, const d2*, double*, int, double*, double*);
 #define CF_INSTANTIATE_WALKER(M, F)                                                                              \
   template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*, d2*); \
-  template __global__ void walker_fast_kernel<M, F>(cf_walker_args, const double*, int64_t, double*, d2*);              \
+  template __global__ void walker_fast_kernel<M, F>(cf_walker_args, const double*, int64_t, double*, d2*, double*);     \
   template __global__ void small_blocks_kernel<M, F>(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, \
                                                      double*);                                                      \
   template __global__ void hz_kernel<M, F>(cf_dev_desc, const double*, const double*, int64_t, double*);                     \
@@ -1268,8 +1318,14 @@ __device__ double finalize_value(const cf_dev_desc& d, const double* __restrict_
   double lp = 0.0;
   if (out_kind == CF_OUT_LOGP_D) {
     if (d.has_bounds) {
+      // all ndim (<= 16) theta reads issued together, no short-circuit: with `&&` every parameter was a dependent load + branch
+      // in the last arriver of the solve, the one workgroup the evaluation's latency waits for
       bool inbox = true;
-      for (int k = 0; k < d.ndim; ++k) inbox = inbox && (d.lo[k] < th[k]) && (th[k] < d.hi[k]);
+#pragma unroll
+      for (int k = 0; k < CF_MAX_NDIM; ++k) {
+        const double t = th[k < d.ndim ? k : 0];
+        inbox = inbox & ((k >= d.ndim) | ((d.lo[k] < t) & (t < d.hi[k])));
+      }
       if (!inbox) return -INFINITY;  // the likelihood is not consulted outside the box, sn/pantheon.py:90-92
       lp = d.log_norm;
     }
@@ -1559,6 +1615,27 @@ extern "C" int cf_debug_gemm_stamps(unsigned long long* out) {
 // have nothing to do with the exchange.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// The last arriver's read-back of a panel's shares: `n` doubles at `src` (written by other workgroups with agent-scope
+// write-through stores) into LDS.  Every thread first ISSUES its (up to eight) agent-scope loads, then stores them: written as
+// one load + one LDS store per loop iteration, each iteration waited for its own round trip to memory (~1.2 us; the loads
+// bypass this XCD's L2) -- seven serialised round trips, 9 of the small-batch kernel's 20 us (truncated builds under
+// rocprofv3: profiles/r03_small_batch_solve.txt).
+__device__ __forceinline__ void fetch_shares_to_lds(const double* src, int n, double* __restrict__ sh, int tid) {
+  for (int base = 0; base < n; base += 8 * 256) {
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int idx = base + k * 256 + tid;
+      v[k] = __hip_atomic_load(&src[idx < n ? idx : n - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // unconditional: no branch, no wait
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int idx = base + k * 256 + tid;
+      if (idx < n) sh[idx] = v[k];
+    }
+  }
+}
+
 // One 16 x 16 tile of Y = X Delta from the four K quarters' partial tiles (C layout: register r of lane l is row (l >> 4) + 4 r,
 // column l & 15), and its share of chi^2 per walker column: the sum of squares over the tile's 16 rows -- four in registers,
 // then across the four lane groups.  ONE function for the throughput kernel and the small-batch kernel: the same expression,
@@ -1726,8 +1803,21 @@ tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict_
   const bool via_lds = n_sh <= 4096;
 #endif
   if (via_lds) {
-    for (int idx = tid; idx < n_sh; idx += 256)
-      sh[idx] = __hip_atomic_load(&partial[(int64_t)(idx / PW) * w_pad + w0 + idx % PW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // every thread issues its loads, then stores them: one load + store per loop iteration waited a round trip to memory each
+    // (see fetch_shares_to_lds)
+    for (int base = 0; base < n_sh; base += 8 * 256) {
+      double v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int idx = base + k * 256 + tid, ic = idx < n_sh ? idx : n_sh - 1;
+        v[k] = __hip_atomic_load(&partial[(int64_t)(ic / PW) * w_pad + w0 + ic % PW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int idx = base + k * 256 + tid;
+        if (idx < n_sh) sh[idx] = v[k];
+      }
+    }
     lds_barrier();
   }
   if (tid < PW && w0 + tid < W) {
@@ -1793,6 +1883,7 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
                       unsigned long long* nonfinite, double* __restrict__ chi2_sn_out, int units_pad) {
   __shared__ __align__(16) d4 part[4][64];  // [K quarter][lane] partial tile: 8 KB
   __shared__ double sh[4096];               // the panel's shares in the last arriver: [row block][tile][walker]
+  __shared__ double rbs[1024];              // ... and their sums over the tiles: [row block][walker]
   __shared__ unsigned int arrived_before;
   const int n_ld = d.n_ld, n_rb = pk.n_rowblocks;
   const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
@@ -1803,6 +1894,9 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
   const int64_t w0 = (int64_t)px * 16;
   if (w0 >= W) return;
   const int nq = 2 * (rb + 1);  // K-step pairs per wave
+#if defined(CF_DBG_SMALL) && CF_DBG_SMALL == 1  // TIMING EXPERIMENTS (wrong results): 1 = empty kernel, 2 = no hand-off, 3 = no epilogue
+  return;
+#endif
   CF_SSTAMP(0);
   CF_SWALL(6);
   // K-step pair q of this wave's quarter: factor fragment of tile j (1 KiB, stride 4 KiB), residual fragment (16 B per lane)
@@ -1857,6 +1951,10 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
   part[g][lane] = acc;
   lds_barrier();
   CF_SSTAMP(2);
+#if defined(CF_DBG_SMALL) && CF_DBG_SMALL == 2
+  if (acc[0] == 1.2345e300) out[0] = acc[1];  // keeps the loop alive
+  return;
+#endif
   // hand-off as in the throughput kernel (agent-scope write-through stores, vmcnt(0), one relaxed agent-scope add, the last
   // arriver's acquire fence); one counter per panel counts the 4 n_rb (row block, tile) workgroups
   double* mine = partial4 + (int64_t)px * (4 * n_rb * 16);
@@ -1873,22 +1971,34 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
   if (arrived_before != 4u * (unsigned)n_rb - 1u) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   if (tid == 0) __hip_atomic_store(&arrivals[px], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if defined(CF_DBG_SMALL) && CF_DBG_SMALL == 3
+  return;
+#endif
   const int n_sh = 4 * n_rb * 16;
   const bool via_lds = n_sh <= 4096;
   if (via_lds) {
-    for (int idx = tid; idx < n_sh; idx += 256) sh[idx] = __hip_atomic_load(&mine[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fetch_shares_to_lds(mine, n_sh, sh, tid);
+    lds_barrier();
+    // the (row block, walker) shares from their four tile shares, 256 threads side by side; thread w then adds its walker's
+    // n_rb row-block shares in order -- the throughput kernel's additions, one short dependent chain instead of 4 n_rb
+    for (int i = tid; i < n_rb * 16; i += 256) {
+      const int r = i >> 4, wl = i & 15;
+      rbs[i] = rowblock_share(sh[(r * 4 + 0) * 16 + wl], sh[(r * 4 + 1) * 16 + wl], sh[(r * 4 + 2) * 16 + wl], sh[(r * 4 + 3) * 16 + wl]);
+    }
     lds_barrier();
   }
   if (tid < 16 && w0 + tid < W) {
     const int64_t w = w0 + tid;
     double c2 = 0.0;
     for (int r = 0; r < n_rb; ++r) {
-      double t[4];
+      if (via_lds) {
+        c2 += rbs[r * 16 + tid];
+      } else {
+        double t[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        t[k] = via_lds ? sh[(r * 4 + k) * 16 + tid]
-                       : __hip_atomic_load(&mine[(r * 4 + k) * 16 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      c2 += rowblock_share(t[0], t[1], t[2], t[3]);
+        for (int k = 0; k < 4; ++k) t[k] = __hip_atomic_load(&mine[(r * 4 + k) * 16 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c2 += rowblock_share(t[0], t[1], t[2], t[3]);
+      }
     }
     if (chi2_sn_out) chi2_sn_out[w] = c2;  // the SN block alone (cf_eval_parts)
     if (chi2_extra) c2 += chi2_extra[w];

@@ -62,8 +62,9 @@ class LikelihoodEngine:
             [N, 3] unit vectors make the peculiar velocity n . (v, v2, v3) x step (sn/pantheon_dipole_xyz.py:50-60).
         logl_const: constant added to log L (Gaussian normalisations a script keeps in its log-likelihood).
         om_mode: 1 = the "Om" slot holds omega_m = Omega_m h^2 (bao/desi_omh2.py:18-20).
-        fs8: dict(z, val, inv_cov, fid, a_init[, steps]) — growth-rate block with the slots "s8" and "fs8err"
-            (fs8/fs8.py:64-125); fid[k] = H_fid(z_k) D_M,fid(z_k) of the Alcock-Paczynski correction.
+        fs8: dict(z, val, inv_cov, fid, a_init[, steps, a_grid]) — growth-rate block with the slots "s8" and "fs8err"
+            (fs8/fs8.py:64-125); fid[k] = H_fid(z_k) D_M,fid(z_k) of the Alcock-Paczynski correction; a_grid = N: delta' at the
+            data by interp_pchip on the scripts' np.logspace(log10 a_init, 0, N) grid (fs8/fs8.py:79-98), 0: read directly.
         cc: dict(z, h, inv_cov, logdet) — cosmic chronometers with the rescale parameter slot "fcc"
             (bao/desi_union3_cc_theta_star.py:129-139).
         bao: dict(z, val, qty (0 DV/rd, 1 DM/rd, 2 DH/rd, 3 F_AP), inv_cov[, dh_exact=False, rd_fit=None]);
@@ -174,6 +175,7 @@ class LikelihoodEngine:
             keep += [fz, fv, finv, ffid]
             d.n_fs8, d.fs8_z, d.fs8_val, d.fs8_inv_cov, d.fs8_fid = fz.size, _ptr(fz), _ptr(fv), _ptr(finv), _ptr(ffid)
             d.fs8_a_init, d.fs8_steps = float(fs8["a_init"]), int(fs8.get("steps", 0))
+            d.fs8_n_agrid = int(fs8.get("a_grid", 0))
             self.n_fs8 = int(fz.size)
         if cmb is not None:
             from .cmb_data import ZSTAR_CONSTS

@@ -413,8 +413,11 @@ class Fs8(_Base):
     log L = -0.5 (chi2 - 2 N ln f_err) (:116-125)."""
     bounds = np.array([(0.1, 0.6), (0.5, 1.0), (-1.0, 0.0), (0.2, 3.2)])
     A_INIT = 10**-2.15  # :79
+    N_A = 1000  # a_span = np.logspace(-2.15, 0, 1000) (:79)
 
-    def __init__(self, z, fs8_vals, cov_mat, omega_fid, *, fid=None, device=0, devices=None, bounds=None, steps=0):
+    def __init__(self, z, fs8_vals, cov_mat, omega_fid, *, fid=None, device=0, devices=None, bounds=None, steps=0, a_grid=None):
+        """a_grid: points of the a-grid delta' is interpolated on as the script does (None: the script's 1000); 0 reads delta' off
+        the integration directly."""
         z = np.asarray(z, dtype=np.float64)
         self.bounds = self.bounds if bounds is None else np.asarray(bounds, float)
         self.z_max = float(np.max(z) + 0.1)  # :18
@@ -425,7 +428,8 @@ class Fs8(_Base):
         self.engine = LikelihoodEngine(
             ndim=4, z_max=self.z_max, n_grid=N_GRID, fde=L.CF_FDE_THAWING,
             params=dict(H0=Param(fixed=1.0), Om=Param(0), s8=Param(1), w0=Param(2), fs8err=Param(3)),
-            fs8=dict(z=z, val=fs8_vals, inv_cov=np.linalg.inv(cov_mat), fid=self.fid, a_init=self.A_INIT, steps=steps),
+            fs8=dict(z=z, val=fs8_vals, inv_cov=np.linalg.inv(cov_mat), fid=self.fid, a_init=self.A_INIT, steps=steps,
+                     a_grid=self.N_A if a_grid is None else a_grid),
             bounds=self.bounds, device=device, devices=devices)
 
     def fs8_theory(self, *args):
@@ -442,6 +446,7 @@ class DesiCmbUnion3Fs8(_Base):
     at z = 0.2), DESI BAO with exact D_H, Planck+ACT (R, l_A, wb) and the growth-rate data with the physical-density
     H(z) (radiation and massive neutrinos enter dH/da, :127-145); the ODE starts at a = 10^-2.7 (:168)."""
     A_INIT = 10**-2.7
+    N_A = 2500  # a_span = np.logspace(-2.7, 0, 2500) (bao/desi_cmb_union3_fs8.py:169)
 
     def __init__(self, z_cmb, z_hel, mu_values, cov_sn, bao_z, bao_val, bao_qty, bao_inv_cov, fs8_z, fs8_vals, fs8_cov, fs8_fid, *,
                  comp=None, device=0, devices=None, steps=0):
@@ -453,7 +458,7 @@ class DesiCmbUnion3Fs8(_Base):
             sn=dict(z_cmb=z_cmb, z_hel=z_hel, obs=mu_values, chol=np.linalg.cholesky(cov_sn), z_turn=0.2),
             bao=dict(z=bao_z, val=bao_val, qty=bao_qty, inv_cov=bao_inv_cov, dh_exact=True, rd_fit=comp["rd_fit"]),
             cmb=dict(mode=comp["cmb_mode"], prior=comp["cmb_prior"], inv_cov=comp["cmb_inv_cov"], zstar_fit=comp["zstar_fit"]),
-            fs8=dict(z=fs8_z, val=fs8_vals, inv_cov=np.linalg.inv(fs8_cov), fid=fs8_fid, a_init=self.A_INIT, steps=steps),
+            fs8=dict(z=fs8_z, val=fs8_vals, inv_cov=np.linalg.inv(fs8_cov), fid=fs8_fid, a_init=self.A_INIT, steps=steps, a_grid=self.N_A),
             physical=_physical(comp), device=device, devices=devices)
 
 
@@ -464,6 +469,7 @@ class CcFs8(_Base):
     vectorised callback ``log_likelihood`` (:143-144)."""
 
     A_INIT = 1.0 / (1.0 + 200.0)  # max_z = 200, :86-87
+    N_A = 1000  # a_span = np.logspace(log10 a_init, 0, 1000) (ohd/cc_fs8.py:87)
 
     def __init__(self, z_cc, H_cc, cov_cc, fs8_z, fs8_vals, fs8_cov, fs8_fid, *, device=0, devices=None, steps=0):
         z_top = float(max(np.max(fs8_z), np.max(z_cc)))
@@ -472,7 +478,7 @@ class CcFs8(_Base):
             ndim=6, z_max=self.z_max, n_grid=N_GRID, fde=L.CF_FDE_THAWING,
             params=dict(H0=Param(0), Om=Param(1), s8=Param(2), fcc=Param(3), fs8err=Param(4), w0=Param(5)),
             cc=dict(z=z_cc, h=H_cc, inv_cov=np.linalg.inv(cov_cc), logdet=-len(z_cc) * np.log(2 * np.pi)),
-            fs8=dict(z=fs8_z, val=fs8_vals, inv_cov=np.linalg.inv(fs8_cov), fid=fs8_fid, a_init=self.A_INIT, steps=steps),
+            fs8=dict(z=fs8_z, val=fs8_vals, inv_cov=np.linalg.inv(fs8_cov), fid=fs8_fid, a_init=self.A_INIT, steps=steps, a_grid=self.N_A),
             device=device, devices=devices)
 
 
@@ -554,6 +560,7 @@ class Fs8Cmb(_Base):
     -0.5 (N ln 2 pi + logdet) + N ln f_err (:19-21,181-183)."""
     bounds = np.array([(50, 80), (0.01, 0.035), (0.1, 0.35), (-1.0, 0.0), (0.5, 1.0), (0.2, 3.2)], dtype=float)
     A_INIT = 1.0 / 501.0
+    N_A = 5000  # a_span = np.logspace(log10 a_init, 0, 5000) (fs8/fs8_cmb.py:129)
 
     def __init__(self, z, fs8_vals, cov_mat, fid, *, comp=None, device=0, devices=None, bounds=None, steps=0):
         comp = cmb_data.PLANCK_ACT if comp is None else comp
@@ -565,7 +572,7 @@ class Fs8Cmb(_Base):
             ndim=6, z_max=self.z_max, n_grid=N_GRID, ez_model=L.CF_EZ_PHYSICAL, fde=L.CF_FDE_THAWING,
             params=dict(H0=Param(0), obh2=Param(1), och2=Param(2), w0=Param(3), s8=Param(4), fs8err=Param(5)),
             cmb=dict(mode=comp["cmb_mode"], prior=comp["cmb_prior"], inv_cov=comp["cmb_inv_cov"], zstar_fit=comp["zstar_fit"]),
-            fs8=dict(z=z, val=fs8_vals, inv_cov=np.linalg.inv(cov_mat), fid=fid, a_init=self.A_INIT, steps=steps),
+            fs8=dict(z=z, val=fs8_vals, inv_cov=np.linalg.inv(cov_mat), fid=fid, a_init=self.A_INIT, steps=steps, a_grid=self.N_A),
             physical=_physical(comp), logl_const=-0.5 * norm_factor, bounds=self.bounds, device=device, devices=devices)
 
 
@@ -574,6 +581,7 @@ class DesiFsLyaCcFs8(_Base):
     cosmic chronometers (f_cc) and growth-rate data (f_fs8), late-time flat thawing; the growth ODE starts at a = 1 / 201
     (:115-116); log L keeps both Gaussian normalisations (:183-192)."""
     A_INIT = 1.0 / 201.0
+    N_A = 2000  # a_span = np.logspace(log10 a_init, 0, 2000) (bao/desi_fs_lya_cc_fs8.py:113)
 
     def __init__(self, bao_z, bao_val, bao_qty, bao_inv_cov, z_cc, H_cc, cov_cc, fs8_z, fs8_vals, fs8_cov, fs8_fid, *, device=0,
                  devices=None, steps=0):
@@ -584,7 +592,7 @@ class DesiFsLyaCcFs8(_Base):
             params=dict(H0=Param(0), Om=Param(1), s8=Param(2), fcc=Param(3), fs8err=Param(4), rd=Param(5), w0=Param(6)),
             bao=dict(z=bao_z, val=bao_val, qty=bao_qty, inv_cov=bao_inv_cov, dh_exact=True),
             cc=dict(z=z_cc, h=H_cc, inv_cov=np.linalg.inv(cov_cc), logdet=np.linalg.slogdet(cov_cc)[1]),
-            fs8=dict(z=fs8_z, val=fs8_vals, inv_cov=np.linalg.inv(fs8_cov), fid=fs8_fid, a_init=self.A_INIT, steps=steps),
+            fs8=dict(z=fs8_z, val=fs8_vals, inv_cov=np.linalg.inv(fs8_cov), fid=fs8_fid, a_init=self.A_INIT, steps=steps, a_grid=self.N_A),
             logl_const=-0.5 * norm_fs8, device=device, devices=devices)
 
 

@@ -266,8 +266,9 @@ typedef struct cf_desc {
    * theory_k = (sigma_8 / delta(1)) a_k delta'(a_k) / q_k,  q_k = H(z_k) D_M(z_k) / fs8_fid[k]  (Alcock-Paczynski);
    * chi2_fs8 = f_err^2 (val - theory)^T inv_cov (val - theory)  and  log L += n_fs8 ln f_err.
    * The reference integrates with scipy's adaptive RK45 at rtol = 1e-6; here a fixed-step RK4 in ln a: fs8_steps steps, rounded
-   * up to 256, 512 (0 = default), 1024 or 2048 (256 lanes per walker, 1-8 steps per lane; the ODE is linear, so the steps are
-   * 2 x 2 matrices combined by a parallel scan): the two agree to the reference's own integration error (~1e-6 relative on theory). */
+   * up to 256, 512, 1024 (0 = default) or 2048 (256 lanes per walker, 1-8 steps per lane; the ODE is linear, so the steps are
+   * 2 x 2 matrices combined by a parallel scan): the two agree to the reference's own integration error (~1e-6 relative on theory);
+   * against the reference's equation integrated to convergence the default leaves < 1e-9 on the theory (fs8_n_agrid below). */
   int32_t n_fs8;
   int32_t fs8_steps;
   const double* fs8_z;      /* [n_fs8] */
@@ -284,7 +285,9 @@ typedef struct cf_desc {
   int32_t cc_f_mode;        /* 0: chi2_cc * f_cc^2, log L += n_cc ln f_cc  (f_cc divides the errors, bao/desi_union3_cc_theta_star.py:129-139)
                                1: chi2_cc * f_cc^-2, log L -= n_cc ln f_cc (f_cc multiplies them)   ohd/cc_pantheon.py:64,92 */
   int32_t prior_norm_mode;  /* 0: log prior inside the box = -sum log(hi - lo) (sn/pantheon.py:77); 1: 0.0 (ohd/cc_cmb.py:70-73) */
-  int32_t _pad6;
+  int32_t fs8_n_agrid;      /* growth block: 0 = delta'(a_k) read from the integration directly; N >= 4 = as the scripts do, by interp_pchip
+                             * of delta' sampled on a_span = np.logspace(log10 fs8_a_init, 0, N) (fs8/fs8.py:79-98: N = 1000;
+                             * bao/desi_cmb_union3_fs8.py:169: 2500; ohd/cc_fs8.py:87: 1000; fs8/fs8_cmb.py:129: 5000) */
 } cf_desc;
 
 typedef struct cf_info {
