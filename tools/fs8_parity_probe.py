@@ -36,5 +36,5 @@ for name, mk in build.items():
         parts = lk.engine.parts(th)
         c_tight = np.array([T.chi2_fs8_from_theory(olk, t, g["theory_tight"][k]) for k, t in enumerate(th)])
         e_chi = np.max(np.abs(parts["chi2_fs8"] / c_tight - 1))
-        print(f"{name:26s} steps {steps or 512:4d}: theory vs tight {e_tight:.2e}  vs reference {e_ref:.2e}  chi2_fs8 vs host(theory_tight) {e_chi:.2e}", flush=True)
+        print(f"{name:26s} steps {steps or 1024:4d}: theory vs tight {e_tight:.2e}  vs reference {e_ref:.2e}  chi2_fs8 vs host(theory_tight) {e_chi:.2e}", flush=True)
         lk.engine.close()
