@@ -35,7 +35,9 @@ def test_gpus_n_self_launches_its_ranks():
     out = r.stderr + r.stdout
     assert r.returncode != 0
     assert "must be launched with torch.distributed.run" not in out, "round-1 behaviour: bench.py could not start N > 1 by itself"
-    assert out.count("needs an MI355X") >= 2, "both child ranks were started and each refused for lack of a GPU"
+    # both child ranks are started and each refuses for lack of a GPU; torchrun ends the surviving sibling as soon as the first
+    # child has failed, so the second refusal may not get printed: one refusal + torchrun's own failure report is the proof
+    assert out.count("needs an MI355X") >= 2 or ("needs an MI355X" in out and "ChildFailedError" in out), out[-1500:]
 
 
 def test_strong_scaling_needs_whole_panels_per_rank():
