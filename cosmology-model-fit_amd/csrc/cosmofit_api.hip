@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <utility>
 #include <condition_variable>
 #include <memory>
@@ -125,22 +126,24 @@ template <int NP, int PF>
 __global__ void tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* theta, int64_t W, const double* delta,
                                      int64_t w_pad, double* partial, unsigned int* arrivals, const double* chi2_extra,
                                      double* out, int out_kind, unsigned long long* nonfinite, double* chi2_sn_out,
-                                     int panels_per_group);
+                                     int panels_per_group, unsigned long long* done_flag, unsigned long long done_seq);
 template <int PF>
 __global__ void tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* theta, int64_t W, const double* delta,
                                       double* partial4, unsigned int* arrivals, const double* chi2_extra, double* out, int out_kind,
-                                      unsigned long long* nonfinite, double* chi2_sn_out, int units_pad);
+                                      unsigned long long* nonfinite, double* chi2_sn_out, int units_pad,
+                                      unsigned long long* done_flag, unsigned long long done_seq);
 #define CF_DECLARE_TRIGEMM_SMALL(PF)                                                                                             \
   extern template __global__ void tri_gemm_small_kernel<PF>(cf_dev_desc, cf_dev_invpack, const double*, int64_t, const double*,   \
                                                             double*, unsigned int*, const double*, double*, int, unsigned long long*, \
-                                                            double*, int);
+                                                            double*, int, unsigned long long*, unsigned long long);
 CF_DECLARE_TRIGEMM_SMALL(4)
 CF_DECLARE_TRIGEMM_SMALL(8)
 CF_DECLARE_TRIGEMM_SMALL(16)
 #define CF_DECLARE_TRIGEMM(NP, PF)                                                                                       \
   extern template __global__ void tri_gemm_chi2_kernel<NP, PF>(cf_dev_desc, cf_dev_invpack, const double*, int64_t,     \
                                                                const double*, int64_t, double*, unsigned int*,          \
-                                                               const double*, double*, int, unsigned long long*, double*, int);
+                                                               const double*, double*, int, unsigned long long*, double*, int,  \
+                                                               unsigned long long*, unsigned long long);
 CF_DECLARE_TRIGEMM(1, 2)
 CF_DECLARE_TRIGEMM(1, 4)
 CF_DECLARE_TRIGEMM(2, 2)
@@ -148,7 +151,8 @@ CF_DECLARE_TRIGEMM(2, 3)
 CF_DECLARE_TRIGEMM(2, 4)
 CF_DECLARE_TRIGEMM(4, 2)
 extern "C" __global__ void finalize_kernel(cf_dev_desc d, const double* theta, int64_t W, const double* chi2_extra,
-                                           double* out, int out_kind, unsigned long long* nonfinite);
+                                           double* out, int out_kind, unsigned long long* nonfinite, unsigned long long* done_flag,
+                                           unsigned long long done_seq);
 extern "C" __global__ void interp_kernel(const double* xq, int64_t nq, const double* x, const double* y,
                                          const double* yp, int64_t n, double* out, int mode);
 extern "C" __global__ void log10_selftest_kernel(const double* x, int64_t n, double* out, int mode, const cf_d2* tab);
@@ -284,6 +288,7 @@ struct PinnedBuf {
 #ifndef CF_ZEROCOPY_DEFAULT
 #define CF_ZEROCOPY_DEFAULT 4096  // walkers; beyond, in-place access to the pinned block is no faster than two copy commands (profiles/r03_zerocopy_threshold.txt)
 #endif
+#define CF_DONE_FLAGS 256       // completion words per handle: panels of the largest zero-copy batch (4096 walkers / 16)
 #define CF_SMALL_MAX_PANELS 16  // largest batch of the small-batch solve kernel: 256 walkers (the default switch is lower)
 #ifndef CF_SMALL_DEFAULT
 #define CF_SMALL_DEFAULT 48  // walkers: batches up to this size take the small-batch solve kernel (faster up to 32-48 walkers, even at 64,
@@ -330,6 +335,9 @@ struct cf_handle {
   DevBuf theta, out, delta, ypk, chi2_extra, nonfinite;
   DevBuf fs8_z, fs8_val, fs8_inv_cov, fs8_fid, fs8_step_of, fs8_order, fs8_tab, fs8_pts;
   DevBuf bao_nodes, bao_base;  // [max_walkers][n_bao][CF_BAO_NODES] table nodes for small_blocks_kernel; first node per datum
+  PinnedBuf done_flags;           // [CF_DONE_FLAGS] words the evaluation's last kernel sets as each panel's results reach the staging block
+  unsigned long long done_seq = 0;
+  int done_armed = 0;             // panels whose word the current synchronous call waits for (0: wait for the stream)
   bool theta_on_host = false;     // set around a zero-copy evaluation: theta is the pinned staging block (reads cross the host link)
   bool has_small_blocks = false;  // BAO and / or CMB block present
   bool has_growth = false;        // growth-rate block present
@@ -405,6 +413,10 @@ static int upload_exp2_table(DevBuf& b) {
 
 static int ensure_workspace(cf_handle* h, int64_t W) {
   const int64_t w_pad = (W + 31) / 32 * 32;  // whole panels of the widest solve kernel (2 x 16 walkers)
+  if (!h->done_flags.p) {  // completion words of synchronous zero-copy calls (every likelihood form)
+    if (h->done_flags.ensure((size_t)CF_DONE_FLAGS * 8)) return CF_ERR_HIP;
+    memset(h->done_flags.p, 0, (size_t)CF_DONE_FLAGS * 8);
+  }
   if (w_pad <= h->max_walkers) return 0;
   // earlier evaluations may still be running on a caller's stream and use the buffers about to be replaced
   HIP_TRY(hipDeviceSynchronize());
@@ -419,6 +431,7 @@ static int ensure_workspace(cf_handle* h, int64_t W) {
     if (h->partial.ensure((size_t)w_pad * h->ipack.dev.n_rowblocks * 8)) return CF_ERR_HIP;
     if (h->arrivals.ensure((size_t)(w_pad / 16) * 4)) return CF_ERR_HIP;
     if (h->partial4.ensure((size_t)CF_SMALL_MAX_PANELS * 4 * h->ipack.dev.n_rowblocks * 16 * 8)) return CF_ERR_HIP;
+
     HIP_TRY(hipMemsetAsync(h->arrivals.p, 0, (size_t)(w_pad / 16) * 4, h->stream));  // the kernel re-arms them itself
   }
   if (h->d.n_sn > 0) {
@@ -1163,6 +1176,8 @@ struct TriGemmArgs {
   unsigned long long* nonfinite;
   double* chi2_sn_out;
   double* partial4;
+  unsigned long long* done_flag;  // pinned host words the small-batch kernel's last arrivers set to done_seq, or null
+  unsigned long long done_seq;
 };
 
 template <int NP, int PF>
@@ -1185,7 +1200,7 @@ static int launch_tri_gemm_t(const TriGemmArgs& a, hipStream_t st) {
   const int n_groups = (panels + ppg - 1) / ppg;
   hipLaunchKernelGGL((tri_gemm_chi2_kernel<NP, PF>), dim3((unsigned)(n_groups * ppg * a.pk->n_rowblocks)), dim3(256), 0, st, *a.d,
                      *a.pk, a.theta, a.W, a.delta, a.w_pad, a.partial, a.arrivals, a.chi2_extra, a.out, a.out_kind, a.nonfinite,
-                     a.chi2_sn_out, ppg);
+                     a.chi2_sn_out, ppg, a.done_flag, a.done_seq);
   return 0;
 }
 
@@ -1196,7 +1211,8 @@ static int launch_tri_gemm_small_t(const TriGemmArgs& a, hipStream_t st) {
   const int panels = (int)((a.W + 15) / 16);
   const int units_pad = (4 * a.pk->n_rowblocks + 7) / 8 * 8;
   hipLaunchKernelGGL((tri_gemm_small_kernel<PF>), dim3((unsigned)(panels * units_pad)), dim3(256), 0, st, *a.d, *a.pk, a.theta, a.W,
-                     a.delta, a.partial4, a.arrivals, a.chi2_extra, a.out, a.out_kind, a.nonfinite, a.chi2_sn_out, units_pad);
+                     a.delta, a.partial4, a.arrivals, a.chi2_extra, a.out, a.out_kind, a.nonfinite, a.chi2_sn_out, units_pad,
+                     a.done_flag, a.done_seq);
   return 0;
 }
 
@@ -1233,6 +1249,12 @@ static int launch_tri_gemm(const TriGemmArgs& a, hipStream_t st) {
     case 4 * 16 + 2: return launch_tri_gemm_t<4, 2>(a, st);
   }
   return fail(CF_ERR_INVALID, "bad CF_GEMM_SHAPE");
+}
+
+// walkers per panel of the throughput solve kernel launch_tri_gemm picks for W walkers (0: an override this file does not model)
+static int tri_gemm_panel_width(int64_t W) {
+  static const bool overridden = getenv("CF_GEMM_SHAPE") != nullptr;
+  return overridden ? 0 : (W > 768 ? 32 : 16);
 }
 
 // One sub-batch [off, off + Wc) of an evaluation on stream `st`: per-walker kernel (distance table, residuals; the
@@ -1279,10 +1301,20 @@ static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_
   if (ev_walker_done) HIP_TRY(hipEventRecord(ev_walker_done, st));
   if (ev) HIP_TRY(hipEventRecord(ev[2], st));
   if (d.n_sn > 0 && h->solve_mode == CF_SOLVE_INVERSE_GEMM) {
-    const TriGemmArgs a{&d, &h->ipack.dev, th, Wc, delta, h->max_walkers, h->partial.as<double>() + off,
+    TriGemmArgs a{&d, &h->ipack.dev, th, Wc, delta, h->max_walkers, h->partial.as<double>() + off,
                         h->arrivals.as<unsigned int>() + off / 16, extra, out, out_kind, nf, chi2_sn_out,
-                        ev_walker_done ? nullptr : h->partial4.as<double>()};  // sub-batches run side by side: one partial4
-
+                        ev_walker_done ? nullptr : h->partial4.as<double>(),  // sub-batches run side by side: one partial4
+                        nullptr, 0ull};
+    // a synchronous zero-copy call: the solve kernel's last arrivers set one word per panel in pinned host memory and the host
+    // waits for those instead of the end of the kernel (launch_tri_gemm's own choice of kernel and panel width decides how many)
+    if (h->theta_on_host && !ev_walker_done && off == 0 && h->done_flags.p) {
+      a.done_flag = (unsigned long long*)h->done_flags.p;
+      a.done_seq = h->done_seq;
+      const bool small = Wc <= small_batch_max() && a.partial4;
+      const int pw = small ? 16 : tri_gemm_panel_width(Wc);
+      h->done_armed = pw > 0 ? (int)((Wc + pw - 1) / pw) : 0;
+      if (h->done_armed == 0 || h->done_armed > CF_DONE_FLAGS) { a.done_flag = nullptr; h->done_armed = 0; }
+    }
     int rc = launch_tri_gemm(a, st);
     if (rc) return rc;
   } else if (d.n_sn > 0) {
@@ -1290,8 +1322,13 @@ static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_
                          nf, st, chi2_sn_out);
     if (rc) return rc;
   } else {
+    unsigned long long* fin_flag = nullptr;
+    if (h->theta_on_host && !ev_walker_done && off == 0 && h->done_flags.p && (Wc + 255) / 256 <= CF_DONE_FLAGS) {
+      fin_flag = (unsigned long long*)h->done_flags.p;
+      h->done_armed = (int)((Wc + 255) / 256);
+    }
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((Wc + 255) / 256)), dim3(256), 0, st, d, th, Wc, (const double*)extra, out,
-                       out_kind, nf);
+                       out_kind, nf, fin_flag, h->done_seq);
   }
   if (ev) HIP_TRY(hipEventRecord(ev[3], st));
   return 0;
@@ -1393,6 +1430,24 @@ static int wait_stream(hipStream_t st) {
   return 0;
 }
 
+// Spin on the words the small-batch kernel's last arrivers set (pinned host memory) for up to ~1 ms; false = not seen (the caller
+// then waits for the stream as usual).  CF_DONE_FLAG=0 disables the short cut (A/B).
+static bool wait_done_flags(cf_handle* h) {
+  static const bool on = [] { const char* e = getenv("CF_DONE_FLAG"); return !e || atoi(e) != 0; }();
+  if (!on) return false;
+  const volatile unsigned long long* f = (const volatile unsigned long long*)h->done_flags.p;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned it = 0;; ++it) {
+    bool all = true;
+    for (int p = 0; p < h->done_armed; ++p) all = all && f[p] == h->done_seq;
+    if (all) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      return true;
+    }
+    if ((it & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(1)) return false;
+  }
+}
+
 // One replica, host buffers: stage through the handle's pinned block, run on the handle's stream, wait.
 static int eval_host_single(cf_handle* h, const double* theta, int64_t W, double* out, int out_kind) {
   int rc;
@@ -1406,9 +1461,15 @@ static int eval_host_single(cf_handle* h, const double* theta, int64_t W, double
   static const int64_t zc_max = [] { const char* e = getenv("CF_ZEROCOPY_MAX"); return e ? atoll(e) : (long long)CF_ZEROCOPY_DEFAULT; }();
   if (W <= zc_max) {
     h->theta_on_host = true;
+    h->done_armed = 0;
+    ++h->done_seq;
     rc = launch_path(h, (const double*)h->stage_in.p, W, (double*)h->stage_out.p, out_kind, h->stream, nullptr, nullptr, nullptr, nullptr);
     h->theta_on_host = false;
     if (rc) return rc;
+    if (h->done_armed > 0 && wait_done_flags(h)) {  // the small-batch kernel has signalled every panel: the stream drains in the background
+      memcpy(out, h->stage_out.p, (size_t)W * 8);
+      return CF_OK;
+    }
   } else {
     HIP_TRY(hipMemcpyAsync(h->theta.p, h->stage_in.p, (size_t)W * h->d.ndim * 8, hipMemcpyHostToDevice, h->stream));
     if ((rc = launch_path(h, h->theta.as<const double>(), W, h->out.as<double>(), out_kind, h->stream, nullptr, nullptr,

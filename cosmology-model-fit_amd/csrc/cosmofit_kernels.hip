@@ -1655,7 +1655,8 @@ __global__ void __launch_bounds__(256)
 tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict__ theta, int64_t W,
                      const double* __restrict__ delta, int64_t w_pad, double* partial, unsigned int* arrivals,
                      const double* __restrict__ chi2_extra, double* __restrict__ out, int out_kind,
-                     unsigned long long* nonfinite, double* __restrict__ chi2_sn_out, int panels_per_group) {
+                     unsigned long long* nonfinite, double* __restrict__ chi2_sn_out, int panels_per_group,
+                     unsigned long long* done_flag, unsigned long long done_seq) {
   __shared__ __align__(16) d4 part[4][4][64];  // [wave][tile][lane] of one 16-walker panel: 32 KB
   __shared__ double chi_tile[4][16 * NP];
   __shared__ unsigned int arrived_before;
@@ -1832,12 +1833,17 @@ tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict_
     if (chi2_extra) c2 += chi2_extra[w];
     out[w] = finalize_value(d, theta + w * d.ndim, c2, out_kind, nonfinite);
   }
+  // the panel's completion word for a synchronous zero-copy host call (see tri_gemm_small_kernel): PW <= 32 lanes of wave 0 stored
+  if (done_flag && tid < 64) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) __hip_atomic_store(&done_flag[px], done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 #define CF_INSTANTIATE_TRIGEMM(NP, PF)                                                                                   \
   template __global__ void tri_gemm_chi2_kernel<NP, PF>(cf_dev_desc, cf_dev_invpack, const double*, int64_t, const double*, \
                                                         int64_t, double*, unsigned int*, const double*, double*, int,   \
-                                                        unsigned long long*, double*, int);
+                                                        unsigned long long*, double*, int, unsigned long long*, unsigned long long);
 CF_INSTANTIATE_TRIGEMM(1, 2)
 CF_INSTANTIATE_TRIGEMM(1, 4)
 CF_INSTANTIATE_TRIGEMM(2, 2)
@@ -1880,7 +1886,8 @@ __global__ void __launch_bounds__(256)
 tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict__ theta, int64_t W,
                       const double* __restrict__ delta, double* partial4, unsigned int* arrivals,
                       const double* __restrict__ chi2_extra, double* __restrict__ out, int out_kind,
-                      unsigned long long* nonfinite, double* __restrict__ chi2_sn_out, int units_pad) {
+                      unsigned long long* nonfinite, double* __restrict__ chi2_sn_out, int units_pad,
+                      unsigned long long* done_flag, unsigned long long done_seq) {
   __shared__ __align__(16) d4 part[4][64];  // [K quarter][lane] partial tile: 8 KB
   __shared__ double sh[4096];               // the panel's shares in the last arriver: [row block][tile][walker]
   __shared__ double rbs[1024];              // ... and their sums over the tiles: [row block][walker]
@@ -2004,11 +2011,20 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
     if (chi2_extra) c2 += chi2_extra[w];
     out[w] = finalize_value(d, theta + w * d.ndim, c2, out_kind, nonfinite);
   }
+  // A synchronous host call (zero-copy: `out` is the pinned staging block) does not wait for the END of this kernel -- its
+  // teardown, the completion signal and the runtime's stream query are microseconds of a 40 us call -- but for this word in pinned
+  // host memory: the panel's results have left (they were stored by lanes of this wave: vmcnt(0)), then ONE system-scope
+  // release store of the call's sequence number.  Writes to the host travel in order.
+  if (done_flag && tid < 64) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) __hip_atomic_store(&done_flag[px], done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   CF_SSTAMP(4);
 }
 #define CF_INSTANTIATE_TRIGEMM_SMALL(PF)                                                                                     \
   template __global__ void tri_gemm_small_kernel<PF>(cf_dev_desc, cf_dev_invpack, const double*, int64_t, const double*, double*, \
-                                                     unsigned int*, const double*, double*, int, unsigned long long*, double*, int);
+                                                     unsigned int*, const double*, double*, int, unsigned long long*, double*, int, \
+                                                     unsigned long long*, unsigned long long);
 CF_INSTANTIATE_TRIGEMM_SMALL(4)
 CF_INSTANTIATE_TRIGEMM_SMALL(8)
 CF_INSTANTIATE_TRIGEMM_SMALL(16)
@@ -2018,9 +2034,14 @@ CF_INSTANTIATE_TRIGEMM_SMALL(16)
 // ------------------------------------------------------------------------------------------------
 extern "C" __global__ void finalize_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W,
                                            const double* __restrict__ chi2_extra, double* __restrict__ out,
-                                           int out_kind, unsigned long long* nonfinite) {
+                                           int out_kind, unsigned long long* nonfinite, unsigned long long* done_flag,
+                                           unsigned long long done_seq) {
   const int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (w < W) out[w] = finalize_value(d, theta + w * d.ndim, chi2_extra ? chi2_extra[w] : 0.0, out_kind, nonfinite);
+  if (done_flag) {  // completion word of this block's 256 walkers for a synchronous zero-copy host call
+    __syncthreads();  // every wave's stores issued and acknowledged
+    if (threadIdx.x == 0) __hip_atomic_store(&done_flag[blockIdx.x], done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
