@@ -1,19 +1,22 @@
 // cosmofit_kernels.hip — gfx950 (MI355X, CDNA4) device code of the batched log-likelihood engine.
 //
-// Two kernels make the hot path:
+// The hot path is two launches per evaluation:
 //
-//   walker_kernel       (a1-a10, a12-a16)  one 512-thread workgroup per walker.  E(z) on the G-point grid,
-//        cumulative trapezoid as chunk-sequential sums + a wave64 shuffle scan + LDS carry, the
-//        two tables (cum_dm, dh) staged in LDS (2*G*8 B = 64 KB), cubic-Hermite at the N data
-//        redshifts and at z_cosmo(theta), mu_corr, mu_theory, residual -> Delta[w][0..Npad).
+//   walker_fast_kernel / walker_kernel   (a1-a10)   one 512-thread workgroup per walker.  E(z) on the G-point grid,
+//        cumulative trapezoid as chunk-sequential sums + a wave64 DPP scan + LDS carry, the table {cum_dm, dh} staged
+//        in LDS (G * 16 B = 64 KB), cubic Hermite at z_cosmo(theta) of the N supernovae, residual -> Delta[w][0..n_ld).
+//        walker_fast_kernel is the production form (lean kernel arguments, theta row across the lanes); walker_kernel
+//        keeps the accessor / calibrator / direction-dependent / long-grid paths.
 //
-//   trsm_chi2_kernel    (a11)     one 256-thread workgroup per PANEL of 16 walkers.  Blocked
-//        forward substitution  Y = L^-1 Delta  on FP64 matrix cores (v_mfma_f64_16x16x4_f64):
-//        256-row block rows, off-diagonal updates as MFMA GEMM steps streamed from the packed
-//        (pre-negated, fragment-ordered) factor, diagonal blocks applied through their
-//        pre-computed inverses; chi^2 = column sums of Y^2, then prior / out_kind epilogue.
+//   tri_gemm_chi2_kernel / tri_gemm_small_kernel   (a11)   chi^2 = || X Delta ||^2 with X = L^-1 inverted once on the
+//        host: a triangular GEMM on FP64 matrix cores (v_mfma_f64_16x16x4_f64) with no dependency between 64-row
+//        blocks; one workgroup per (row block, panel of 16-32 walkers), or per (panel, row block, 16-row tile) for
+//        batches of <= 48 walkers (bit-identical); the workgroup that arrives last for a panel adds the shares in a
+//        fixed order and applies the prior / output epilogue.  trsm_chi2_kernel (blocked forward substitution) is the
+//        fallback when the explicit inverse fails its create-time probe.
 //
-// Written for wave64 / gfx950 only; no other target is supported.
+// Joint likelihoods add small_blocks_kernel (BAO, compressed CMB, cosmic chronometers) and growth_kernel (f sigma_8)
+// between the two.  Written for wave64 / gfx950 only; no other target is supported.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
