@@ -291,7 +291,7 @@ struct PinnedBuf {
 #define CF_DONE_FLAGS 256       // completion words per handle: panels of the largest zero-copy batch (4096 walkers / 16)
 #define CF_SMALL_MAX_PANELS 16  // largest batch of the small-batch solve kernel: 256 walkers (the default switch is lower)
 #ifndef CF_SMALL_DEFAULT
-#define CF_SMALL_DEFAULT 48  // walkers: batches up to this size take the small-batch solve kernel (faster up to 32-48 walkers, even at 64,
+#define CF_SMALL_DEFAULT 64  // walkers: batches up to this size take the small-batch solve kernel (faster up to 64 walkers, even at 75-96,
                              // slower beyond: profiles/r03_small_batch_solve.txt)
 #endif
 #define CF_MAX_CHUNKS 8  // sub-batches of one evaluation (walker kernel of chunk c + 1 beside the solve of chunk c)

@@ -11,7 +11,7 @@
 //   tri_gemm_chi2_kernel / tri_gemm_small_kernel   (a11)   chi^2 = || X Delta ||^2 with X = L^-1 inverted once on the
 //        host: a triangular GEMM on FP64 matrix cores (v_mfma_f64_16x16x4_f64) with no dependency between 64-row
 //        blocks; one workgroup per (row block, panel of 16-32 walkers), or per (panel, row block, 16-row tile) for
-//        batches of <= 48 walkers (bit-identical); the workgroup that arrives last for a panel adds the shares in a
+//        batches of <= 64 walkers (bit-identical); the workgroup that arrives last for a panel adds the shares in a
 //        fixed order and applies the prior / output epilogue.  trsm_chi2_kernel (blocked forward substitution) is the
 //        fallback when the explicit inverse fails its create-time probe.
 //
