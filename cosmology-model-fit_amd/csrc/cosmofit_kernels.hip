@@ -792,11 +792,12 @@ walker_fast_kernel(cf_walker_args d, const double* __restrict__ theta, int64_t W
   extern __shared__ __align__(16) d2 lds_tab[];
   __shared__ __align__(16) d4 wave_pub[CF_TPB_A / 64];
   __shared__ __align__(16) d2 log_tab[64];
-  __shared__ double exp2_tab[64];
+  __shared__ double exp2_all[CF_TPB_A / 64][64];  // exp_tab's 2^(j/64), one copy PER WAVE: filled with no workgroup barrier
 
   const int64_t w = blockIdx.x;
   if (w >= W) return;
   const int tid = threadIdx.x, lane = tid & 63;
+  double* const exp2_tab = exp2_all[tid >> 6];
   CF_WSTAMP(0);
   // loads in the order their values are needed: the theta row (the cosmology scalars wait for nothing else), the two small
   // reduction tables, then the theta-independent node tables of the table build
@@ -806,7 +807,7 @@ walker_fast_kernel(cf_walker_args d, const double* __restrict__ theta, int64_t W
   d2 lt = (d2){0.0, 0.0};
   double et = 0.0;
   if (tid < 64 && d.n_sn > 0) lt = reinterpret_cast<const d2*>(d.log10_tab)[tid];
-  if (POWER_LAW && tid >= 64 && tid < 128) et = d.exp2_tab[tid - 64];
+  if (POWER_LAW) et = d.exp2_tab[lane];
   double nu_pre[8], ln_pre[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -814,8 +815,7 @@ walker_fast_kernel(cf_walker_args d, const double* __restrict__ theta, int64_t W
     ln_pre[k] = POWER_LAW ? d.ln_sw[k * CF_TPB_A + tid] : -1.0;
   }
   if (tid < 64 && d.n_sn > 0) log_tab[tid] = lt;
-  if (POWER_LAW && tid >= 64 && tid < 128) exp2_tab[tid - 64] = et;
-  if (POWER_LAW) __syncthreads();  // the table build reads exp2_tab before its own first barrier
+  if (POWER_LAW) exp2_tab[lane] = et;  // read back by this wave only: a wave's LDS accesses complete in order
   const WalkerCosmo wc = make_cosmo(d, th);
   const double off = slot_get(d, CF_P_OFFSET_D, th);
   const double v100 = 100 * slot_get(d, CF_P_V_D, th);
