@@ -308,7 +308,7 @@ static void cf_pack_inverse(const double* L, int64_t n, int64_t ld, cf_host_invp
   int64_t total = 0;
   for (int rb = 0; rb < RB; ++rb)
     for (int g = 0; g < 4; ++g) {
-      out.off[rb * 4 + g] = total;
+      out.off[rb * 4 + g] = cf_inv_stream_off(rb, g);  // == total: the streams are contiguous in (rb, g) order
       total += (int64_t)2 * (rb + 1) * 4;
     }
   total += 32;  // slack for the kernel's software pipeline

@@ -31,11 +31,14 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define CF_DELTA_SLACK 4096  // the inverse-GEMM pipeline prefetches a few K-step pairs past the last residual row
 
 #define CF_BAO_NODES 6  // table nodes copied out per BAO datum (cosmofit_kernels.hip)
+#define CF_SN_PARTS_MAX 4                         // workgroups per walker of a small batch (walker_fast_kernel)
+#define CF_SN_REC_SLACK (512 * CF_SN_PARTS_MAX)   // spare SN records behind the last one
 template <int MODEL, int FDE>
 __global__ void walker_kernel(cf_dev_desc d, const double* theta, int64_t W, double* delta, double* dm_out, double* mucorr_out,
                               d2* bao_nodes, d2* table_out);
 template <int MODEL, int FDE>
-__global__ void walker_fast_kernel(cf_walker_args d, const double* theta, int64_t W, double* delta, d2* bao_nodes, double* theta_copy);
+__global__ void walker_fast_kernel(cf_walker_args d, const double* theta, int64_t W, double* delta, d2* bao_nodes, double* theta_copy,
+                                   int frag_b, int sn_parts);
 template <int MODEL, int FDE>
 __global__ void small_blocks_kernel(cf_dev_desc d, const double* theta, int64_t W, const d2* bao_nodes, double* chi2_extra,
                                     double* blocks_out, double* bao_out);
@@ -48,7 +51,7 @@ __global__ void hz_kernel(cf_dev_desc d, const double* theta, const double* z, i
   extern template __global__ void growth_kernel<M, F, C>(cf_dev_desc, const double*, int64_t, const d2*, double*, int, double*, double*);
 #define CF_DECLARE_WALKER(M, F)                                                                                            \
   extern template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*, d2*); \
-  extern template __global__ void walker_fast_kernel<M, F>(cf_walker_args, const double*, int64_t, double*, d2*, double*);         \
+  extern template __global__ void walker_fast_kernel<M, F>(cf_walker_args, const double*, int64_t, double*, d2*, double*, int, int); \
   extern template __global__ void small_blocks_kernel<M, F>(cf_dev_desc, const double*, int64_t, const d2*, double*,       \
                                                             double*, double*);                                            \
   extern template __global__ void hz_kernel<M, F>(cf_dev_desc, const double*, const double*, int64_t, double*);             \
@@ -63,7 +66,7 @@ static walker_fn pick_walker(int model, int fde) {
       {walker_kernel<1, 0>, walker_kernel<1, 1>, walker_kernel<1, 2>, walker_kernel<1, 3>}};
   return table[model][fde];
 }
-typedef void (*walker_fast_fn)(cf_walker_args, const double*, int64_t, double*, d2*, double*);
+typedef void (*walker_fast_fn)(cf_walker_args, const double*, int64_t, double*, d2*, double*, int, int);
 static walker_fast_fn pick_walker_fast(int model, int fde) {
   static const walker_fast_fn table[2][4] = {
       {walker_fast_kernel<0, 0>, walker_fast_kernel<0, 1>, walker_fast_kernel<0, 2>, walker_fast_kernel<0, 3>},
@@ -127,18 +130,21 @@ __global__ void tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const dou
                                      int64_t w_pad, double* partial, unsigned int* arrivals, const double* chi2_extra,
                                      double* out, int out_kind, unsigned long long* nonfinite, double* chi2_sn_out,
                                      int panels_per_group, unsigned long long* done_flag, unsigned long long done_seq);
-template <int PF>
+template <int PF, bool FRAG>
 __global__ void tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* theta, int64_t W, const double* delta,
                                       double* partial4, unsigned int* arrivals, const double* chi2_extra, double* out, int out_kind,
                                       unsigned long long* nonfinite, double* chi2_sn_out, int units_pad,
                                       unsigned long long* done_flag, unsigned long long done_seq);
-#define CF_DECLARE_TRIGEMM_SMALL(PF)                                                                                             \
-  extern template __global__ void tri_gemm_small_kernel<PF>(cf_dev_desc, cf_dev_invpack, const double*, int64_t, const double*,   \
-                                                            double*, unsigned int*, const double*, double*, int, unsigned long long*, \
-                                                            double*, int, unsigned long long*, unsigned long long);
-CF_DECLARE_TRIGEMM_SMALL(4)
-CF_DECLARE_TRIGEMM_SMALL(8)
-CF_DECLARE_TRIGEMM_SMALL(16)
+#define CF_DECLARE_TRIGEMM_SMALL(PF, FRAG)                                                                                             \
+  extern template __global__ void tri_gemm_small_kernel<PF, FRAG>(cf_dev_desc, cf_dev_invpack, const double*, int64_t, const double*,   \
+                                                                  double*, unsigned int*, const double*, double*, int,                  \
+                                                                  unsigned long long*, double*, int, unsigned long long*, unsigned long long);
+CF_DECLARE_TRIGEMM_SMALL(4, false)
+CF_DECLARE_TRIGEMM_SMALL(8, false)
+CF_DECLARE_TRIGEMM_SMALL(16, false)
+CF_DECLARE_TRIGEMM_SMALL(4, true)
+CF_DECLARE_TRIGEMM_SMALL(8, true)
+CF_DECLARE_TRIGEMM_SMALL(16, true)
 #define CF_DECLARE_TRIGEMM(NP, PF)                                                                                       \
   extern template __global__ void tri_gemm_chi2_kernel<NP, PF>(cf_dev_desc, cf_dev_invpack, const double*, int64_t,     \
                                                                const double*, int64_t, double*, unsigned int*,          \
@@ -746,8 +752,9 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
     d.obs = h->obs.as<const double>();
     d.sn_step = h->sn_step.as<const double>();
     {
-      // one record per SN for the production loop; 512 spare records so that its look-ahead needs no bounds check
-      std::vector<cf_d4> rec((size_t)d.n_ld + 512, cf_d4{1.0, 1.0, 1.0, 0.0});
+      // one record per SN for the production loop; spare records so that its look-ahead (one stride of at most CF_SN_PARTS_MAX x
+      // 512 records) needs no bounds check
+      std::vector<cf_d4> rec((size_t)d.n_ld + CF_SN_REC_SLACK, cf_d4{1.0, 1.0, 1.0, 0.0});
       for (int64_t i = 0; i < c->n_sn; ++i)
         rec[i] = cf_d4{d.has_vstep ? 1.0 + c->sn_z_cmb[i] : c->sn_z_cmb[i], d.lin_in_rec ? c->sn_lin_coef[i] : step[i],
                        1.0 + c->sn_z_hel[i], c->sn_obs[i]};
@@ -1178,6 +1185,7 @@ struct TriGemmArgs {
   double* partial4;
   unsigned long long* done_flag;  // pinned host words the small-batch kernel's last arrivers set to done_seq, or null
   unsigned long long done_seq;
+  bool frag_b;  // `delta` holds the panels' residuals in the small-batch kernel's fragment order (walker_fast_kernel, frag_b)
 };
 
 template <int NP, int PF>
@@ -1206,11 +1214,11 @@ static int launch_tri_gemm_t(const TriGemmArgs& a, hipStream_t st) {
 
 // Small batches: one workgroup per (panel, row block, 16-row tile), see tri_gemm_small_kernel.  CF_SMALL_MAX=<walkers> moves the
 // switch (0 = never; at most 16 x CF_SMALL_MAX_PANELS), CF_SMALL_PF=4|8|16 the prefetch depth (tuning).
-template <int PF>
+template <int PF, bool FRAG>
 static int launch_tri_gemm_small_t(const TriGemmArgs& a, hipStream_t st) {
   const int panels = (int)((a.W + 15) / 16);
   const int units_pad = (4 * a.pk->n_rowblocks + 7) / 8 * 8;
-  hipLaunchKernelGGL((tri_gemm_small_kernel<PF>), dim3((unsigned)(panels * units_pad)), dim3(256), 0, st, *a.d, *a.pk, a.theta, a.W,
+  hipLaunchKernelGGL((tri_gemm_small_kernel<PF, FRAG>), dim3((unsigned)(panels * units_pad)), dim3(256), 0, st, *a.d, *a.pk, a.theta, a.W,
                      a.delta, a.partial4, a.arrivals, a.chi2_extra, a.out, a.out_kind, a.nonfinite, a.chi2_sn_out, units_pad,
                      a.done_flag, a.done_seq);
   return 0;
@@ -1229,11 +1237,12 @@ static int launch_tri_gemm(const TriGemmArgs& a, hipStream_t st) {
   if (a.W <= small_batch_max() && a.partial4) {
     static const int pf = [] { const char* e = getenv("CF_SMALL_PF"); return e ? atoi(e) : 16; }();
     switch (pf) {
-      case 4: return launch_tri_gemm_small_t<4>(a, st);
-      case 8: return launch_tri_gemm_small_t<8>(a, st);
-      default: return launch_tri_gemm_small_t<16>(a, st);
+      case 4: return a.frag_b ? launch_tri_gemm_small_t<4, true>(a, st) : launch_tri_gemm_small_t<4, false>(a, st);
+      case 8: return a.frag_b ? launch_tri_gemm_small_t<8, true>(a, st) : launch_tri_gemm_small_t<8, false>(a, st);
+      default: return a.frag_b ? launch_tri_gemm_small_t<16, true>(a, st) : launch_tri_gemm_small_t<16, false>(a, st);
     }
   }
+  if (a.frag_b) return fail(CF_ERR_INVALID, "internal: fragment-ordered residuals handed to the throughput solve kernel");
   static const int shape = [] {
     const char* e = getenv("CF_GEMM_SHAPE");
     return (e && strlen(e) == 3 && e[1] == 'x') ? (e[0] - '0') * 16 + (e[2] - '0') : 0;
@@ -1275,6 +1284,11 @@ static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_
   if (ev && !(h->d.n_sn > 0 || h->has_small_blocks || h->has_growth)) HIP_TRY(hipEventRecord(ev[1], st));
   const bool walker_work = d.n_sn > 0 || h->has_small_blocks || h->has_growth;
   double* extra = (h->has_small_blocks || h->has_growth) ? h->chi2_extra.as<double>() + off : nullptr;
+  // a small batch of the production path: walker_fast_kernel writes the residuals in the fragment order the small-batch solve
+  // kernel loads them in (one contiguous 1 KiB load per K-step pair instead of a 16-row gather: sn_fast_loop, FRAG)
+  static const bool frag_env = [] { const char* e = getenv("CF_SMALL_FRAG"); return !e || atoi(e) != 0; }();
+  const bool small_solve = d.n_sn > 0 && h->solve_mode == CF_SOLVE_INVERSE_GEMM && !ev_walker_done && h->partial4.p && Wc <= small_batch_max();
+  const bool frag_b = frag_env && small_solve && !dm_out && !mucorr_out && walker_fast_ok(d);
   if (walker_work) {
     // skewed {cum, dh} table: one spare 16-byte slot per 2^chunk_shift nodes
     const size_t lds = ((size_t)d.n_grid + (d.n_grid >> d.chunk_shift) + 2) * 16;
@@ -1283,8 +1297,13 @@ static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_
       // memory and every later kernel of the evaluation (small blocks, growth, the solve's prior / output epilogue) reads THAT --
       // the epilogue's dependent theta reads were microseconds each across the host link
       double* th_copy = h->theta_on_host ? h->theta.as<double>() + off * d.ndim : nullptr;
-      hipLaunchKernelGGL(pick_walker_fast(d.ez_model, d.fde), dim3((unsigned)Wc), dim3(512), lds, st, walker_args_of(d), th, Wc, delta,
-                         bao_nodes, th_copy);
+      // a small batch leaves most of the chip idle: several workgroups per walker, each with the walker's table and a share of
+      // its SNe (CF_SN_PARTS=1|2|4 overrides)
+      static const int parts_env = [] { const char* e = getenv("CF_SN_PARTS"); return e ? atoi(e) : 0; }();
+      int sn_parts = parts_env > 0 ? parts_env : (Wc <= 64 ? 4 : 1);  // measured: W = 16 26.5 -> 25.3 us, W = 64 31.5 -> 30.1 us per call
+      if (sn_parts > CF_SN_PARTS_MAX || d.n_sn == 0) sn_parts = 1;
+      hipLaunchKernelGGL(pick_walker_fast(d.ez_model, d.fde), dim3((unsigned)(Wc * sn_parts)), dim3(512), lds, st, walker_args_of(d), th,
+                         Wc, delta, bao_nodes, th_copy, frag_b ? 1 : 0, sn_parts);
       if (th_copy) th = th_copy;
     } else
       hipLaunchKernelGGL(pick_walker(d.ez_model, d.fde), dim3((unsigned)Wc), dim3(512), lds, st, d, th, Wc, delta, dm_out, mucorr_out,
@@ -1304,7 +1323,7 @@ static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_
     TriGemmArgs a{&d, &h->ipack.dev, th, Wc, delta, h->max_walkers, h->partial.as<double>() + off,
                         h->arrivals.as<unsigned int>() + off / 16, extra, out, out_kind, nf, chi2_sn_out,
                         ev_walker_done ? nullptr : h->partial4.as<double>(),  // sub-batches run side by side: one partial4
-                        nullptr, 0ull};
+                        nullptr, 0ull, frag_b};
     // a synchronous zero-copy call: the solve kernel's last arrivers set one word per panel in pinned host memory and the host
     // waits for those instead of the end of the kernel (launch_tri_gemm's own choice of kernel and panel width decides how many)
     if (h->theta_on_host && !ev_walker_done && off == 0 && h->done_flags.p) {

@@ -190,6 +190,11 @@ struct cf_dev_invpack {
 #define CF_HD
 #endif
 
+// Inverse-GEMM solve: offset (in 1 KiB fragments) of the stream of (row block rb, K quarter g) -- row block r holds 4 quarters of
+// 2 (r + 1) K-step pairs x 4 tiles, so the streams before it add up to 16 rb (rb + 1).  cf_pack_inverse lays the streams out by this
+// formula and the solve kernels evaluate it instead of loading cf_dev_invpack::off.
+CF_HD static inline int64_t cf_inv_stream_off(int rb, int g) { return (int64_t)8 * (rb + 1) * (2 * rb + g); }
+
 // Tiles of a block row that wave v (of NW = 4, 8 or 16) solves in the diagonal phase, slot j.
 // Pairs (v, 2NW-1-v) balance the triangular work.  Returns -1 when the slot does not exist.
 CF_HD static inline int cf_diag_slots(int NW) { return CF_BLOCK_TILES / NW; }

@@ -617,19 +617,29 @@ __device__ double r_drag_fit(const double* f, double wb, double wm) {
 // ------------------------------------------------------------------------------------------------
 // LIN: the record's second field carries the coefficient of the linear magnitude term instead of a step weight (only
 // likelihoods without a velocity step): offset_i = offset + lin * coef_i    bao/desi_cmb_pantheon_H0trgb.py:102-106
-template <bool PM1, bool LIN = false, class D = cf_dev_desc>
+// FRAG: the residual goes to the small-batch solve kernel's B-fragment order instead of the walker's row (`out` then points at
+// the walker's column of its 16-walker panel): row i of walker 16 px + col is double (i / 8) * 128 + (i / 2 % 4) * 32 + 2 col + i % 2
+// of the panel's 16 n_ld doubles -- what lane (kq = i / 2 % 4, col) of the MFMA reads for K-step pair i / 8 (tri_gemm_small_kernel).
+template <bool FRAG>
+__device__ __forceinline__ int delta_index(int i) {
+  return FRAG ? ((i >> 3) * 128 + ((i >> 1) & 3) * 32 + (i & 1)) : i;
+}
+template <bool PM1, bool LIN = false, bool FRAG = false, class D = cf_dev_desc>
 __device__ __forceinline__ void sn_fast_loop(const D& d, const DistTable& T, const d2* __restrict__ log_tab,
-                                             double* __restrict__ out, double off, double v100, int tid, double lin = 0.0) {
-  const int n_sn = d.n_sn;
+                                             double* __restrict__ out, double off, double v100, int tid, double lin = 0.0,
+                                             int part = 0, int n_parts = 1) {
+  // part / n_parts: a small batch spreads a walker's SNe over n_parts workgroups (walker_fast_kernel): this one takes the SNe
+  // part * CF_TPB_A + tid, then every n_parts * CF_TPB_A-th
+  const int n_sn = d.n_sn, first = part * CF_TPB_A + tid, stride = n_parts * CF_TPB_A;
   double r_pos = 1.0, r_neg = 1.0;
   if (PM1 && d.has_vstep) {
     r_pos = 1.0 / (1.0 + v100 / d.c);
     r_neg = 1.0 / (1.0 + (-v100) / d.c);
   }
   // {has_vstep ? 1 + z_cmb : z_cmb, step, 1 + z_hel, obs}: the two sums are the reference's own first operations
-  const d4* __restrict__ rec = reinterpret_cast<const d4*>(d.sn_rec) + tid;
+  const d4* __restrict__ rec = reinterpret_cast<const d4*>(d.sn_rec) + first;
   // rows n_sn .. n_ld - 1 are zero padding for the MFMA tiles / the 64-row blocks of the inverse-GEMM solve
-  if (tid < d.n_ld - n_sn) out[n_sn + tid] = 0.0;
+  if (part == 0 && tid < d.n_ld - n_sn) out[delta_index<FRAG>(n_sn + tid)] = 0.0;
   auto one_sn = [&](const d4& r, int i) {
     const double za = r[0], st = r[1], zhp1 = r[2], ob = r[3];
     double z_cosmo = za;
@@ -642,23 +652,23 @@ __device__ __forceinline__ void sn_fast_loop(const D& d, const DistTable& T, con
       }
     }
     const double off_i = LIN ? off + lin * st : off;
-    out[i] = ob - off_i - (25.0 + 5 * log10_tab(zhp1 * hermite_fast(T, z_cosmo), log_tab));
+    out[delta_index<FRAG>(i)] = ob - off_i - (25.0 + 5 * log10_tab(zhp1 * hermite_fast(T, z_cosmo), log_tab));
   };
-  // two records in flight, ping-pong (no register copies); the record array carries 512 spare entries past n_ld.
+  // two records in flight, ping-pong (no register copies); the record array carries CF_SN_REC_SLACK spare entries past n_ld.
   // (A variant with three branch-free evaluations per iteration -- selects instead of the extrapolation / range guards, so
   // that the three dependent chains share one basic block -- measured the same 0.051 ms: the loop is issue-, not
   // latency-bound; profiles/r02_sn_loop_ab.txt.)
   d4 ra = rec[0], rb;
-  int i = tid;
+  int i = first;
   while (i < n_sn) {
-    rb = rec[CF_TPB_A];
+    rb = rec[stride];
     one_sn(ra, i);
-    i += CF_TPB_A;
+    i += stride;
     if (i >= n_sn) break;
-    rec += 2 * CF_TPB_A;
+    rec += 2 * stride;
     ra = rec[0];
     one_sn(rb, i);
-    i += CF_TPB_A;
+    i += stride;
   }
 }
 
@@ -788,13 +798,16 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
 template <int MODEL, int FDE>
 __global__ void __launch_bounds__(CF_TPB_A, 4)
 walker_fast_kernel(cf_walker_args d, const double* __restrict__ theta, int64_t W, double* __restrict__ delta,
-                   d2* __restrict__ bao_nodes, double* __restrict__ theta_copy) {
+                   d2* __restrict__ bao_nodes, double* __restrict__ theta_copy, int frag_b, int sn_parts) {
   extern __shared__ __align__(16) d2 lds_tab[];
   __shared__ __align__(16) d4 wave_pub[CF_TPB_A / 64];
   __shared__ __align__(16) d2 log_tab[64];
   __shared__ double exp2_all[CF_TPB_A / 64][64];  // exp_tab's 2^(j/64), one copy PER WAVE: filled with no workgroup barrier
 
-  const int64_t w = blockIdx.x;
+  // sn_parts > 1 (a small batch: most of the chip would idle): sn_parts workgroups per walker, each builds the walker's table and
+  // evaluates every sn_parts-th stretch of CF_TPB_A SNe (the residual rows are disjoint); part 0 writes everything else
+  const int64_t w = sn_parts > 1 ? blockIdx.x / (unsigned)sn_parts : blockIdx.x;
+  const int part = sn_parts > 1 ? (int)(blockIdx.x % (unsigned)sn_parts) : 0;
   if (w >= W) return;
   const int tid = threadIdx.x, lane = tid & 63;
   double* const exp2_tab = exp2_all[tid >> 6];
@@ -802,7 +815,7 @@ walker_fast_kernel(cf_walker_args d, const double* __restrict__ theta, int64_t W
   // loads in the order their values are needed: the theta row (the cosmology scalars wait for nothing else), the two small
   // reduction tables, then the theta-independent node tables of the table build
   const ThetaRow th{theta[w * d.ndim + (lane < d.ndim ? lane : 0)]};
-  if (theta_copy && tid < d.ndim) theta_copy[w * d.ndim + tid] = th.v;  // for the later kernels of a zero-copy evaluation
+  if (theta_copy && part == 0 && tid < d.ndim) theta_copy[w * d.ndim + tid] = th.v;  // for the later kernels of a zero-copy evaluation
   constexpr bool POWER_LAW = FDE == CF_FDE_WCDM_D || FDE == CF_FDE_CPL_D;
   d2 lt = (d2){0.0, 0.0};
   double et = 0.0;
@@ -831,15 +844,20 @@ walker_fast_kernel(cf_walker_args d, const double* __restrict__ theta, int64_t W
   CF_WSTAMP(1);
   build_distance_table_regs<MODEL, FDE, 8>(d, wc, lds_tab, wave_pub, nu_pre, ln_pre, exp2_tab);
   CF_WSTAMP(4);
-  for (int e = CF_TPB_A - 1 - tid; e < CF_BAO_NODES * d.n_aux; e += CF_TPB_A) {
+  for (int e = CF_TPB_A - 1 - tid; part == 0 && e < CF_BAO_NODES * d.n_aux; e += CF_TPB_A) {
     const int k = e / CF_BAO_NODES, o = e % CF_BAO_NODES;
     bao_nodes[(w * d.n_aux + k) * CF_BAO_NODES + o] = T.at(d.bao_base[k] + o);
   }
-  if (d.n_sn > 0) {
+  if (d.n_sn > 0 && !frag_b) {
     double* out = delta + w * d.n_ld;
-    if (d.lin_in_rec) sn_fast_loop<false, true>(d, T, log_tab, out, off, v100, tid, lin);
-    else if (d.step_pm1) sn_fast_loop<true>(d, T, log_tab, out, off, v100, tid);
-    else sn_fast_loop<false>(d, T, log_tab, out, off, v100, tid);
+    if (d.lin_in_rec) sn_fast_loop<false, true>(d, T, log_tab, out, off, v100, tid, lin, part, sn_parts);
+    else if (d.step_pm1) sn_fast_loop<true>(d, T, log_tab, out, off, v100, tid, 0.0, part, sn_parts);
+    else sn_fast_loop<false>(d, T, log_tab, out, off, v100, tid, 0.0, part, sn_parts);
+  } else if (d.n_sn > 0) {  // a small batch: the residuals in the solve kernel's fragment order (sn_fast_loop, FRAG)
+    double* out = delta + (w >> 4) * (16 * (int64_t)d.n_ld) + 2 * (w & 15);
+    if (d.lin_in_rec) sn_fast_loop<false, true, true>(d, T, log_tab, out, off, v100, tid, lin, part, sn_parts);
+    else if (d.step_pm1) sn_fast_loop<true, false, true>(d, T, log_tab, out, off, v100, tid, 0.0, part, sn_parts);
+    else sn_fast_loop<false, false, true>(d, T, log_tab, out, off, v100, tid, 0.0, part, sn_parts);
   }
   CF_WSTAMP(5);
 }
@@ -1300,7 +1318,7 @@ __global__ void hz_kernel(cf_dev_desc d, const double* __restrict__ theta, const
   template __global__ void growth_kernel<M, F, C>(cf_dev_desc, const double*, int64_t, const d2*, double*, int, double*, double*);
 #define CF_INSTANTIATE_WALKER(M, F)                                                                              \
   template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*, d2*); \
-  template __global__ void walker_fast_kernel<M, F>(cf_walker_args, const double*, int64_t, double*, d2*, double*);     \
+  template __global__ void walker_fast_kernel<M, F>(cf_walker_args, const double*, int64_t, double*, d2*, double*, int, int);     \
   template __global__ void small_blocks_kernel<M, F>(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, \
                                                      double*);                                                      \
   template __global__ void hz_kernel<M, F>(cf_dev_desc, const double*, const double*, int64_t, double*);                     \
@@ -1311,8 +1329,8 @@ CF_INSTANTIATE_WALKER(1, 0) CF_INSTANTIATE_WALKER(1, 1) CF_INSTANTIATE_WALKER(1,
 // ------------------------------------------------------------------------------------------------
 // Prior / output epilogue shared by every likelihood form.   sn/pantheon.py:80-97
 // ------------------------------------------------------------------------------------------------
-__device__ double finalize_value(const cf_dev_desc& d, const double* __restrict__ th, double chi2, int out_kind,
-                                 unsigned long long* nonfinite) {
+__device__ __forceinline__ double finalize_value(const cf_dev_desc& d, const double* __restrict__ th, double chi2, int out_kind,
+                                                 unsigned long long* nonfinite) {
   for (int g = 0; g < d.n_chi2_gauss; ++g) {
     double diff = th[d.chi2_gauss_idx[g]] - d.chi2_gauss_mean[g];
     chi2 += diff * diff / (d.chi2_gauss_sigma[g] * d.chi2_gauss_sigma[g]);
@@ -1623,20 +1641,23 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // one load + one LDS store per loop iteration, each iteration waited for its own round trip to memory (~1.2 us; the loads
 // bypass this XCD's L2) -- seven serialised round trips, 9 of the small-batch kernel's 20 us (truncated builds under
 // rocprofv3: profiles/r03_small_batch_solve.txt).
-__device__ __forceinline__ void fetch_shares_to_lds(const double* src, int n, double* __restrict__ sh, int tid) {
-  for (int base = 0; base < n; base += 8 * 256) {
-    double v[8];
+// n <= 4096: two straight-line stages of eight loads, not a loop -- at a loop head hipcc waits for every load in flight (vmcnt(0)).
+__device__ __forceinline__ void fetch_shares_stage(const double* src, int n, double* __restrict__ sh, int tid, int base) {
+  double v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int idx = base + k * 256 + tid;
-      v[k] = __hip_atomic_load(&src[idx < n ? idx : n - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // unconditional: no branch, no wait
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int idx = base + k * 256 + tid;
-      if (idx < n) sh[idx] = v[k];
-    }
+  for (int k = 0; k < 8; ++k) {
+    const int idx = base + k * 256 + tid;
+    v[k] = __hip_atomic_load(&src[idx < n ? idx : n - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // unconditional: no branch, no wait
   }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int idx = base + k * 256 + tid;
+    if (idx < n) sh[idx] = v[k];
+  }
+}
+__device__ __forceinline__ void fetch_shares_to_lds(const double* src, int n, double* __restrict__ sh, int tid) {
+  fetch_shares_stage(src, n, sh, tid, 0);
+  if (n > 8 * 256) fetch_shares_stage(src, n, sh, tid, 8 * 256);
 }
 
 // One 16 x 16 tile of Y = X Delta from the four K quarters' partial tiles (C layout: register r of lane l is row (l >> 4) + 4 r,
@@ -1879,12 +1900,22 @@ extern "C" int cf_debug_small_stamps(unsigned long long* out) {
   if (px == 0 && lane == 0 && unit < 128) cf_small_stamps[(unit * 4 + g) * 8 + (k)] = __builtin_amdgcn_s_memtime()
 #define CF_SWALL(k) \
   if (px == 0 && lane == 0 && unit < 128) cf_small_stamps[(unit * 4 + g) * 8 + (k)] = wall_clock64()
+__device__ unsigned long long cf_small_epi[16];  // the last arriver of panel 0, wave 0: s_memtime per epilogue phase; [15] wall_clock64 at the end
+extern "C" int cf_debug_small_epi(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cf_small_epi), sizeof(cf_small_epi));
+}
+#define CF_ESTAMP(k) \
+  if (px == 0 && tid == 0) cf_small_epi[k] = __builtin_amdgcn_s_memtime()
+#define CF_EWALL(k) \
+  if (px == 0 && tid == 0) cf_small_epi[k] = wall_clock64()
 #else
 #define CF_SSTAMP(k)
 #define CF_SWALL(k)
+#define CF_ESTAMP(k)
+#define CF_EWALL(k)
 #endif
 
-template <int PF>
+template <int PF, bool FRAG>
 __global__ void __launch_bounds__(256)
 tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict__ theta, int64_t W,
                       const double* __restrict__ delta, double* partial4, unsigned int* arrivals,
@@ -1894,6 +1925,8 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
   __shared__ __align__(16) d4 part[4][64];  // [K quarter][lane] partial tile: 8 KB
   __shared__ double sh[4096];               // the panel's shares in the last arriver: [row block][tile][walker]
   __shared__ double rbs[1024];              // ... and their sums over the tiles: [row block][walker]
+  __shared__ __align__(16) unsigned long long desc_lds[(sizeof(cf_dev_desc) + 7) / 8];  // the last arriver's copy of `d` (see below)
+  __shared__ double th_lds[16 * CF_MAX_NDIM];                                           // ... and of the panel's theta rows
   __shared__ unsigned int arrived_before;
   const int n_ld = d.n_ld, n_rb = pk.n_rowblocks;
   const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
@@ -1910,20 +1943,37 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
   CF_SSTAMP(0);
   CF_SWALL(6);
   // K-step pair q of this wave's quarter: factor fragment of tile j (1 KiB, stride 4 KiB), residual fragment (16 B per lane)
-  const d2* A = pk.frags + pk.off[rb * 4 + g] * 64 + j * 64 + lane;
-  const d2* Bq = reinterpret_cast<const d2*>(delta) + ((w0 + col) * (int64_t)n_ld + 8 * (int64_t)g * nq + 2 * kq) / 2;
+  // (the stream offset in closed form, cf_inv_stream_off: one dependent load less in front of every wave's first fragment)
+  const d2* A = pk.frags + cf_inv_stream_off(rb, g) * 64 + j * 64 + lane;
+  // FRAG: walker_fast_kernel left the panel's residuals in fragment order (delta_index): a K-step pair is 1 KiB in a row, like
+  // the factor's -- the row form's 16 B per lane from 16 walker rows 8 n_ld bytes apart is sixteen cache lines per load, and those
+  // gathers, not the matrix pipe (64 cycles per MFMA of a dependent chain, tools/mfma_chain_latency.hip) or the factor stream, set
+  // the K loop's ~180 cycles per MFMA (profiles/r03_small_batch_solve.txt)
+  constexpr int BS = FRAG ? 64 : 4;  // d2 per K-step pair
+  const d2* Bq = FRAG ? reinterpret_cast<const d2*>(delta) + ((int64_t)px * (n_ld / 8) + (int64_t)g * nq) * 64 + lane
+                      : reinterpret_cast<const d2*>(delta) + ((w0 + col) * (int64_t)n_ld + 8 * (int64_t)g * nq + 2 * kq) / 2;
   d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
   d2 a[PF], bf[PF];
+#ifdef CF_SMALL_ALIAS_A  // TIMING EXPERIMENTS (wrong results): every factor / residual load of a wave hits its first PF pairs
+#define CF_SA_ADV 0
+#else
+#define CF_SA_ADV 1
+#endif
+#ifdef CF_SMALL_ALIAS_B
+#define CF_SB_ADV 0
+#else
+#define CF_SB_ADV 1
+#endif
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int p = 0; p < PF; ++p) {  // a short stream (nq < PF) re-reads its last pair: nothing outside the wave's range is touched
     const int q = p < nq ? p : nq - 1;
     a[p] = A[q * 256];
-    bf[p] = Bq[q * 4];
+    bf[p] = Bq[q * BS];
     __builtin_amdgcn_sched_barrier(0);  // stage 0 must be the oldest load
   }
-  A += PF * 256;
-  Bq += PF * 4;
+  A += CF_SA_ADV * PF * 256;
+  Bq += CF_SB_ADV * PF * BS;
   const int n_groups = nq / PF, rem = nq - n_groups * PF;
   for (int grp = 0; grp + 1 < n_groups; ++grp) {  // branch-free body, as in the throughput kernel
 #pragma unroll
@@ -1932,11 +1982,11 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
       acc = mfma_f64(a[p].y, bf[p].y, acc);
       __builtin_amdgcn_sched_barrier(0);
       a[p] = A[p * 256];
-      bf[p] = Bq[p * 4];
+      bf[p] = Bq[p * BS];
       __builtin_amdgcn_sched_barrier(0);
     }
-    A += PF * 256;
-    Bq += PF * 4;
+    A += CF_SA_ADV * PF * 256;
+    Bq += CF_SB_ADV * PF * BS;
   }
   if (n_groups > 0) {  // last full group: only the nq % PF pairs of the tail are still to be fetched
 #pragma unroll
@@ -1946,7 +1996,7 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
       __builtin_amdgcn_sched_barrier(0);
       if (p < rem) {
         a[p] = A[p * 256];
-        bf[p] = Bq[p * 4];
+        bf[p] = Bq[p * BS];
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1958,6 +2008,23 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
       acc = mfma_f64(a[p].y, bf[p].y, acc);
     }
   CF_SSTAMP(1);
+  // The prior / output epilogue of the LAST ARRIVER reads a dozen fields of `d` and the walkers' theta rows: as scalar loads from the
+  // kernel-argument segment and dependent vector loads, each in its own basic block, they were 5 k cycles of the one workgroup the
+  // whole call waits for.  Instead every workgroup issues, HERE, one load per lane of the descriptor (from the kernel-argument
+  // segment: `d` is the first argument) and of the panel's theta rows -- they return behind the hand-off's own wait -- and the last
+  // arriver parks them in LDS, where finalize_value reads them.
+  constexpr int DW = (int)((sizeof(cf_dev_desc) + 7) / 8);
+  static_assert(DW <= 256, "one descriptor word per thread");
+  const int n_th = 16 * d.ndim;
+  unsigned long long dv = 0ull;
+  double tv = 0.0;
+  {
+    const unsigned long long __attribute__((address_space(4)))* ka =
+        (const unsigned long long __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    const int64_t ti = w0 * d.ndim + tid;
+    if (tid < DW) dv = ka[tid];
+    if (tid < n_th && ti < W * d.ndim) tv = theta[ti];
+  }
   part[g][lane] = acc;
   lds_barrier();
   CF_SSTAMP(2);
@@ -1979,16 +2046,22 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
   CF_SSTAMP(3);
   CF_SWALL(7);
   if (arrived_before != 4u * (unsigned)n_rb - 1u) return;
+  CF_ESTAMP(0);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   if (tid == 0) __hip_atomic_store(&arrivals[px], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #if defined(CF_DBG_SMALL) && CF_DBG_SMALL == 3
   return;
 #endif
+  CF_ESTAMP(1);
   const int n_sh = 4 * n_rb * 16;
   const bool via_lds = n_sh <= 4096;
+  if (tid < DW) desc_lds[tid] = dv;  // the descriptor and theta copies fetched before the hand-off (see above)
+  if (tid < n_th) th_lds[tid] = tv;
+  if (via_lds) fetch_shares_to_lds(mine, n_sh, sh, tid);
+  const cf_dev_desc& dl = *reinterpret_cast<const cf_dev_desc*>(desc_lds);
   if (via_lds) {
-    fetch_shares_to_lds(mine, n_sh, sh, tid);
     lds_barrier();
+    CF_ESTAMP(2);
     // the (row block, walker) shares from their four tile shares, 256 threads side by side; thread w then adds its walker's
     // n_rb row-block shares in order -- the throughput kernel's additions, one short dependent chain instead of 4 n_rb
     for (int i = tid; i < n_rb * 16; i += 256) {
@@ -1997,13 +2070,26 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
     }
     lds_barrier();
   }
+  else
+    lds_barrier();  // desc_lds, th_lds
+  CF_ESTAMP(3);
   if (tid < 16 && w0 + tid < W) {
     const int64_t w = w0 + tid;
+    const double extra = chi2_extra ? chi2_extra[w] : 0.0;
     double c2 = 0.0;
-    for (int r = 0; r < n_rb; ++r) {
-      if (via_lds) {
-        c2 += rbs[r * 16 + tid];
-      } else {
+    if (via_lds) {
+      // the row-block shares added in order, 32 LDS reads in flight at a time (one read + one add per iteration waited an LDS
+      // round trip each: 110 cycles x n_rb)
+      for (int r0 = 0; r0 < n_rb; r0 += 32) {
+        double v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] = rbs[(r0 + k < n_rb ? r0 + k : n_rb - 1) * 16 + tid];
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+          if (r0 + k < n_rb) c2 += v[k];
+      }
+    } else {
+      for (int r = 0; r < n_rb; ++r) {
         double t[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) t[k] = __hip_atomic_load(&mine[(r * 4 + k) * 16 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2011,8 +2097,10 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
       }
     }
     if (chi2_sn_out) chi2_sn_out[w] = c2;  // the SN block alone (cf_eval_parts)
-    if (chi2_extra) c2 += chi2_extra[w];
-    out[w] = finalize_value(d, theta + w * d.ndim, c2, out_kind, nonfinite);
+    if (chi2_extra) c2 += extra;
+    CF_ESTAMP(4);
+    out[w] = finalize_value(dl, th_lds + tid * dl.ndim, c2, out_kind, nonfinite);
+    CF_ESTAMP(5);
   }
   // A synchronous host call (zero-copy: `out` is the pinned staging block) does not wait for the END of this kernel -- its
   // teardown, the completion signal and the runtime's stream query are microseconds of a 40 us call -- but for this word in pinned
@@ -2020,17 +2108,23 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
   // release store of the call's sequence number.  Writes to the host travel in order.
   if (done_flag && tid < 64) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CF_ESTAMP(6);
     if (tid == 0) __hip_atomic_store(&done_flag[px], done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  CF_ESTAMP(7);
+  CF_EWALL(15);
   CF_SSTAMP(4);
 }
-#define CF_INSTANTIATE_TRIGEMM_SMALL(PF)                                                                                     \
-  template __global__ void tri_gemm_small_kernel<PF>(cf_dev_desc, cf_dev_invpack, const double*, int64_t, const double*, double*, \
-                                                     unsigned int*, const double*, double*, int, unsigned long long*, double*, int, \
-                                                     unsigned long long*, unsigned long long);
-CF_INSTANTIATE_TRIGEMM_SMALL(4)
-CF_INSTANTIATE_TRIGEMM_SMALL(8)
-CF_INSTANTIATE_TRIGEMM_SMALL(16)
+#define CF_INSTANTIATE_TRIGEMM_SMALL(PF, FRAG)                                                                                     \
+  template __global__ void tri_gemm_small_kernel<PF, FRAG>(cf_dev_desc, cf_dev_invpack, const double*, int64_t, const double*, double*, \
+                                                           unsigned int*, const double*, double*, int, unsigned long long*, double*, int, \
+                                                           unsigned long long*, unsigned long long);
+CF_INSTANTIATE_TRIGEMM_SMALL(4, false)
+CF_INSTANTIATE_TRIGEMM_SMALL(8, false)
+CF_INSTANTIATE_TRIGEMM_SMALL(16, false)
+CF_INSTANTIATE_TRIGEMM_SMALL(4, true)
+CF_INSTANTIATE_TRIGEMM_SMALL(8, true)
+CF_INSTANTIATE_TRIGEMM_SMALL(16, true)
 
 // ------------------------------------------------------------------------------------------------
 // Likelihoods without an SN block: only the epilogue.

@@ -35,3 +35,12 @@ wall = st[:n_units, :, 7].max() - w0
 print(f"span entry -> last hand-off: {span} cycles; last arriver's epilogue ends at {last - t0} cycles; wall_clock64 span {wall} ticks (100 MHz: {wall * 10} ns)"
       f" -> shader clock ~ {span / (wall * 10e-9) / 1e9:.2f} GHz")
 print("workgroup starts (rel cycles), sorted:", np.sort(st[:n_units, :, 0].min(axis=1) - t0)[[0, n_units // 4, n_units // 2, 3 * n_units // 4, n_units - 1]])
+if hasattr(amd._lib.lib(), "cf_debug_small_epi"):
+    e = (C.c_uint64 * 16)()
+    amd._lib.lib().cf_debug_small_epi.argtypes = [C.c_void_p]
+    assert amd._lib.lib().cf_debug_small_epi(e) == 0
+    e = np.array(e, dtype=np.uint64).astype(np.int64)
+    names = ["acquire fence + counter re-arm", "shares -> LDS + barrier", "row-block shares + barrier", "27 adds (+ chi2_extra)", "prior + log P + store",
+             "vmcnt(0) (results at the host)", "completion word issued"]
+    print("last arriver's epilogue (cycles):", ", ".join(f"{n} {e[k + 1] - e[k]}" for k, n in enumerate(names)))
+    print(f"wall_clock64: first workgroup entry -> end of the epilogue {(e[15] - w0) * 10} ns")
