@@ -297,7 +297,7 @@ struct PinnedBuf {
 #define CF_DONE_FLAGS 256       // completion words per handle: panels of the largest zero-copy batch (4096 walkers / 16)
 #define CF_SMALL_MAX_PANELS 16  // largest batch of the small-batch solve kernel: 256 walkers (the default switch is lower)
 #ifndef CF_SMALL_DEFAULT
-#define CF_SMALL_DEFAULT 64  // walkers: batches up to this size take the small-batch solve kernel (faster up to 64 walkers, even at 75-96,
+#define CF_SMALL_DEFAULT 128  // walkers: batches up to this size take the small-batch solve kernel (faster up to 128 walkers, even at 150,
                              // slower beyond: profiles/r03_small_batch_solve.txt)
 #endif
 #define CF_MAX_CHUNKS 8  // sub-batches of one evaluation (walker kernel of chunk c + 1 beside the solve of chunk c)
@@ -1300,7 +1300,7 @@ static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_
       // a small batch leaves most of the chip idle: several workgroups per walker, each with the walker's table and a share of
       // its SNe (CF_SN_PARTS=1|2|4 overrides)
       static const int parts_env = [] { const char* e = getenv("CF_SN_PARTS"); return e ? atoi(e) : 0; }();
-      int sn_parts = parts_env > 0 ? parts_env : (Wc <= 64 ? 4 : 1);  // measured: W = 16 26.5 -> 25.3 us, W = 64 31.5 -> 30.1 us per call
+      int sn_parts = parts_env > 0 ? parts_env : (Wc <= 64 ? 4 : (Wc <= 128 ? 2 : 1));  // measured: W = 16 26.5 -> 25.3 us, W = 64 31.5 -> 30.1 us per call
       if (sn_parts > CF_SN_PARTS_MAX || d.n_sn == 0) sn_parts = 1;
       hipLaunchKernelGGL(pick_walker_fast(d.ez_model, d.fde), dim3((unsigned)(Wc * sn_parts)), dim3(512), lds, st, walker_args_of(d), th,
                          Wc, delta, bao_nodes, th_copy, frag_b ? 1 : 0, sn_parts);

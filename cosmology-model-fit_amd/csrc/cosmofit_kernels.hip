@@ -11,7 +11,7 @@
 //   tri_gemm_chi2_kernel / tri_gemm_small_kernel   (a11)   chi^2 = || X Delta ||^2 with X = L^-1 inverted once on the
 //        host: a triangular GEMM on FP64 matrix cores (v_mfma_f64_16x16x4_f64) with no dependency between 64-row
 //        blocks; one workgroup per (row block, panel of 16-32 walkers), or per (panel, row block, 16-row tile) for
-//        batches of <= 64 walkers (bit-identical); the workgroup that arrives last for a panel adds the shares in a
+//        batches of <= 128 walkers (bit-identical); the workgroup that arrives last for a panel adds the shares in a
 //        fixed order and applies the prior / output epilogue.  trsm_chi2_kernel (blocked forward substitution) is the
 //        fallback when the explicit inverse fails its create-time probe.
 //
@@ -1703,7 +1703,13 @@ tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict_
   CF_GSTAMP(0);
   const d2* A = pk.frags + pk.off[rb * 4 + g] * 64 + lane;
   // B fragments: 16 bytes per lane from the walker's residual row; panel c is 16 rows (8 n_ld d2) further on
+#ifdef CF_DEBUG_FRAG_B  // TIMING EXPERIMENT (wrong results): the residual loads as contiguous 1 KiB fragments (the small-batch kernel's FRAG order)
+#define CF_BQ 64
+  const d2* Bq = reinterpret_cast<const d2*>(delta) + ((w0 / 16) * (int64_t)(n_ld / 8) + (int64_t)g * nq) * 64 + lane;
+#else
+#define CF_BQ 4
   const d2* Bq = reinterpret_cast<const d2*>(delta) + ((w0 + col) * (int64_t)n_ld + 8 * (int64_t)g * nq + 2 * kq) / 2;
+#endif
   const int64_t bstride = 8 * (int64_t)n_ld;
 #ifdef CF_DEBUG_ALIAS_A  // TIMING EXPERIMENT (wrong results): every factor load hits the same 16 KiB
 #define CF_A_ADV 0
@@ -1729,7 +1735,7 @@ tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict_
 #pragma unroll
     for (int j = 0; j < 4; ++j) a[p][j] = A[(p * 4 + j) * 64];
 #pragma unroll
-    for (int c = 0; c < NP; ++c) bf[p][c] = Bq[c * bstride + p * 4];
+    for (int c = 0; c < NP; ++c) bf[p][c] = Bq[c * bstride + p * CF_BQ];
   };
   auto mfma_stage = [&](int p) {
 #pragma unroll
@@ -1748,7 +1754,7 @@ tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict_
     __builtin_amdgcn_sched_barrier(0);  // stage 0 must be the oldest load
   }
   A += CF_A_ADV * PF * 4 * 64;
-  Bq += CF_B_ADV * PF * 4;
+  Bq += CF_B_ADV * PF * CF_BQ;
   const int n_groups = nq / PF, rem = nq - n_groups * PF;
   CF_GSTAMP(1);
   for (int grp = 0; grp + 1 < n_groups; ++grp) {  // branch-free body: a guard around the MFMAs makes hipcc drain vmcnt(0) per stage
@@ -1760,7 +1766,7 @@ tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict_
       __builtin_amdgcn_sched_barrier(0);
     }
     A += CF_A_ADV * PF * 4 * 64;
-    Bq += CF_B_ADV * PF * 4;
+    Bq += CF_B_ADV * PF * CF_BQ;
   }
   if (n_groups > 0) {  // last full group: only the nq % PF pairs of the tail are still to be fetched
 #pragma unroll

@@ -168,7 +168,9 @@ def test_config2_batch_invariance(config2):
     np.testing.assert_array_equal(lk.chi_squared(theta[perm]), full[perm])
     halves = np.concatenate([lk.chi_squared(theta[:2048]), lk.chi_squared(theta[2048:])])
     np.testing.assert_array_equal(halves, full)
-    for W in (1, 2, 15, 16, 17, 31, 33, 48, 63, 64, 65, 100, 256, 257):  # ragged panels; the small-batch solve kernel (<= 64) and the throughput kernel
+    # ragged panels; the small-batch path (<= 128 walkers: residuals in fragment order, 4 / 2 workgroups per walker up to 64 / 128)
+    # and the throughput kernel
+    for W in (1, 2, 15, 16, 17, 31, 33, 48, 63, 64, 65, 100, 127, 128, 129, 256, 257):
         np.testing.assert_array_equal(lk.chi_squared(theta[:W]), full[:W])
     assert lk.chi_squared(theta[:0]).shape == (0,)
 
