@@ -1824,19 +1824,36 @@ tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict_
   if (tid == 0) __hip_atomic_store(&arrivals[px], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // The shares come back through LDS: 256 threads fetch the (row block, walker) entries side by side, then thread w adds its
   // walker's shares in row-block order -- the same additions as a loop of dependent loads, without its n_rowblocks round
-  // trips to memory (27 x ~0.7 us: two thirds of a one-panel solve; profiles/r02_epilogue_loads_ab.txt).
+  // trips to memory (27 x ~0.7 us: two thirds of a one-panel solve; profiles/r02_epilogue_loads_ab.txt).  With them come one
+  // load per lane of the descriptor (from the kernel-argument segment: `d` is the first argument) and the panel's theta rows,
+  // parked in LDS for finalize_value: as scalar loads from the argument segment and dependent vector loads, one basic block each,
+  // the prior / output stage was 5 k cycles of the last arriver (tri_gemm_small_kernel, profiles/r03_small_batch_solve.txt).
+  // Straight-line code: at a loop head hipcc drains every load in flight.
   constexpr int PW = 16 * NP;
+  constexpr int DW = (int)((sizeof(cf_dev_desc) + 7) / 8);
+  static_assert(DW <= 256, "one descriptor word per thread");
   double* sh = reinterpret_cast<double*>(part);  // 4096 doubles; the K-quarter exchange is over
-  const int n_sh = pk.n_rowblocks * PW;
+  const int n_rb = pk.n_rowblocks, n_sh = n_rb * PW, n_th = PW * d.ndim;
 #ifdef CF_EPILOGUE_SERIAL  // A/B build: the loop of dependent loads
   const bool via_lds = false;
 #else
-  const bool via_lds = n_sh <= 4096;
+  const bool via_lds = n_sh + DW + PW * CF_MAX_NDIM <= 4096;  // shares, descriptor words, theta rows
 #endif
   if (via_lds) {
-    // every thread issues its loads, then stores them: one load + store per loop iteration waited a round trip to memory each
-    // (see fetch_shares_to_lds)
-    for (int base = 0; base < n_sh; base += 8 * 256) {
+    unsigned long long* desc_lds = reinterpret_cast<unsigned long long*>(sh + n_sh);
+    double* th_lds = sh + n_sh + DW;
+    const unsigned long long __attribute__((address_space(4)))* ka =
+        (const unsigned long long __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned long long dv = 0ull;
+    double tv[NP];
+    if (tid < DW) dv = ka[tid];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {  // PW * CF_MAX_NDIM = 256 NP entries at most
+      const int idx = k * 256 + tid;
+      const int64_t ti = w0 * d.ndim + idx;
+      tv[k] = (idx < n_th && ti < W * d.ndim) ? theta[ti] : 0.0;
+    }
+    auto stage = [&](int base) {
       double v[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -1848,18 +1865,37 @@ tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict_
         const int idx = base + k * 256 + tid;
         if (idx < n_sh) sh[idx] = v[k];
       }
-    }
+    };
+    stage(0);
+    if (n_sh > 8 * 256) stage(8 * 256);
+    if (tid < DW) desc_lds[tid] = dv;
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+      if (k * 256 + tid < n_th) th_lds[k * 256 + tid] = tv[k];
     lds_barrier();
-  }
-  if (tid < PW && w0 + tid < W) {
+    if (tid < PW && w0 + tid < W) {
+      const cf_dev_desc& dl = *reinterpret_cast<const cf_dev_desc*>(desc_lds);
+      const int64_t w = w0 + tid;
+      const double extra = chi2_extra ? chi2_extra[w] : 0.0;
+      double c2 = 0.0;
+      for (int r0 = 0; r0 < n_rb; r0 += 32) {  // in row-block order, 32 LDS reads in flight
+        double v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] = sh[(r0 + k < n_rb ? r0 + k : n_rb - 1) * PW + tid];
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+          if (r0 + k < n_rb) c2 += v[k];
+      }
+      if (chi2_sn_out) chi2_sn_out[w] = c2;  // the SN block alone (cf_eval_parts)
+      if (chi2_extra) c2 += extra;
+      out[w] = finalize_value(dl, th_lds + tid * dl.ndim, c2, out_kind, nonfinite);
+    }
+  } else if (tid < PW && w0 + tid < W) {
     const int64_t w = w0 + tid;
     double c2 = 0.0;
-    if (via_lds)
-      for (int r = 0; r < pk.n_rowblocks; ++r) c2 += sh[r * PW + tid];
-    else
-      for (int r = 0; r < pk.n_rowblocks; ++r)
-        c2 += __hip_atomic_load(&partial[(int64_t)r * w_pad + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (chi2_sn_out) chi2_sn_out[w] = c2;  // the SN block alone (cf_eval_parts)
+    for (int r = 0; r < n_rb; ++r)
+      c2 += __hip_atomic_load(&partial[(int64_t)r * w_pad + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (chi2_sn_out) chi2_sn_out[w] = c2;
     if (chi2_extra) c2 += chi2_extra[w];
     out[w] = finalize_value(d, theta + w * d.ndim, c2, out_kind, nonfinite);
   }
