@@ -130,21 +130,27 @@ __global__ void tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const dou
                                      int64_t w_pad, double* partial, unsigned int* arrivals, const double* chi2_extra,
                                      double* out, int out_kind, unsigned long long* nonfinite, double* chi2_sn_out,
                                      int panels_per_group, unsigned long long* done_flag, unsigned long long done_seq);
-template <int PF, bool FRAG>
+template <int PF, bool FRAG, int TPW>
 __global__ void tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* theta, int64_t W, const double* delta,
                                       double* partial4, unsigned int* arrivals, const double* chi2_extra, double* out, int out_kind,
                                       unsigned long long* nonfinite, double* chi2_sn_out, int units_pad,
                                       unsigned long long* done_flag, unsigned long long done_seq);
-#define CF_DECLARE_TRIGEMM_SMALL(PF, FRAG)                                                                                             \
-  extern template __global__ void tri_gemm_small_kernel<PF, FRAG>(cf_dev_desc, cf_dev_invpack, const double*, int64_t, const double*,   \
-                                                                  double*, unsigned int*, const double*, double*, int,                  \
-                                                                  unsigned long long*, double*, int, unsigned long long*, unsigned long long);
-CF_DECLARE_TRIGEMM_SMALL(4, false)
-CF_DECLARE_TRIGEMM_SMALL(8, false)
-CF_DECLARE_TRIGEMM_SMALL(16, false)
-CF_DECLARE_TRIGEMM_SMALL(4, true)
-CF_DECLARE_TRIGEMM_SMALL(8, true)
-CF_DECLARE_TRIGEMM_SMALL(16, true)
+#define CF_DECLARE_TRIGEMM_SMALL(PF, FRAG, TPW)                                                                                        \
+  extern template __global__ void tri_gemm_small_kernel<PF, FRAG, TPW>(cf_dev_desc, cf_dev_invpack, const double*, int64_t, const double*, \
+                                                                       double*, unsigned int*, const double*, double*, int,                \
+                                                                       unsigned long long*, double*, int, unsigned long long*, unsigned long long);
+CF_DECLARE_TRIGEMM_SMALL(4, false, 1)
+CF_DECLARE_TRIGEMM_SMALL(8, false, 1)
+CF_DECLARE_TRIGEMM_SMALL(16, false, 1)
+CF_DECLARE_TRIGEMM_SMALL(4, true, 1)
+CF_DECLARE_TRIGEMM_SMALL(8, true, 1)
+CF_DECLARE_TRIGEMM_SMALL(16, true, 1)
+CF_DECLARE_TRIGEMM_SMALL(4, false, 2)
+CF_DECLARE_TRIGEMM_SMALL(8, false, 2)
+CF_DECLARE_TRIGEMM_SMALL(4, true, 2)
+CF_DECLARE_TRIGEMM_SMALL(8, true, 2)
+CF_DECLARE_TRIGEMM_SMALL(4, false, 4)
+CF_DECLARE_TRIGEMM_SMALL(4, true, 4)
 #define CF_DECLARE_TRIGEMM(NP, PF)                                                                                       \
   extern template __global__ void tri_gemm_chi2_kernel<NP, PF>(cf_dev_desc, cf_dev_invpack, const double*, int64_t,     \
                                                                const double*, int64_t, double*, unsigned int*,          \
@@ -297,8 +303,8 @@ struct PinnedBuf {
 #define CF_DONE_FLAGS 256       // completion words per handle: panels of the largest zero-copy batch (4096 walkers / 16)
 #define CF_SMALL_MAX_PANELS 16  // largest batch of the small-batch solve kernel: 256 walkers (the default switch is lower)
 #ifndef CF_SMALL_DEFAULT
-#define CF_SMALL_DEFAULT 128  // walkers: batches up to this size take the small-batch solve kernel (faster up to 128 walkers, even at 150,
-                             // slower beyond: profiles/r03_small_batch_solve.txt)
+#define CF_SMALL_DEFAULT 160  // walkers: batches up to this size take the small-batch solve kernel (150 walkers: 39 against 44 us per call,
+                             // 200: 45-47 against 48, 256: slower; profiles/r03_small_batch_solve.txt)
 #endif
 #define CF_MAX_CHUNKS 8  // sub-batches of one evaluation (walker kernel of chunk c + 1 beside the solve of chunk c)
 
@@ -1214,11 +1220,24 @@ static int launch_tri_gemm_t(const TriGemmArgs& a, hipStream_t st) {
 
 // Small batches: one workgroup per (panel, row block, 16-row tile), see tri_gemm_small_kernel.  CF_SMALL_MAX=<walkers> moves the
 // switch (0 = never; at most 16 x CF_SMALL_MAX_PANELS), CF_SMALL_PF=4|8|16 the prefetch depth (tuning).
-template <int PF, bool FRAG>
+template <int PF, bool FRAG, int TPW>
 static int launch_tri_gemm_small_t(const TriGemmArgs& a, hipStream_t st) {
   const int panels = (int)((a.W + 15) / 16);
-  const int units_pad = (4 * a.pk->n_rowblocks + 7) / 8 * 8;
-  hipLaunchKernelGGL((tri_gemm_small_kernel<PF, FRAG>), dim3((unsigned)(panels * units_pad)), dim3(256), 0, st, *a.d, *a.pk, a.theta, a.W,
+  const int units_pad = ((4 / TPW) * a.pk->n_rowblocks + 7) / 8 * 8;
+  // dynamic LDS: the last arriver's shares + row-block sums -- padded so that at most TWO workgroups fit a CU.  With several
+  // panels the grid outnumbers the CUs, and left to itself the dispatcher stacks three or four of these bandwidth-bound workgroups
+  // on some CUs while others hold one (75 walkers: 33.7-34.6 -> 31.8-32.2 us per call, 150 walkers with two tiles per workgroup:
+  // 44 -> 39 us; profiles/r03_small_batch_solve.txt).  CF_SMALL_LDS_CAP=0 turns the padding off (tuning).
+  static const bool cap2 = [] { const char* e = getenv("CF_SMALL_LDS_CAP"); return !e || atoi(e) != 0; }();
+  static const size_t static_lds = [] {
+    hipFuncAttributes fa;
+    return hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&tri_gemm_small_kernel<PF, FRAG, TPW>)) == hipSuccess ? fa.sharedSizeBytes
+                                                                                                                          : (size_t)0;
+  }();
+  size_t dyn_lds = 64 * a.pk->n_rowblocks <= 4096 ? (size_t)80 * a.pk->n_rowblocks * 8 : 0;
+  const size_t third_of_cu = 160 * 1024 / 3 + 1024;  // a third of a CU's LDS and a little: three workgroups no longer fit
+  if (cap2 && static_lds + dyn_lds < third_of_cu && third_of_cu - static_lds <= 64 * 1024) dyn_lds = third_of_cu - static_lds;
+  hipLaunchKernelGGL((tri_gemm_small_kernel<PF, FRAG, TPW>), dim3((unsigned)(panels * units_pad)), dim3(256), dyn_lds, st, *a.d, *a.pk, a.theta, a.W,
                      a.delta, a.partial4, a.arrivals, a.chi2_extra, a.out, a.out_kind, a.nonfinite, a.chi2_sn_out, units_pad,
                      a.done_flag, a.done_seq);
   return 0;
@@ -1235,11 +1254,21 @@ static int64_t small_batch_max() {
 
 static int launch_tri_gemm(const TriGemmArgs& a, hipStream_t st) {
   if (a.W <= small_batch_max() && a.partial4) {
-    static const int pf = [] { const char* e = getenv("CF_SMALL_PF"); return e ? atoi(e) : 16; }();
+    // tiles per workgroup (CF_SMALL_TPW=1|2|4 overrides) and prefetch depth (CF_SMALL_PF=4|8|16; at most 8 / 4 for 2 / 4 tiles)
+    static const int pf_env = [] { const char* e = getenv("CF_SMALL_PF"); return e ? atoi(e) : 0; }();
+    static const int tpw_env = [] { const char* e = getenv("CF_SMALL_TPW"); return e ? atoi(e) : 0; }();
+    const int tpw = tpw_env > 0 ? tpw_env : (a.W <= 96 ? 1 : 2);  // measured: one tile up to 96 walkers (75: 32.0 against 34.0 us), two beyond (128: 37 against 38.5)
+    const int pf = pf_env > 0 ? pf_env : (tpw == 1 ? 16 : (tpw == 2 ? 8 : 4));
+    const bool f = a.frag_b;
+    if (tpw == 4) return f ? launch_tri_gemm_small_t<4, true, 4>(a, st) : launch_tri_gemm_small_t<4, false, 4>(a, st);
+    if (tpw == 2) {
+      if (pf <= 4) return f ? launch_tri_gemm_small_t<4, true, 2>(a, st) : launch_tri_gemm_small_t<4, false, 2>(a, st);
+      return f ? launch_tri_gemm_small_t<8, true, 2>(a, st) : launch_tri_gemm_small_t<8, false, 2>(a, st);
+    }
     switch (pf) {
-      case 4: return a.frag_b ? launch_tri_gemm_small_t<4, true>(a, st) : launch_tri_gemm_small_t<4, false>(a, st);
-      case 8: return a.frag_b ? launch_tri_gemm_small_t<8, true>(a, st) : launch_tri_gemm_small_t<8, false>(a, st);
-      default: return a.frag_b ? launch_tri_gemm_small_t<16, true>(a, st) : launch_tri_gemm_small_t<16, false>(a, st);
+      case 4: return f ? launch_tri_gemm_small_t<4, true, 1>(a, st) : launch_tri_gemm_small_t<4, false, 1>(a, st);
+      case 8: return f ? launch_tri_gemm_small_t<8, true, 1>(a, st) : launch_tri_gemm_small_t<8, false, 1>(a, st);
+      default: return f ? launch_tri_gemm_small_t<16, true, 1>(a, st) : launch_tri_gemm_small_t<16, false, 1>(a, st);
     }
   }
   if (a.frag_b) return fail(CF_ERR_INVALID, "internal: fragment-ordered residuals handed to the throughput solve kernel");
@@ -1300,7 +1329,7 @@ static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_
       // a small batch leaves most of the chip idle: several workgroups per walker, each with the walker's table and a share of
       // its SNe (CF_SN_PARTS=1|2|4 overrides)
       static const int parts_env = [] { const char* e = getenv("CF_SN_PARTS"); return e ? atoi(e) : 0; }();
-      int sn_parts = parts_env > 0 ? parts_env : (Wc <= 64 ? 4 : (Wc <= 128 ? 2 : 1));  // measured: W = 16 26.5 -> 25.3 us, W = 64 31.5 -> 30.1 us per call
+      int sn_parts = parts_env > 0 ? parts_env : (Wc <= 64 ? 4 : (Wc <= 160 ? 2 : 1));  // measured: W = 16 26.5 -> 25.3 us, W = 64 31.5 -> 30.1 us per call
       if (sn_parts > CF_SN_PARTS_MAX || d.n_sn == 0) sn_parts = 1;
       hipLaunchKernelGGL(pick_walker_fast(d.ez_model, d.fde), dim3((unsigned)(Wc * sn_parts)), dim3(512), lds, st, walker_args_of(d), th,
                          Wc, delta, bao_nodes, th_copy, frag_b ? 1 : 0, sn_parts);

@@ -11,7 +11,7 @@
 //   tri_gemm_chi2_kernel / tri_gemm_small_kernel   (a11)   chi^2 = || X Delta ||^2 with X = L^-1 inverted once on the
 //        host: a triangular GEMM on FP64 matrix cores (v_mfma_f64_16x16x4_f64) with no dependency between 64-row
 //        blocks; one workgroup per (row block, panel of 16-32 walkers), or per (panel, row block, 16-row tile) for
-//        batches of <= 128 walkers (bit-identical); the workgroup that arrives last for a panel adds the shares in a
+//        batches of <= 160 walkers (bit-identical); the workgroup that arrives last for a panel adds the shares in a
 //        fixed order and applies the prior / output epilogue.  trsm_chi2_kernel (blocked forward substitution) is the
 //        fallback when the explicit inverse fails its create-time probe.
 //
@@ -1957,16 +1957,22 @@ extern "C" int cf_debug_small_epi(unsigned long long* out) {
 #define CF_EWALL(k)
 #endif
 
-template <int PF, bool FRAG>
+template <int PF, bool FRAG, int TPW>
 __global__ void __launch_bounds__(256)
 tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict__ theta, int64_t W,
                       const double* __restrict__ delta, double* partial4, unsigned int* arrivals,
                       const double* __restrict__ chi2_extra, double* __restrict__ out, int out_kind,
                       unsigned long long* nonfinite, double* __restrict__ chi2_sn_out, int units_pad,
                       unsigned long long* done_flag, unsigned long long done_seq) {
-  __shared__ __align__(16) d4 part[4][64];  // [K quarter][lane] partial tile: 8 KB
-  __shared__ double sh[4096];               // the panel's shares in the last arriver: [row block][tile][walker]
-  __shared__ double rbs[1024];              // ... and their sums over the tiles: [row block][walker]
+  static_assert(TPW == 1 || TPW == 2 || TPW == 4, "tiles per workgroup");
+  __shared__ __align__(16) d4 part[4][TPW][64];  // [K quarter][tile][lane] partial tiles: 8 KB per tile
+  __shared__ double chi_tile[TPW][16];
+  // the last arriver's copy of the panel's shares [row block][tile][walker] and their sums over the tiles [row block][walker]:
+  // dynamic LDS, 80 n_rb doubles (the launcher sizes it; none when the shares exceed 4096 doubles), so that the workgroups of a
+  // many-panel batch fit four to a CU
+  extern __shared__ double small_dyn[];
+  double* const sh = small_dyn;
+  double* const rbs = small_dyn + 64 * pk.n_rowblocks;
   __shared__ __align__(16) unsigned long long desc_lds[(sizeof(cf_dev_desc) + 7) / 8];  // the last arriver's copy of `d` (see below)
   __shared__ double th_lds[16 * CF_MAX_NDIM];                                           // ... and of the panel's theta rows
   __shared__ unsigned int arrived_before;
@@ -1974,8 +1980,11 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
   const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
   const int col = lane & 15, kq = lane >> 4;
   const int unit = (int)blockIdx.x % units_pad, px = (int)blockIdx.x / units_pad;
-  if (unit >= 4 * n_rb) return;
-  const int rb = n_rb - 1 - (unit >> 2), j = unit & 3;
+  // TPW tiles per workgroup (units of TPW / 4 row block): with more than ~2 panels the one-tile units outnumber the CUs and share
+  // their L1 bandwidth, and a unit of several tiles loads a residual fragment once for all of them
+  constexpr int UPR = 4 / TPW;  // units per row block
+  if (unit >= UPR * n_rb) return;
+  const int rb = n_rb - 1 - unit / UPR, j = (unit % UPR) * TPW;  // first tile of the unit
   const int64_t w0 = (int64_t)px * 16;
   if (w0 >= W) return;
   const int nq = 2 * (rb + 1);  // K-step pairs per wave
@@ -1994,8 +2003,21 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
   constexpr int BS = FRAG ? 64 : 4;  // d2 per K-step pair
   const d2* Bq = FRAG ? reinterpret_cast<const d2*>(delta) + ((int64_t)px * (n_ld / 8) + (int64_t)g * nq) * 64 + lane
                       : reinterpret_cast<const d2*>(delta) + ((w0 + col) * (int64_t)n_ld + 8 * (int64_t)g * nq + 2 * kq) / 2;
-  d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-  d2 a[PF], bf[PF];
+  d4 acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+  d2 a[PF][TPW], bf[PF];
+  auto load_pair = [&](int p, int q) {
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) a[p][t] = A[q * 256 + t * 64];
+    bf[p] = Bq[q * BS];
+  };
+  auto mfma_pair = [&](int p) {  // per tile: the pair's two K steps in order, as the throughput kernel accumulates them
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = mfma_f64(a[p][t].x, bf[p].x, acc[t]);
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = mfma_f64(a[p][t].y, bf[p].y, acc[t]);
+  };
 #ifdef CF_SMALL_ALIAS_A  // TIMING EXPERIMENTS (wrong results): every factor / residual load of a wave hits its first PF pairs
 #define CF_SA_ADV 0
 #else
@@ -2009,9 +2031,7 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int p = 0; p < PF; ++p) {  // a short stream (nq < PF) re-reads its last pair: nothing outside the wave's range is touched
-    const int q = p < nq ? p : nq - 1;
-    a[p] = A[q * 256];
-    bf[p] = Bq[q * BS];
+    load_pair(p, p < nq ? p : nq - 1);
     __builtin_amdgcn_sched_barrier(0);  // stage 0 must be the oldest load
   }
   A += CF_SA_ADV * PF * 256;
@@ -2020,11 +2040,9 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
   for (int grp = 0; grp + 1 < n_groups; ++grp) {  // branch-free body, as in the throughput kernel
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
-      acc = mfma_f64(a[p].x, bf[p].x, acc);
-      acc = mfma_f64(a[p].y, bf[p].y, acc);
+      mfma_pair(p);
       __builtin_amdgcn_sched_barrier(0);
-      a[p] = A[p * 256];
-      bf[p] = Bq[p * BS];
+      load_pair(p, p);
       __builtin_amdgcn_sched_barrier(0);
     }
     A += CF_SA_ADV * PF * 256;
@@ -2033,22 +2051,15 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
   if (n_groups > 0) {  // last full group: only the nq % PF pairs of the tail are still to be fetched
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
-      acc = mfma_f64(a[p].x, bf[p].x, acc);
-      acc = mfma_f64(a[p].y, bf[p].y, acc);
+      mfma_pair(p);
       __builtin_amdgcn_sched_barrier(0);
-      if (p < rem) {
-        a[p] = A[p * 256];
-        bf[p] = Bq[p * BS];
-      }
+      if (p < rem) load_pair(p, p);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
 #pragma unroll
   for (int p = 0; p < PF - 1; ++p)
-    if (p < rem) {
-      acc = mfma_f64(a[p].x, bf[p].x, acc);
-      acc = mfma_f64(a[p].y, bf[p].y, acc);
-    }
+    if (p < rem) mfma_pair(p);
   CF_SSTAMP(1);
   // The prior / output epilogue of the LAST ARRIVER reads a dozen fields of `d` and the walkers' theta rows: as scalar loads from the
   // kernel-argument segment and dependent vector loads, each in its own basic block, they were 5 k cycles of the one workgroup the
@@ -2067,27 +2078,40 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
     if (tid < DW) dv = ka[tid];
     if (tid < n_th && ti < W * d.ndim) tv = theta[ti];
   }
-  part[g][lane] = acc;
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) part[g][t][lane] = acc[t];
   lds_barrier();
   CF_SSTAMP(2);
 #if defined(CF_DBG_SMALL) && CF_DBG_SMALL == 2
-  if (acc[0] == 1.2345e300) out[0] = acc[1];  // keeps the loop alive
+  if (acc[0][0] == 1.2345e300) out[0] = acc[0][1];  // keeps the loop alive
   return;
 #endif
   // hand-off as in the throughput kernel (agent-scope write-through stores, vmcnt(0), one relaxed agent-scope add, the last
-  // arriver's acquire fence); one counter per panel counts the 4 n_rb (row block, tile) workgroups
+  // arriver's acquire fence); one counter per panel counts the 4 n_rb (row block, tile) shares, TPW per workgroup
   double* mine = partial4 + (int64_t)px * (4 * n_rb * 16);
+  if (TPW == 1) {
+    if (g == 0) {
+      const double v = tile_chi2_share(part[0][0][lane], part[1][0][lane], part[2][0][lane], part[3][0][lane]);
+      if (lane < 16) __hip_atomic_store(&mine[(rb * 4 + j) * 16 + lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else {  // wave t forms tile t's share; wave 0 stores them all, so that its vmcnt(0) covers every store in front of the add
+    if (g < TPW) {
+      const double v = tile_chi2_share(part[0][g][lane], part[1][g][lane], part[2][g][lane], part[3][g][lane]);
+      if (lane < 16) chi_tile[g][lane] = v;
+    }
+    lds_barrier();
+    if (g == 0 && lane < 16 * TPW)
+      __hip_atomic_store(&mine[(rb * 4 + j) * 16 + lane], chi_tile[lane >> 4][lane & 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (g == 0) {
-    const double v = tile_chi2_share(part[0][lane], part[1][lane], part[2][lane], part[3][lane]);
-    if (lane < 16) __hip_atomic_store(&mine[(rb * 4 + j) * 16 + lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0)
-      arrived_before = __hip_atomic_fetch_add(&arrivals[px], 1u, CF_ARRIVE_ORDER, __HIP_MEMORY_SCOPE_AGENT);
+      arrived_before = __hip_atomic_fetch_add(&arrivals[px], (unsigned)TPW, CF_ARRIVE_ORDER, __HIP_MEMORY_SCOPE_AGENT);
   }
   lds_barrier();
   CF_SSTAMP(3);
   CF_SWALL(7);
-  if (arrived_before != 4u * (unsigned)n_rb - 1u) return;
+  if (arrived_before != 4u * (unsigned)n_rb - (unsigned)TPW) return;
   CF_ESTAMP(0);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   if (tid == 0) __hip_atomic_store(&arrivals[px], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2157,16 +2181,22 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
   CF_EWALL(15);
   CF_SSTAMP(4);
 }
-#define CF_INSTANTIATE_TRIGEMM_SMALL(PF, FRAG)                                                                                     \
-  template __global__ void tri_gemm_small_kernel<PF, FRAG>(cf_dev_desc, cf_dev_invpack, const double*, int64_t, const double*, double*, \
-                                                           unsigned int*, const double*, double*, int, unsigned long long*, double*, int, \
-                                                           unsigned long long*, unsigned long long);
-CF_INSTANTIATE_TRIGEMM_SMALL(4, false)
-CF_INSTANTIATE_TRIGEMM_SMALL(8, false)
-CF_INSTANTIATE_TRIGEMM_SMALL(16, false)
-CF_INSTANTIATE_TRIGEMM_SMALL(4, true)
-CF_INSTANTIATE_TRIGEMM_SMALL(8, true)
-CF_INSTANTIATE_TRIGEMM_SMALL(16, true)
+#define CF_INSTANTIATE_TRIGEMM_SMALL(PF, FRAG, TPW)                                                                                     \
+  template __global__ void tri_gemm_small_kernel<PF, FRAG, TPW>(cf_dev_desc, cf_dev_invpack, const double*, int64_t, const double*, double*, \
+                                                                unsigned int*, const double*, double*, int, unsigned long long*, double*, int, \
+                                                                unsigned long long*, unsigned long long);
+CF_INSTANTIATE_TRIGEMM_SMALL(4, false, 1)
+CF_INSTANTIATE_TRIGEMM_SMALL(8, false, 1)
+CF_INSTANTIATE_TRIGEMM_SMALL(16, false, 1)
+CF_INSTANTIATE_TRIGEMM_SMALL(4, true, 1)
+CF_INSTANTIATE_TRIGEMM_SMALL(8, true, 1)
+CF_INSTANTIATE_TRIGEMM_SMALL(16, true, 1)
+CF_INSTANTIATE_TRIGEMM_SMALL(4, false, 2)
+CF_INSTANTIATE_TRIGEMM_SMALL(8, false, 2)
+CF_INSTANTIATE_TRIGEMM_SMALL(4, true, 2)
+CF_INSTANTIATE_TRIGEMM_SMALL(8, true, 2)
+CF_INSTANTIATE_TRIGEMM_SMALL(4, false, 4)
+CF_INSTANTIATE_TRIGEMM_SMALL(4, true, 4)
 
 // ------------------------------------------------------------------------------------------------
 // Likelihoods without an SN block: only the epilogue.
