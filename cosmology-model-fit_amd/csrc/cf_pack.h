@@ -308,7 +308,7 @@ static void cf_pack_inverse(const double* L, int64_t n, int64_t ld, cf_host_invp
   int64_t total = 0;
   for (int rb = 0; rb < RB; ++rb)
     for (int g = 0; g < 4; ++g) {
-      out.off[rb * 4 + g] = cf_inv_stream_off(rb, g);  // == total: the streams are contiguous in (rb, g) order
+      out.off[rb * 4 + g] = total;  // == cf_inv_stream_off(rb, g), which the kernels evaluate (cf_invpack_probe checks it)
       total += (int64_t)2 * (rb + 1) * 4;
     }
   total += 32;  // slack for the kernel's software pipeline
@@ -356,6 +356,10 @@ static double cf_invpack_replay_host(const cf_host_invpack& pk, const double* b_
 // CF_PROBE_MODES right-hand sides (cf_probe_rhs).
 static double cf_invpack_probe(const cf_host_invpack& pk, const double* L, int64_t ld) {
   double worst = 0.0;
+  // the solve kernels compute a stream's offset in closed form: a pack laid out differently must not reach them
+  for (int rb = 0; rb < pk.n_rowblocks; ++rb)
+    for (int g = 0; g < 4; ++g)
+      if (pk.off[rb * 4 + g] != cf_inv_stream_off(rb, g)) return INFINITY;
   std::vector<double> b;
   for (int mode = 0; mode < CF_PROBE_MODES; ++mode) {
     cf_probe_rhs(mode, pk.n, b);

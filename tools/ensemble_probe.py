@@ -18,7 +18,8 @@ for name in ("stretch", "de", "kde"):
     e = amd.ensemble.ShardedEnsemble(f, x0, seed=3, moves=((name, 1.0),))
     e.run(5); torch.cuda.synchronize(); t0 = time.perf_counter()
     e.run(30); torch.cuda.synchronize()
-    print(f"{name:8s}: {(time.perf_counter() - t0) / 30 * 1e3:.3f} ms per step (2 half-steps of {W // 2} walkers), acceptance {e.acceptance_fraction():.2f}")
+    n_upd = 3 if name == "de" else 2
+    print(f"{name:8s}: {(time.perf_counter() - t0) / 30 * 1e3:.3f} ms per step ({n_upd} split updates), acceptance {e.acceptance_fraction():.2f}")
 e = amd.ensemble.ShardedEnsemble(f, x0, seed=3, moves=amd.ensemble.REFERENCE_MOVES)
 e.run(5); torch.cuda.synchronize(); t0 = time.perf_counter()
 e.run(100); torch.cuda.synchronize()
