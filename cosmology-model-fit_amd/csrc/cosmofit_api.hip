@@ -1339,7 +1339,7 @@ static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_
                          bao_nodes, (d2*)nullptr);
     if (ev) HIP_TRY(hipEventRecord(ev[1], st));  // between walker_kernel and the small-block / growth kernels
     if (h->has_small_blocks)  // sixteen lanes per walker, sixteen walkers per workgroup
-      hipLaunchKernelGGL(pick_small_blocks(d.ez_model, d.fde), dim3((unsigned)((Wc + 15) / 16)), dim3(256), 0, st, d, th, Wc,
+      hipLaunchKernelGGL(pick_small_blocks(d.ez_model, d.fde), dim3((unsigned)((Wc + 256 / CF_SB_LANES - 1) / (256 / CF_SB_LANES))), dim3(256), 0, st, d, th, Wc,
                          (const d2*)bao_nodes, extra, blocks_out, bao_out);
     if (h->has_growth)  // 256 lanes per walker: the growth ODE as a scan of 2 x 2 step matrices, the f sigma_8 quadratic form
       hipLaunchKernelGGL(pick_growth(d.ez_model, d.fde, d.fs8_steps), dim3((unsigned)Wc), dim3(256),

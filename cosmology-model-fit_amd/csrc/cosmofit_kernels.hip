@@ -879,8 +879,7 @@ walker_fast_kernel(cf_walker_args d, const double* __restrict__ theta, int64_t W
 //   datum k: Hermite D_M; D_H by PCHIP with the two Fritsch-Carlson slopes it needs, or exactly as c/H
 //   (bao/desi_cmb_des5y.py:82-100,132-135) -- then column j of delta @ inv_cov, then ... @ delta by a butterfly
 // ------------------------------------------------------------------------------------------------
-#define CF_SB_LANES 16
-__device__ __forceinline__ double group_sum(double v) {  // over the 16 lanes of a walker
+__device__ __forceinline__ double group_sum(double v) {  // over the CF_SB_LANES lanes of a walker
 #pragma unroll
   for (int o = CF_SB_LANES / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o, CF_SB_LANES);
   return v;
