@@ -39,7 +39,7 @@ __global__ void walker_kernel(cf_dev_desc d, const double* theta, int64_t W, dou
 template <int MODEL, int FDE>
 __global__ void walker_fast_kernel(cf_walker_args d, const double* theta, int64_t W, double* delta, d2* bao_nodes, double* theta_copy,
                                    int frag_b, int sn_parts);
-template <int MODEL, int FDE>
+template <int MODEL, int FDE, int LANES>
 __global__ void small_blocks_kernel(cf_dev_desc d, const double* theta, int64_t W, const d2* bao_nodes, double* chi2_extra,
                                     double* blocks_out, double* bao_out);
 template <int MODEL, int FDE, int C>
@@ -52,8 +52,10 @@ __global__ void hz_kernel(cf_dev_desc d, const double* theta, const double* z, i
 #define CF_DECLARE_WALKER(M, F)                                                                                            \
   extern template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*, d2*); \
   extern template __global__ void walker_fast_kernel<M, F>(cf_walker_args, const double*, int64_t, double*, d2*, double*, int, int); \
-  extern template __global__ void small_blocks_kernel<M, F>(cf_dev_desc, const double*, int64_t, const d2*, double*,       \
-                                                            double*, double*);                                            \
+  extern template __global__ void small_blocks_kernel<M, F, 16>(cf_dev_desc, const double*, int64_t, const d2*, double*,   \
+                                                                double*, double*);                                        \
+  extern template __global__ void small_blocks_kernel<M, F, 64>(cf_dev_desc, const double*, int64_t, const d2*, double*,   \
+                                                                double*, double*);                                        \
   extern template __global__ void hz_kernel<M, F>(cf_dev_desc, const double*, const double*, int64_t, double*);             \
   CF_DECLARE_GROWTH(M, F, 1) CF_DECLARE_GROWTH(M, F, 2) CF_DECLARE_GROWTH(M, F, 4) CF_DECLARE_GROWTH(M, F, 8)
 CF_DECLARE_WALKER(0, 0) CF_DECLARE_WALKER(0, 1) CF_DECLARE_WALKER(0, 2) CF_DECLARE_WALKER(0, 3)
@@ -93,11 +95,14 @@ static cf_walker_args walker_args_of(const cf_dev_desc& d) {
   return a;
 }
 typedef void (*small_blocks_fn)(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, double*);
-static small_blocks_fn pick_small_blocks(int model, int fde) {
-  static const small_blocks_fn table[2][4] = {
-      {small_blocks_kernel<0, 0>, small_blocks_kernel<0, 1>, small_blocks_kernel<0, 2>, small_blocks_kernel<0, 3>},
-      {small_blocks_kernel<1, 0>, small_blocks_kernel<1, 1>, small_blocks_kernel<1, 2>, small_blocks_kernel<1, 3>}};
-  return table[model][fde];
+static small_blocks_fn pick_small_blocks(int model, int fde, int lanes) {  // lanes per walker: 16 or 64
+  static const small_blocks_fn narrow[2][4] = {
+      {small_blocks_kernel<0, 0, 16>, small_blocks_kernel<0, 1, 16>, small_blocks_kernel<0, 2, 16>, small_blocks_kernel<0, 3, 16>},
+      {small_blocks_kernel<1, 0, 16>, small_blocks_kernel<1, 1, 16>, small_blocks_kernel<1, 2, 16>, small_blocks_kernel<1, 3, 16>}};
+  static const small_blocks_fn wide[2][4] = {
+      {small_blocks_kernel<0, 0, 64>, small_blocks_kernel<0, 1, 64>, small_blocks_kernel<0, 2, 64>, small_blocks_kernel<0, 3, 64>},
+      {small_blocks_kernel<1, 0, 64>, small_blocks_kernel<1, 1, 64>, small_blocks_kernel<1, 2, 64>, small_blocks_kernel<1, 3, 64>}};
+  return lanes == 64 ? wide[model][fde] : narrow[model][fde];
 }
 typedef void (*hz_fn)(cf_dev_desc, const double*, const double*, int64_t, double*);
 static hz_fn pick_hz(int model, int fde) {
@@ -1338,9 +1343,17 @@ static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_
       hipLaunchKernelGGL(pick_walker(d.ez_model, d.fde), dim3((unsigned)Wc), dim3(512), lds, st, d, th, Wc, delta, dm_out, mucorr_out,
                          bao_nodes, (d2*)nullptr);
     if (ev) HIP_TRY(hipEventRecord(ev[1], st));  // between walker_kernel and the small-block / growth kernels
-    if (h->has_small_blocks)  // sixteen lanes per walker, sixteen walkers per workgroup
-      hipLaunchKernelGGL(pick_small_blocks(d.ez_model, d.fde), dim3((unsigned)((Wc + 256 / CF_SB_LANES - 1) / (256 / CF_SB_LANES))), dim3(256), 0, st, d, th, Wc,
+    if (h->has_small_blocks) {
+      // sixteen lanes per walker, sixteen walkers per workgroup (4096 walkers = one wave per SIMD, issue-bound); below that the
+      // chip is not full and the time is the serial chain of a lane: a whole wave per walker then (4 instead of 13 Gauss-Legendre
+      // nodes per lane).  Measured on the w0waCDM joint likelihood: 16 walkers 50.7 -> 45.1 us per call, 256: 77 -> 67, 2048: 193 ->
+      // 185, 4096: 329 -> 334 (profiles/r03_small_blocks_lanes_ab.txt).  The sums do not depend on the width (VirtualLaneSum): a
+      // walker's result is the same bits either way.  CF_SB_WIDE_MAX=<walkers> moves the switch.
+      static const int64_t wide_max = [] { const char* e = getenv("CF_SB_WIDE_MAX"); return e ? atoll(e) : 2048ll; }();
+      const int lanes = Wc <= wide_max ? 64 : 16, per_wg = 256 / lanes;
+      hipLaunchKernelGGL(pick_small_blocks(d.ez_model, d.fde, lanes), dim3((unsigned)((Wc + per_wg - 1) / per_wg)), dim3(256), 0, st, d, th, Wc,
                          (const d2*)bao_nodes, extra, blocks_out, bao_out);
+    }
     if (h->has_growth)  // 256 lanes per walker: the growth ODE as a scan of 2 x 2 step matrices, the f sigma_8 quadratic form
       hipLaunchKernelGGL(pick_growth(d.ez_model, d.fde, d.fs8_steps), dim3((unsigned)Wc), dim3(256),
                          (size_t)(2 * (d.fs8_steps + 1) + 16 + CF_MAX_FS8 + 2 + 256) * 8, st, d, th, Wc, (const d2*)bao_nodes, extra,
@@ -1781,7 +1794,7 @@ extern "C" int cf_eval_bao_at(cf_handle* h, const double* theta, const double* z
     const size_t lds = ((size_t)d.n_grid + (d.n_grid >> d.chunk_shift) + 2) * 16;
     hipLaunchKernelGGL(pick_walker(d.ez_model, d.fde), dim3(1), dim3(512), lds, h->stream, d, h->theta.as<const double>(), (int64_t)1,
                        (double*)nullptr, (double*)nullptr, (double*)nullptr, nodes.as<d2>(), (d2*)nullptr);
-    hipLaunchKernelGGL(pick_small_blocks(d.ez_model, d.fde), dim3(1), dim3(256), 0, h->stream, d, h->theta.as<const double>(), (int64_t)1,
+    hipLaunchKernelGGL(pick_small_blocks(d.ez_model, d.fde, 16), dim3(1), dim3(256), 0, h->stream, d, h->theta.as<const double>(), (int64_t)1,
                        (const d2*)nodes.as<d2>(), extra.as<double>(), (double*)nullptr, dout.as<double>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out + k0, dout.p, (size_t)m * 8, hipMemcpyDeviceToHost, h->stream));

@@ -7,9 +7,6 @@
 #include <stdint.h>
 
 #define CF_MAX_NDIM 16
-#ifndef CF_SB_LANES
-#define CF_SB_LANES 16  // lanes per walker of small_blocks_kernel (a power of two, 16 .. 64)
-#endif
 #define CF_MAX_GAUSS 8
 #define CF_MAX_BAO 64
 #define CF_MAX_GL 256

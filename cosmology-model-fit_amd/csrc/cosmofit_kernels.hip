@@ -879,29 +879,72 @@ walker_fast_kernel(cf_walker_args d, const double* __restrict__ theta, int64_t W
 //   datum k: Hermite D_M; D_H by PCHIP with the two Fritsch-Carlson slopes it needs, or exactly as c/H
 //   (bao/desi_cmb_des5y.py:82-100,132-135) -- then column j of delta @ inv_cov, then ... @ delta by a butterfly
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double group_sum(double v) {  // over the CF_SB_LANES lanes of a walker
+template <int LANES>
+__device__ __forceinline__ double group_sum(double v) {  // over the LANES lanes of a walker
 #pragma unroll
-  for (int o = CF_SB_LANES / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o, CF_SB_LANES);
+  for (int o = LANES / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o, LANES);
   return v;
 }
 
-// delta @ inv_cov @ delta for a vector held in LDS (n <= 64): lane j, j + 16, ... forms column j in the
-// reference's order of operations, the lanes' products meet in a butterfly
+// A sum over items k = 0 .. n - 1 spread over the lanes of a walker's group that does NOT depend on the group's width (16, 32 or
+// 64 lanes: a batch of a few walkers takes wide groups -- fewer items per lane, a shorter serial chain -- a large one narrow
+// groups, and a walker's result must be the same bits in both).  64 VIRTUAL lanes: virtual lane v adds its items v, v + 64, ...
+// in ascending order, and the 64 partial sums meet in the xor butterfly of a 64-lane group.  A group of LANES < 64 lanes keeps
+// NV = 64 / LANES partial sums per lane (lane sl holds the virtual lanes sl, sl + LANES, ...) and folds them in the butterfly's own
+// order -- its first log2(NV) levels -- before the remaining levels run across the lanes.
+// Use: every lane calls push() the same number of times, iteration `it` with the term of item sl + it LANES (0.0 past the end);
+// the partial sums rotate through a[] so that the one being added to is always a[0] (registers, no dynamic index).
+template <int LANES>
+struct VirtualLaneSum {
+  static constexpr int NV = 64 / LANES;
+  double a[NV];
+  __device__ __forceinline__ VirtualLaneSum() {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) a[j] = 0.0;
+  }
+  __device__ __forceinline__ void push(double t) {
+    const double tmp = a[0] + t;
+#pragma unroll
+    for (int j = 0; j + 1 < NV; ++j) a[j] = a[j + 1];
+    a[NV - 1] = tmp;
+  }
+  __device__ __forceinline__ double total(int pushes) const {  // after `pushes` calls virtual lane sl + j LANES sits in a[(j - pushes) mod NV]
+    double v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      v[j] = a[0];
+#pragma unroll
+      for (int i = 1; i < NV; ++i) v[j] = (((j - pushes) & (NV - 1)) == i) ? a[i] : v[j];
+    }
+    double r = v[0];
+    if (NV == 2) r = v[0] + v[1];
+    if (NV == 4) r = (v[0] + v[2]) + (v[1] + v[3]);
+    return group_sum<LANES>(r);
+  }
+};
+
+// delta @ inv_cov @ delta for a vector held in LDS (n <= 64): a lane forms column j (j = sl, sl + LANES, ...) in the reference's
+// order of operations; the columns' products meet in a VirtualLaneSum
+template <int LANES>
 __device__ __forceinline__ double group_quadratic_form(const double* __restrict__ dl, const double* __restrict__ inv_cov, int n,
                                                        int sl) {
-  double acc = 0.0;
-  for (int j = sl; j < n; j += CF_SB_LANES) {
+  VirtualLaneSum<LANES> acc;
+  const int iters = (n + LANES - 1) / LANES;
+  for (int it = 0; it < iters; ++it) {
+    const int j = sl + it * LANES, jc = j < n ? j : n - 1;
     double t = 0.0;
-    for (int i = 0; i < n; ++i) t += dl[i] * inv_cov[i * n + j];
-    acc += t * dl[j];
+    for (int i = 0; i < n; ++i) t += dl[i] * inv_cov[i * n + jc];
+    acc.push(j < n ? t * dl[jc] : 0.0);
   }
-  return group_sum(acc);
+  return acc.total(iters);
 }
 
-template <int MODEL, int FDE>
+template <int MODEL, int FDE, int LANES>
 __global__ void __launch_bounds__(256)
 small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, const d2* __restrict__ bao_nodes,
                     double* __restrict__ chi2_extra, double* __restrict__ blocks_out, double* __restrict__ bao_out) {
+  static_assert(LANES == 16 || LANES == 32 || LANES == 64, "lanes per walker");
+  constexpr int CF_SB_LANES = LANES;
   __shared__ double delta_s[256 / CF_SB_LANES][CF_MAX_BAO > CF_MAX_CC ? CF_MAX_BAO : CF_MAX_CC];
   const int grp = threadIdx.x / CF_SB_LANES, sl = threadIdx.x % CF_SB_LANES;
   const int64_t w_raw = (int64_t)blockIdx.x * (256 / CF_SB_LANES) + grp;
@@ -952,16 +995,19 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
 
   double c_cmb = 0.0, vec[3] = {0.0, 0.0, 0.0};
   if (d.cmb_mode) {
-    double s_rs = 0.0, s_dm = 0.0;
+    VirtualLaneSum<LANES> s_rs, s_dm;
     const double half_a = (1.0 / (1.0 + z_star)) / 2.0, half_z = z_star / 2.0;
-    for (int k = sl; k < d.n_gl; k += CF_SB_LANES) {
+    const int gl_iters = (d.n_gl + LANES - 1) / LANES;  // the same for every lane (VirtualLaneSum); a lane past the last node adds 0
+    for (int it = 0; it < gl_iters; ++it) {
+      const int k_raw = sl + it * LANES, k = k_raw < d.n_gl ? k_raw : d.n_gl - 1;
+      const double gw = k_raw < d.n_gl ? d.gl_w[k] : 0.0;
       const double a = half_a * d.gl_x[k] + half_a;
       const double z = (1.0 / a) - 1.0;
       const double Rb = (3.0 / 4.0) * (Ob / d.o_gamma_h2) * a;
-      s_rs += d.gl_w[k] * (d.c / (a * a * H_of_z<MODEL, FDE>(d, wc, z) * sqrt(3.0 * (1.0 + Rb))));
-      s_dm += d.gl_w[k] * (d.c / H_of_z<MODEL, FDE>(d, wc, half_z * d.gl_x[k] + half_z));
+      s_rs.push(gw * (d.c / (a * a * H_of_z<MODEL, FDE>(d, wc, z) * sqrt(3.0 * (1.0 + Rb)))));
+      s_dm.push(gw * (d.c / H_of_z<MODEL, FDE>(d, wc, half_z * d.gl_x[k] + half_z)));
     }
-    const double i_rs = group_sum(s_rs), i_dm = group_sum(s_dm);
+    const double i_rs = s_rs.total(gl_iters), i_dm = s_dm.total(gl_iters);
     const double rs_star = half_a * i_rs;
     const double DM_star = half_z * i_dm;
     const double Om_h2 = Oc + Ob + d.omnu_h2;
@@ -987,7 +1033,7 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
   if (d.n_cc > 0) {  // delta @ inv_cov @ delta * f_cc^2
     for (int k = sl; k < d.n_cc; k += CF_SB_LANES) dl[k] = d.cc_h[k] - H_of_z<MODEL, FDE>(d, wc, d.cc_z[k]);
     __syncthreads();
-    c_cc = group_quadratic_form(dl, d.cc_inv_cov, d.n_cc, sl);
+    c_cc = group_quadratic_form<LANES>(dl, d.cc_inv_cov, d.n_cc, sl);
     const double f = slot_get(d, CF_P_FCC_D, th);
     c_cc = d.cc_f_inverse ? c_cc * pow(f, -2.0) : c_cc * (f * f);  // ohd/cc_pantheon.py:64 / bao/desi_union3_cc_theta_star.py:130
     __syncthreads();  // dl is reused by the BAO block
@@ -1018,7 +1064,7 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
       if (bao_out && live) bao_out[w * d.n_bao + k] = t;
     }
     __syncthreads();
-    c_bao = group_quadratic_form(dl, d.bao_inv_cov, d.n_bao, sl);
+    c_bao = group_quadratic_form<LANES>(dl, d.bao_inv_cov, d.n_bao, sl);
   }
   if (sl == 0 && live) {
     chi2_extra[w] = c_cmb + c_bao + c_cc;
@@ -1318,8 +1364,10 @@ __global__ void hz_kernel(cf_dev_desc d, const double* __restrict__ theta, const
 #define CF_INSTANTIATE_WALKER(M, F)                                                                              \
   template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*, d2*); \
   template __global__ void walker_fast_kernel<M, F>(cf_walker_args, const double*, int64_t, double*, d2*, double*, int, int);     \
-  template __global__ void small_blocks_kernel<M, F>(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, \
-                                                     double*);                                                      \
+  template __global__ void small_blocks_kernel<M, F, 16>(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, \
+                                                         double*);                                                      \
+  template __global__ void small_blocks_kernel<M, F, 64>(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, \
+                                                         double*);                                                      \
   template __global__ void hz_kernel<M, F>(cf_dev_desc, const double*, const double*, int64_t, double*);                     \
   CF_INSTANTIATE_GROWTH(M, F, 1) CF_INSTANTIATE_GROWTH(M, F, 2) CF_INSTANTIATE_GROWTH(M, F, 4) CF_INSTANTIATE_GROWTH(M, F, 8)
 CF_INSTANTIATE_WALKER(0, 0) CF_INSTANTIATE_WALKER(0, 1) CF_INSTANTIATE_WALKER(0, 2) CF_INSTANTIATE_WALKER(0, 3)
