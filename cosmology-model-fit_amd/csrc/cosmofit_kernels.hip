@@ -52,6 +52,19 @@ __device__ __forceinline__ double slot_get(const D& d, int s, const ThetaRow& th
   return p.idx >= 0 ? p.scale * v : p.fixed;
 }
 
+// The same for a GROUP of LANES lanes per walker (small_blocks_kernel: several walkers per wave, so the slot's lane differs from
+// group to group -- a shuffle inside the group instead of v_readlane): lane sl of the group holds theta[sl].
+template <int LANES>
+struct ThetaGroup {
+  double v;
+};
+template <class D, int LANES>
+__device__ __forceinline__ double slot_get(const D& d, int s, const ThetaGroup<LANES>& th) {
+  const cf_dev_slot& p = d.slot[s];
+  const double v = __shfl(th.v, p.idx >= 0 ? p.idx : 0, LANES);
+  return p.idx >= 0 ? p.scale * v : p.fixed;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Expansion rate.  dh(z) = c / H(z).   Reference: sn/pantheon.py:28-31, bao/desi.py:26-35,
 // sn/pantheon_and_sh0es.py:26-28, bao/desi_fs_lya_cmb.py:19-22.  (1+z)^3 by multiplies (numba).
@@ -958,8 +971,10 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
   const int64_t w_raw = (int64_t)blockIdx.x * (256 / CF_SB_LANES) + grp;
   const bool live = w_raw < W;
   const int64_t w = live ? w_raw : W - 1;  // spare groups of the last workgroup shadow the last walker and write nothing
-  const double* th = theta + w * d.ndim;
   CF_BSTAMP(0);
+  // the walker's theta row across the lanes of its group: ONE load that waits for nothing (read slot by slot through the pointer,
+  // each slot was a load behind the scalar load of its index)
+  const ThetaGroup<LANES> th{theta[w * d.ndim + (sl < d.ndim ? sl : 0)]};
   const WalkerCosmo wc = make_cosmo(d, th);
   const double Ob = slot_get(d, CF_P_OBH2_D, th), Oc = slot_get(d, CF_P_OCH2_D, th);
   double* dl = delta_s[grp];
