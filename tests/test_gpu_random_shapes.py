@@ -107,4 +107,8 @@ def test_random_shape(gpu, seed):
     np.testing.assert_allclose(got_c, want_c, rtol=RTOL, err_msg=f"seed {seed}: {names}, N={n_sn}, G={n_grid}, B={n_bao}, physical={physical}, fde={fde}")
     np.testing.assert_allclose(got_p[fin], want_p[fin], rtol=RTOL)
     assert np.all(got_p[~fin] == -np.inf)
+    # the same walkers inside a batch large enough for the throughput kernels (solve: 32-walker panels, residuals in walker rows;
+    # per-walker kernel: one workgroup per walker; small blocks: sixteen lanes per walker): a walker's result must be the same BITS
+    big = np.concatenate([theta, gpu.synthetic.walkers(bounds, 2200 - W, seed=seed + 1000)])
+    np.testing.assert_array_equal(eng.chi_squared(big)[:W], got_c)
     eng.close()
