@@ -39,7 +39,7 @@ __global__ void walker_kernel(cf_dev_desc d, const double* theta, int64_t W, dou
 template <int MODEL, int FDE>
 __global__ void walker_fast_kernel(cf_walker_args d, const double* theta, int64_t W, double* delta, d2* bao_nodes, double* theta_copy,
                                    int frag_b, int sn_parts);
-template <int MODEL, int FDE, int LANES>
+template <int MODEL, int FDE, int LANES, int ROLES>
 __global__ void small_blocks_kernel(cf_dev_desc d, const double* theta, int64_t W, const d2* bao_nodes, double* chi2_extra,
                                     double* blocks_out, double* bao_out);
 template <int MODEL, int FDE, int C>
@@ -52,10 +52,12 @@ __global__ void hz_kernel(cf_dev_desc d, const double* theta, const double* z, i
 #define CF_DECLARE_WALKER(M, F)                                                                                            \
   extern template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*, d2*); \
   extern template __global__ void walker_fast_kernel<M, F>(cf_walker_args, const double*, int64_t, double*, d2*, double*, int, int); \
-  extern template __global__ void small_blocks_kernel<M, F, 16>(cf_dev_desc, const double*, int64_t, const d2*, double*,   \
-                                                                double*, double*);                                        \
-  extern template __global__ void small_blocks_kernel<M, F, 64>(cf_dev_desc, const double*, int64_t, const d2*, double*,   \
-                                                                double*, double*);                                        \
+  extern template __global__ void small_blocks_kernel<M, F, 16, 1>(cf_dev_desc, const double*, int64_t, const d2*, double*, \
+                                                                   double*, double*);                                      \
+  extern template __global__ void small_blocks_kernel<M, F, 64, 1>(cf_dev_desc, const double*, int64_t, const d2*, double*, \
+                                                                   double*, double*);                                      \
+  extern template __global__ void small_blocks_kernel<M, F, 64, 2>(cf_dev_desc, const double*, int64_t, const d2*, double*, \
+                                                                   double*, double*);                                      \
   extern template __global__ void hz_kernel<M, F>(cf_dev_desc, const double*, const double*, int64_t, double*);             \
   CF_DECLARE_GROWTH(M, F, 1) CF_DECLARE_GROWTH(M, F, 2) CF_DECLARE_GROWTH(M, F, 4) CF_DECLARE_GROWTH(M, F, 8)
 CF_DECLARE_WALKER(0, 0) CF_DECLARE_WALKER(0, 1) CF_DECLARE_WALKER(0, 2) CF_DECLARE_WALKER(0, 3)
@@ -95,14 +97,16 @@ static cf_walker_args walker_args_of(const cf_dev_desc& d) {
   return a;
 }
 typedef void (*small_blocks_fn)(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, double*);
-static small_blocks_fn pick_small_blocks(int model, int fde, int lanes) {  // lanes per walker: 16 or 64
-  static const small_blocks_fn narrow[2][4] = {
-      {small_blocks_kernel<0, 0, 16>, small_blocks_kernel<0, 1, 16>, small_blocks_kernel<0, 2, 16>, small_blocks_kernel<0, 3, 16>},
-      {small_blocks_kernel<1, 0, 16>, small_blocks_kernel<1, 1, 16>, small_blocks_kernel<1, 2, 16>, small_blocks_kernel<1, 3, 16>}};
-  static const small_blocks_fn wide[2][4] = {
-      {small_blocks_kernel<0, 0, 64>, small_blocks_kernel<0, 1, 64>, small_blocks_kernel<0, 2, 64>, small_blocks_kernel<0, 3, 64>},
-      {small_blocks_kernel<1, 0, 64>, small_blocks_kernel<1, 1, 64>, small_blocks_kernel<1, 2, 64>, small_blocks_kernel<1, 3, 64>}};
-  return lanes == 64 ? wide[model][fde] : narrow[model][fde];
+// lanes per walker: 16 or 64; roles (waves per walker, 64 lanes only): 1 or 2
+static small_blocks_fn pick_small_blocks(int model, int fde, int lanes, int roles = 1) {
+#define CF_SB_TABLE(L, R)                                                                                                                \
+  {{small_blocks_kernel<0, 0, L, R>, small_blocks_kernel<0, 1, L, R>, small_blocks_kernel<0, 2, L, R>, small_blocks_kernel<0, 3, L, R>}, \
+   {small_blocks_kernel<1, 0, L, R>, small_blocks_kernel<1, 1, L, R>, small_blocks_kernel<1, 2, L, R>, small_blocks_kernel<1, 3, L, R>}}
+  static const small_blocks_fn narrow[2][4] = CF_SB_TABLE(16, 1);
+  static const small_blocks_fn wide[2][4] = CF_SB_TABLE(64, 1);
+  static const small_blocks_fn wide2[2][4] = CF_SB_TABLE(64, 2);
+#undef CF_SB_TABLE
+  return lanes == 64 ? (roles == 2 ? wide2[model][fde] : wide[model][fde]) : narrow[model][fde];
 }
 typedef void (*hz_fn)(cf_dev_desc, const double*, const double*, int64_t, double*);
 static hz_fn pick_hz(int model, int fde) {
@@ -1350,8 +1354,11 @@ static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_
       // 185, 4096: 329 -> 334 (profiles/r03_small_blocks_lanes_ab.txt).  The sums do not depend on the width (VirtualLaneSum): a
       // walker's result is the same bits either way.  CF_SB_WIDE_MAX=<walkers> moves the switch.
       static const int64_t wide_max = [] { const char* e = getenv("CF_SB_WIDE_MAX"); return e ? atoll(e) : 2048ll; }();
-      const int lanes = Wc <= wide_max ? 64 : 16, per_wg = 256 / lanes;
-      hipLaunchKernelGGL(pick_small_blocks(d.ez_model, d.fde, lanes), dim3((unsigned)((Wc + per_wg - 1) / per_wg)), dim3(256), 0, st, d, th, Wc,
+      // ... and TWO waves per walker: the BAO / cosmic-chronometer blocks beside the powers and the CMB integrals (small_blocks_kernel,
+      // ROLES): 16 walkers 44.6 -> 37.9 us per call, 256: 67 -> 60, 2048: 184 -> 182.  CF_SB_ROLES_MAX=<walkers> (0 = never) moves the switch.
+      static const int64_t roles_max = [] { const char* e = getenv("CF_SB_ROLES_MAX"); return e ? atoll(e) : 2048ll; }();
+      const int lanes = Wc <= wide_max ? 64 : 16, roles = (lanes == 64 && Wc <= roles_max) ? 2 : 1, per_wg = 256 / (lanes * roles);
+      hipLaunchKernelGGL(pick_small_blocks(d.ez_model, d.fde, lanes, roles), dim3((unsigned)((Wc + per_wg - 1) / per_wg)), dim3(256), 0, st, d, th, Wc,
                          (const d2*)bao_nodes, extra, blocks_out, bao_out);
     }
     if (h->has_growth)  // 256 lanes per walker: the growth ODE as a scan of 2 x 2 step matrices, the f sigma_8 quadratic form

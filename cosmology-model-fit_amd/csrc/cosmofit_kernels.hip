@@ -960,15 +960,26 @@ extern "C" int cf_debug_sb_stamps(unsigned long long* out) { return (int)hipMemc
 #else
 #define CF_BSTAMP(k)
 #endif
-template <int MODEL, int FDE, int LANES>
+// ROLES = 2 (only with a wave per walker, LANES = 64: batches that leave the chip mostly idle): TWO waves per walker.  Wave A runs the
+// z* / r_drag powers, then the compressed-CMB integrals; wave B the cosmic chronometers and the BAO numerators (table look-ups, the
+// cube root), which need nothing from A but the final division by r_d.  Two workgroup barriers: after the first B reads r_d from LDS
+// and finishes the BAO block while A integrates, after the second A adds B's two chi^2 and writes the walker's results.  Every
+// operation and every order of operations is that of the one-role form: the same bits (tests/test_gpu_joint.py, test_gpu_random_shapes.py).
+template <int MODEL, int FDE, int LANES, int ROLES>
 __global__ void __launch_bounds__(256)
 small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, const d2* __restrict__ bao_nodes,
                     double* __restrict__ chi2_extra, double* __restrict__ blocks_out, double* __restrict__ bao_out) {
   static_assert(LANES == 16 || LANES == 32 || LANES == 64, "lanes per walker");
+  static_assert(ROLES == 1 || (ROLES == 2 && LANES == 64 && CF_MAX_BAO <= 64), "two roles: a wave each, one BAO datum per lane");
   constexpr int CF_SB_LANES = LANES;
-  __shared__ double delta_s[256 / CF_SB_LANES][CF_MAX_BAO > CF_MAX_CC ? CF_MAX_BAO : CF_MAX_CC];
-  const int grp = threadIdx.x / CF_SB_LANES, sl = threadIdx.x % CF_SB_LANES;
-  const int64_t w_raw = (int64_t)blockIdx.x * (256 / CF_SB_LANES) + grp;
+  constexpr bool SPLIT = ROLES == 2;
+  constexpr int WALKERS_PER_WG = 256 / (LANES * ROLES);
+  __shared__ double delta_s[WALKERS_PER_WG][CF_MAX_BAO > CF_MAX_CC ? CF_MAX_BAO : CF_MAX_CC];
+  __shared__ double xch[WALKERS_PER_WG][4];  // SPLIT: {r_d from wave A; chi2_bao, chi2_cc from wave B}
+  const int grp = threadIdx.x / (LANES * ROLES), sl = threadIdx.x % LANES;
+  const bool do_a = !SPLIT || ((threadIdx.x / LANES) & 1) == 0;  // powers, CMB, output
+  const bool do_b = !SPLIT || ((threadIdx.x / LANES) & 1) == 1;  // cosmic chronometers, BAO
+  const int64_t w_raw = (int64_t)blockIdx.x * WALKERS_PER_WG + grp;
   const bool live = w_raw < W;
   const int64_t w = live ? w_raw : W - 1;  // spare groups of the last workgroup shadow the last walker and write nothing
   CF_BSTAMP(0);
@@ -980,8 +991,14 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
   double* dl = delta_s[grp];
   if (Ob == 1.2345e300) dl[0] = wc.H0;  // (stamps: keeps the loads in front of the stamp)
   CF_BSTAMP(1);
+  // dl is written and read by the lanes of one group: a workgroup barrier when a wave holds several groups' neighbours, the wave's
+  // own LDS order when the group IS the wave (SPLIT: the other role's waves are not at this point of the program)
+  auto group_sync = [&]() {
+    if (SPLIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else __syncthreads();
+  };
   double z_star = 0.0, r_d = 0.0;
-  if (d.cmb_mode || d.rd_from_fit) {
+  auto pow_block = [&]() {
     const double h_late = wc.H0 / 100;
     const double wm_z = Oc + Ob + d.omnu_h2, wm_r = d.rd_wm_late ? wc.Om * (h_late * h_late) : Ob + Oc + d.omnu_h2;
     const double* fz = d.zstar_fit;  // s1 s2 b m e0 c1 e1 e2 c2 e3 e4
@@ -1018,11 +1035,10 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
     const double den = (fr[2] * q[5]) + (fr[4] * q[6] * q[7]) + (fr[7] * q[8]);
     r_d = 1.0 / den - fr[9] / q[9];
     CF_BSTAMP(3);
-  }
-  if (!d.rd_from_fit) r_d = slot_get(d, CF_P_RD_D, th);
+  };
 
   double c_cmb = 0.0, vec[3] = {0.0, 0.0, 0.0};
-  if (d.cmb_mode) {
+  auto cmb_block = [&]() {
     VirtualLaneSum<LANES> s_rs, s_dm;
     const double half_a = (1.0 / (1.0 + z_star)) / 2.0, half_z = z_star / 2.0;
     const int gl_iters = (d.n_gl + LANES - 1) / LANES;  // the same for every lane (VirtualLaneSum); a lane past the last node adds 0
@@ -1056,49 +1072,96 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
         c_cmb += t * dv[j];
       }
     }
-  }
+  };
 
-  CF_BSTAMP(5);
   double c_cc = 0.0;
-  if (d.n_cc > 0) {  // delta @ inv_cov @ delta * f_cc^2
+  auto cc_block = [&]() {  // delta @ inv_cov @ delta * f_cc^2
     for (int k = sl; k < d.n_cc; k += CF_SB_LANES) dl[k] = d.cc_h[k] - H_of_z<MODEL, FDE>(d, wc, d.cc_z[k]);
-    __syncthreads();
+    group_sync();
     c_cc = group_quadratic_form<LANES>(dl, d.cc_inv_cov, d.n_cc, sl);
     const double f = slot_get(d, CF_P_FCC_D, th);
     c_cc = d.cc_f_inverse ? c_cc * pow(f, -2.0) : c_cc * (f * f);  // ohd/cc_pantheon.py:64 / bao/desi_union3_cc_theta_star.py:130
-    __syncthreads();  // dl is reused by the BAO block
-  }
+    group_sync();  // dl is reused by the BAO block
+  };
+
+  // BAO datum k in two parts: the look-ups that need only the walker's table, then the division by r_d and the residual
+  auto bao_num = [&](int k, double& z, double& DM, double& DH) {
+    NodeView T;
+    T.p = bao_nodes + (w * d.n_aux + k) * CF_BAO_NODES;
+    T.base = d.bao_base[k];
+    T.G = d.n_grid;
+    T.step = d.step;
+    T.inv_step = d.inv_step;
+    T.inv_last = d.inv_last;
+    T.z_max = d.z_max;
+    z = d.bao_z[k];
+    DM = hermite_tab(T, z);
+    DH = d.bao_dh_exact ? d.c / H_of_z<MODEL, FDE>(d, wc, z) : pchip_dh_tab(T, z);
+  };
+  auto bao_fin = [&](int k, double z, double DM, double DH) {
+    double t;
+    switch (d.bao_qty[k]) {
+      case 2: t = DH / r_d; break;
+      case 1: t = DM / r_d; break;
+      case 0: t = pow(z * DH * (DM * DM), 1.0 / 3) / r_d; break;
+      default: t = DM / DH; break;
+    }
+    dl[k] = d.bao_val[k] - t;
+    if (bao_out && live) bao_out[w * d.n_bao + k] = t;
+  };
 
   double c_bao = 0.0;
-  if (d.n_bao > 0) {
-    for (int k = sl; k < d.n_bao; k += CF_SB_LANES) {
-      NodeView T;
-      T.p = bao_nodes + (w * d.n_aux + k) * CF_BAO_NODES;
-      T.base = d.bao_base[k];
-      T.G = d.n_grid;
-      T.step = d.step;
-      T.inv_step = d.inv_step;
-      T.inv_last = d.inv_last;
-      T.z_max = d.z_max;
-      const double z = d.bao_z[k];
-      const double DM = hermite_tab(T, z);
-      const double DH = d.bao_dh_exact ? d.c / H_of_z<MODEL, FDE>(d, wc, z) : pchip_dh_tab(T, z);
-      double t;
-      switch (d.bao_qty[k]) {
-        case 2: t = DH / r_d; break;
-        case 1: t = DM / r_d; break;
-        case 0: t = pow(z * DH * (DM * DM), 1.0 / 3) / r_d; break;
-        default: t = DM / DH; break;
+  if (!SPLIT) {
+    if (d.cmb_mode || d.rd_from_fit) pow_block();
+    if (!d.rd_from_fit) r_d = slot_get(d, CF_P_RD_D, th);
+    if (d.cmb_mode) cmb_block();
+    CF_BSTAMP(5);
+    if (d.n_cc > 0) cc_block();
+    if (d.n_bao > 0) {
+      for (int k = sl; k < d.n_bao; k += CF_SB_LANES) {
+        double z, DM, DH;
+        bao_num(k, z, DM, DH);
+        bao_fin(k, z, DM, DH);
       }
-      dl[k] = d.bao_val[k] - t;
-      if (bao_out && live) bao_out[w * d.n_bao + k] = t;
+      CF_BSTAMP(6);
+      group_sync();
+      c_bao = group_quadratic_form<LANES>(dl, d.bao_inv_cov, d.n_bao, sl);
     }
-    CF_BSTAMP(6);
-    __syncthreads();
-    c_bao = group_quadratic_form<LANES>(dl, d.bao_inv_cov, d.n_bao, sl);
+    CF_BSTAMP(7);
+  } else {
+    double bz = 0.0, bDM = 0.0, bDH = 0.0;
+    const bool has_datum = sl < d.n_bao;  // CF_MAX_BAO <= LANES: one datum per lane
+    if (do_a && (d.cmb_mode || d.rd_from_fit)) pow_block();
+    if (!d.rd_from_fit) r_d = slot_get(d, CF_P_RD_D, th);
+    if (do_b) {
+      if (d.n_cc > 0) cc_block();
+      if (has_datum) bao_num(sl, bz, bDM, bDH);
+    }
+    if (do_a && sl == 0) xch[grp][0] = r_d;
+    __syncthreads();  // r_d is in LDS; B's numerators are in its registers
+    if (do_a) {
+      if (d.cmb_mode) cmb_block();
+      CF_BSTAMP(5);
+    } else {
+      r_d = xch[grp][0];
+      if (d.n_bao > 0) {
+        if (has_datum) bao_fin(sl, bz, bDM, bDH);
+        group_sync();
+        c_bao = group_quadratic_form<LANES>(dl, d.bao_inv_cov, d.n_bao, sl);
+      }
+      if (sl == 0) {
+        xch[grp][1] = c_bao;
+        xch[grp][2] = c_cc;
+      }
+    }
+    __syncthreads();  // B's chi^2 are in LDS
+    if (do_a) {
+      c_bao = xch[grp][1];
+      c_cc = xch[grp][2];
+    }
+    CF_BSTAMP(7);
   }
-  CF_BSTAMP(7);
-  if (sl == 0 && live) {
+  if (sl == 0 && live && do_a) {
     chi2_extra[w] = c_cmb + c_bao + c_cc;
     if (blocks_out) {
       blocks_out[8 * w + 0] = c_bao; blocks_out[8 * w + 1] = c_cmb; blocks_out[8 * w + 5] = c_cc;
@@ -1396,10 +1459,12 @@ __global__ void hz_kernel(cf_dev_desc d, const double* __restrict__ theta, const
 #define CF_INSTANTIATE_WALKER(M, F)                                                                              \
   template __global__ void walker_kernel<M, F>(cf_dev_desc, const double*, int64_t, double*, double*, double*, d2*, d2*); \
   template __global__ void walker_fast_kernel<M, F>(cf_walker_args, const double*, int64_t, double*, d2*, double*, int, int);     \
-  template __global__ void small_blocks_kernel<M, F, 16>(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, \
-                                                         double*);                                                      \
-  template __global__ void small_blocks_kernel<M, F, 64>(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, \
-                                                         double*);                                                      \
+  template __global__ void small_blocks_kernel<M, F, 16, 1>(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, \
+                                                            double*);                                                      \
+  template __global__ void small_blocks_kernel<M, F, 64, 1>(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, \
+                                                            double*);                                                      \
+  template __global__ void small_blocks_kernel<M, F, 64, 2>(cf_dev_desc, const double*, int64_t, const d2*, double*, double*, \
+                                                            double*);                                                      \
   template __global__ void hz_kernel<M, F>(cf_dev_desc, const double*, const double*, int64_t, double*);                     \
   CF_INSTANTIATE_GROWTH(M, F, 1) CF_INSTANTIATE_GROWTH(M, F, 2) CF_INSTANTIATE_GROWTH(M, F, 4) CF_INSTANTIATE_GROWTH(M, F, 8)
 CF_INSTANTIATE_WALKER(0, 0) CF_INSTANTIATE_WALKER(0, 1) CF_INSTANTIATE_WALKER(0, 2) CF_INSTANTIATE_WALKER(0, 3)
