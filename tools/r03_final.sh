@@ -18,6 +18,7 @@ python3 bench.py --workload desi_cmb_des5y --fde cpl > $O/bench_config3_cpl.json
 python3 bench.py --workload desi_des5y_bbn_theta_star > $O/bench_config5.json 2>/dev/null && show $O/bench_config5.json
 timeout -k 10 300 python tools/fs8_parity_probe.py 2>&1 | grep -v amdgpu.ids | tee $O/fs8_parity.txt
 WS=1,16,32,64,75,128,150,256,512,2048 REPS=300 timeout -k 10 300 python tools/small_batch_timeline.py 2>&1 | grep -v amdgpu.ids | tee $O/small_batch_wall.txt
+WORKLOAD=desi_cmb_des5y:cpl WS=1,16,64,100,256,2048 REPS=300 timeout -k 10 300 python tools/small_batch_timeline.py 2>&1 | grep -v amdgpu.ids | tee $O/small_batch_wall_joint_cpl.txt
 cd /tmp && export TMPDIR=/tmp
 WS=16 REPS=300 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/trace -- python3 $GRAFT_REPO_ROOT/tools/small_batch_timeline.py > $GRAFT_REPO_ROOT/$O/trace.log 2>&1
 f=$(find $GRAFT_REPO_ROOT/$O/trace -name '*kernel_trace.csv' | head -1); python3 $GRAFT_REPO_ROOT/tools/timeline_gaps.py $f 600 | tee $GRAFT_REPO_ROOT/$O/timeline_w16.txt
