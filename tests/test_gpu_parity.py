@@ -175,6 +175,20 @@ def test_config2_batch_invariance(config2):
     assert lk.chi_squared(theta[:0]).shape == (0,)
 
 
+def test_config2_random_small_batches_soak(config2):
+    """Thousands of synchronous calls of random batch sizes at random offsets (mostly the small-batch path: fragment-ordered
+    residuals, one / two tiles per solve workgroup, several workgroups per walker, completion words), every result the same BITS as
+    in the 4096-walker batch: an intermittent hand-off or completion race would show here (tools/soak_small_batches.py runs 10^5s)."""
+    lk, _, theta = config2
+    full = np.array(lk.log_probs_vectorized(theta), copy=True)
+    rng = np.random.default_rng(11)
+    sizes = np.concatenate([rng.integers(1, 200, 2700), rng.integers(200, 3000, 300)])
+    rng.shuffle(sizes)
+    for W in sizes:
+        o = int(rng.integers(0, len(theta) - W + 1))
+        np.testing.assert_array_equal(lk.log_probs_vectorized(theta[o:o + W]), full[o:o + W], err_msg=f"W={W} offset={o}")
+
+
 @pytest.mark.parametrize("W", [8192, 65536])
 def test_configs3_shape_per_rank_and_whole_ensemble(config2, W):
     """BASELINE configs[3]: 65536 walkers over 8 GPUs = 8192 per rank.  Both shapes on ONE GPU (the per-rank batch, and the
