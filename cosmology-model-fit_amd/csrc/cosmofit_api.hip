@@ -138,7 +138,7 @@ template <int NP, int PF>
 __global__ void tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* theta, int64_t W, const double* delta,
                                      int64_t w_pad, double* partial, unsigned int* arrivals, const double* chi2_extra,
                                      double* out, int out_kind, unsigned long long* nonfinite, double* chi2_sn_out,
-                                     int panels_per_group, unsigned long long* done_flag, unsigned long long done_seq);
+                                     int panels_per_group, unsigned long long* done_flag, unsigned long long done_seq, int snake);
 template <int PF, bool FRAG, int TPW>
 __global__ void tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* theta, int64_t W, const double* delta,
                                       double* partial4, unsigned int* arrivals, const double* chi2_extra, double* out, int out_kind,
@@ -164,7 +164,7 @@ CF_DECLARE_TRIGEMM_SMALL(4, true, 4)
   extern template __global__ void tri_gemm_chi2_kernel<NP, PF>(cf_dev_desc, cf_dev_invpack, const double*, int64_t,     \
                                                                const double*, int64_t, double*, unsigned int*,          \
                                                                const double*, double*, int, unsigned long long*, double*, int,  \
-                                                               unsigned long long*, unsigned long long);
+                                                               unsigned long long*, unsigned long long, int);
 CF_DECLARE_TRIGEMM(1, 2)
 CF_DECLARE_TRIGEMM(1, 4)
 CF_DECLARE_TRIGEMM(2, 2)
@@ -1221,9 +1221,14 @@ static int launch_tri_gemm_t(const TriGemmArgs& a, hipStream_t st) {
     ppg = ((panels + n_groups - 1) / n_groups + 7) / 8 * 8;
   }
   const int n_groups = (panels + ppg - 1) / ppg;
-  hipLaunchKernelGGL((tri_gemm_chi2_kernel<NP, PF>), dim3((unsigned)(n_groups * ppg * a.pk->n_rowblocks)), dim3(256), 0, st, *a.d,
+  const int n_wgs = n_groups * ppg * a.pk->n_rowblocks;
+  // order of the row blocks inside the grid: descending; for a grid that is resident all at once, alternate blocks of 256 workgroups
+  // ascending (see the kernel).  CF_GEMM_ORDER=0|1 forces one (tuning).
+  static const int order_env = [] { const char* e = getenv("CF_GEMM_ORDER"); return e ? atoi(e) : -1; }();
+  const int snake = order_env >= 0 ? order_env : (n_wgs <= 1024 ? 1 : 0);
+  hipLaunchKernelGGL((tri_gemm_chi2_kernel<NP, PF>), dim3((unsigned)n_wgs), dim3(256), 0, st, *a.d,
                      *a.pk, a.theta, a.W, a.delta, a.w_pad, a.partial, a.arrivals, a.chi2_extra, a.out, a.out_kind, a.nonfinite,
-                     a.chi2_sn_out, ppg, a.done_flag, a.done_seq);
+                     a.chi2_sn_out, ppg, a.done_flag, a.done_seq, snake);
   return 0;
 }
 

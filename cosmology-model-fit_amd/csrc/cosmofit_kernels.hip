@@ -1824,7 +1824,7 @@ tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict_
                      const double* __restrict__ delta, int64_t w_pad, double* partial, unsigned int* arrivals,
                      const double* __restrict__ chi2_extra, double* __restrict__ out, int out_kind,
                      unsigned long long* nonfinite, double* __restrict__ chi2_sn_out, int panels_per_group,
-                     unsigned long long* done_flag, unsigned long long done_seq) {
+                     unsigned long long* done_flag, unsigned long long done_seq, int snake) {
   __shared__ __align__(16) d4 part[4][4][64];  // [wave][tile][lane] of one 16-walker panel: 32 KB
   __shared__ double chi_tile[4][16 * NP];
   __shared__ unsigned int arrived_before;
@@ -1835,7 +1835,16 @@ tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict_
   // blocks pass) > row block, largest first > panel inside the group (consecutive ids = different XCDs, all on the
   // same factor stream)
   const int per_group = panels_per_group * pk.n_rowblocks;
-  const int grp = (int)blockIdx.x / per_group, rem_id = (int)blockIdx.x % per_group;
+  const int grp = (int)blockIdx.x / per_group;
+  int rem_id = (int)blockIdx.x % per_group;
+  // `snake`: a grid that is resident all at once (<= 1024 workgroups) is placed statically, workgroups i, i + 256, i + 512, ... on the
+  // same CU: in plain descending order some CUs then hold 60 row-block units and others 36 (512 walkers).  Alternate blocks of 256
+  // workgroups run ascending instead: 256 walkers 46.4 -> 43.0 us per call, 512: 58.9 -> 55.5, 1024: 94.5 -> 87.3; a grid that
+  // arrives in waves (4096 walkers) is better off descending (254 against 257.5 us).  profiles/r03_gemm_stamps_and_pairing.txt
+  if (snake) {
+    const int b = rem_id >> 8, len = (per_group - (b << 8)) < 256 ? per_group - (b << 8) : 256;
+    if (b & 1) rem_id = (b << 8) + (len - 1 - (rem_id & 255));
+  }
   // largest row blocks first (alternating large / small, or mixing the first 1024-workgroup wave, measured no better: 0.744 /
   // 0.776 of peak against 0.778; profiles/r02_dispatch_order_ab.txt)
   const int rb = pk.n_rowblocks - 1 - rem_id / panels_per_group;
@@ -2053,7 +2062,7 @@ tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict_
 #define CF_INSTANTIATE_TRIGEMM(NP, PF)                                                                                   \
   template __global__ void tri_gemm_chi2_kernel<NP, PF>(cf_dev_desc, cf_dev_invpack, const double*, int64_t, const double*, \
                                                         int64_t, double*, unsigned int*, const double*, double*, int,   \
-                                                        unsigned long long*, double*, int, unsigned long long*, unsigned long long);
+                                                        unsigned long long*, double*, int, unsigned long long*, unsigned long long, int);
 CF_INSTANTIATE_TRIGEMM(1, 2)
 CF_INSTANTIATE_TRIGEMM(1, 4)
 CF_INSTANTIATE_TRIGEMM(2, 2)
