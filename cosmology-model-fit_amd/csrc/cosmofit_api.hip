@@ -315,6 +315,9 @@ struct PinnedBuf {
 #define CF_SMALL_DEFAULT 160  // walkers: batches up to this size take the small-batch solve kernel (150 walkers: 39 against 44 us per call,
                              // 200: 45-47 against 48, 256: slower; profiles/r03_small_batch_solve.txt)
 #endif
+#ifndef CF_NP2_FROM
+#define CF_NP2_FROM 512  // walkers: 32-walker panels in the throughput solve kernel beyond this batch size, 16-walker panels up to it
+#endif
 #define CF_MAX_CHUNKS 8  // sub-batches of one evaluation (walker kernel of chunk c + 1 beside the solve of chunk c)
 
 // A host thread that evaluates one replica's slice of a multi-device cf_eval (one per replica beyond the first).
@@ -1290,7 +1293,7 @@ static int launch_tri_gemm(const TriGemmArgs& a, hipStream_t st) {
     const char* e = getenv("CF_GEMM_SHAPE");
     return (e && strlen(e) == 3 && e[1] == 'x') ? (e[0] - '0') * 16 + (e[2] - '0') : 0;
   }();
-  int np = a.W > 768 ? 2 : 1, pf = 2;  // measured: NP = 1 wins up to 512 walkers (48 vs 53 us), ties at 1024-2048, loses 10 % at 4096
+  int np = a.W > CF_NP2_FROM ? 2 : 1, pf = 2;  // measured: NP = 1 wins up to 512 walkers (48 vs 53 us), NP = 2 beyond (528-576 walkers 64 vs 67-69 us, 768: 71.7 vs 77.1; profiles/r03_gemm_stamps_and_pairing.txt), 10 % at 4096
   if (shape) { np = shape / 16; pf = shape % 16; }
   switch (np * 16 + pf) {
     case 1 * 16 + 2: return launch_tri_gemm_t<1, 2>(a, st);
@@ -1306,7 +1309,7 @@ static int launch_tri_gemm(const TriGemmArgs& a, hipStream_t st) {
 // walkers per panel of the throughput solve kernel launch_tri_gemm picks for W walkers (0: an override this file does not model)
 static int tri_gemm_panel_width(int64_t W) {
   static const bool overridden = getenv("CF_GEMM_SHAPE") != nullptr;
-  return overridden ? 0 : (W > 768 ? 32 : 16);
+  return overridden ? 0 : (W > CF_NP2_FROM ? 32 : 16);
 }
 
 // One sub-batch [off, off + Wc) of an evaluation on stream `st`: per-walker kernel (distance table, residuals; the

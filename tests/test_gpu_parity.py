@@ -170,7 +170,7 @@ def test_config2_batch_invariance(config2):
     np.testing.assert_array_equal(halves, full)
     # ragged panels; the small-batch path (<= 160 walkers: residuals in fragment order, 4 / 2 workgroups per walker up to 64 / 160,
     # one / two tiles per solve workgroup up to 96 / 160) and the throughput kernel
-    for W in (1, 2, 15, 16, 17, 31, 33, 48, 63, 64, 65, 96, 97, 100, 127, 128, 129, 160, 161, 256, 257):
+    for W in (1, 2, 15, 16, 17, 31, 33, 48, 63, 64, 65, 96, 97, 100, 127, 128, 129, 160, 161, 256, 257, 512, 513, 1000):  # 512 / 513: 16- / 32-walker panels
         np.testing.assert_array_equal(lk.chi_squared(theta[:W]), full[:W])
     assert lk.chi_squared(theta[:0]).shape == (0,)
 
