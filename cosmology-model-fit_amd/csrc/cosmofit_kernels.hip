@@ -10,13 +10,15 @@
 //
 //   tri_gemm_chi2_kernel / tri_gemm_small_kernel   (a11)   chi^2 = || X Delta ||^2 with X = L^-1 inverted once on the
 //        host: a triangular GEMM on FP64 matrix cores (v_mfma_f64_16x16x4_f64) with no dependency between 64-row
-//        blocks; one workgroup per (row block, panel of 16-32 walkers), or per (panel, row block, 16-row tile) for
-//        batches of <= 160 walkers (bit-identical); the workgroup that arrives last for a panel adds the shares in a
-//        fixed order and applies the prior / output epilogue.  trsm_chi2_kernel (blocked forward substitution) is the
-//        fallback when the explicit inverse fails its create-time probe.
+//        blocks; one workgroup per (row block, panel of 16-32 walkers), or per (panel, row block, one or two 16-row tiles)
+//        for batches of <= 160 walkers (bit-identical; the per-walker kernel then writes the residuals in this kernel's
+//        fragment order and runs several workgroups per walker); the workgroup that arrives last for a panel adds the
+//        shares in a fixed order and applies the prior / output epilogue.  trsm_chi2_kernel (blocked forward
+//        substitution) is the fallback when the explicit inverse fails its create-time probe.
 //
-// Joint likelihoods add small_blocks_kernel (BAO, compressed CMB, cosmic chronometers) and growth_kernel (f sigma_8)
-// between the two.  Written for wave64 / gfx950 only; no other target is supported.
+// Joint likelihoods add small_blocks_kernel (BAO, compressed CMB, cosmic chronometers: sixteen lanes per walker when the
+// batch fills the chip, one or two waves per walker below, the same bits either way) and growth_kernel (f sigma_8) between
+// the two.  A walker's result never depends on the batch it is evaluated in.  Written for wave64 / gfx950 only.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
