@@ -1246,14 +1246,23 @@ static int launch_tri_gemm_small_t(const TriGemmArgs& a, hipStream_t st) {
   // on some CUs while others hold one (75 walkers: 33.7-34.6 -> 31.8-32.2 us per call, 150 walkers with two tiles per workgroup:
   // 44 -> 39 us; profiles/r03_small_batch_solve.txt).  CF_SMALL_LDS_CAP=0 turns the padding off (tuning).
   static const bool cap2 = [] { const char* e = getenv("CF_SMALL_LDS_CAP"); return !e || atoi(e) != 0; }();
+  // the kernel's static LDS and the CU's LDS size as the runtime reports them; 0 = a query failed -> no padding (a guess could push
+  // static + dynamic LDS past the 64 KB a workgroup may have, which would only show as a launch failure)
   static const size_t static_lds = [] {
     hipFuncAttributes fa;
     return hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&tri_gemm_small_kernel<PF, FRAG, TPW>)) == hipSuccess ? fa.sharedSizeBytes
                                                                                                                           : (size_t)0;
   }();
+  static const size_t cu_lds = [] {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? (size_t)pr.maxSharedMemoryPerMultiProcessor
+                                                                                                 : (size_t)0;
+  }();
   size_t dyn_lds = 64 * a.pk->n_rowblocks <= 4096 ? (size_t)80 * a.pk->n_rowblocks * 8 : 0;
-  const size_t third_of_cu = 160 * 1024 / 3 + 1024;  // a third of a CU's LDS and a little: three workgroups no longer fit
-  if (cap2 && static_lds + dyn_lds < third_of_cu && third_of_cu - static_lds <= 64 * 1024) dyn_lds = third_of_cu - static_lds;
+  const size_t third_of_cu = cu_lds / 3 + 1024;  // a third of a CU's LDS and a little: three workgroups no longer fit
+  if (cap2 && static_lds > 0 && cu_lds > 0 && static_lds + dyn_lds < third_of_cu && third_of_cu <= 64 * 1024)
+    dyn_lds = third_of_cu - static_lds;
   hipLaunchKernelGGL((tri_gemm_small_kernel<PF, FRAG, TPW>), dim3((unsigned)(panels * units_pad)), dim3(256), dyn_lds, st, *a.d, *a.pk, a.theta, a.W,
                      a.delta, a.partial4, a.arrivals, a.chi2_extra, a.out, a.out_kind, a.nonfinite, a.chi2_sn_out, units_pad,
                      a.done_flag, a.done_seq);
@@ -1410,16 +1419,29 @@ static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_
   return 0;
 }
 
+// The ONE workspace of a handle is shared by all its evaluations: an evaluation on another stream than the previous one first
+// waits, on the HOST, for the previous one (a rare switch -- host calls run on the handle's own stream, a device-resident sampler
+// on its own -- so no event is recorded per evaluation: a record is a marker packet and ~2-4 us of every call).  The caller's
+// stream handle is only ever COMPARED here, never passed back to HIP: its owner may have destroyed it since, so the
+// wait for a foreign stream's evaluation is a device-wide synchronise; the library's own stream is waited for directly.
+// Consequence, documented in cosmofit.h: the first evaluation after a stream switch blocks the host and cannot be captured.
+static int order_behind_last(cf_handle* h, hipStream_t st) {
+  if (!h->has_last || h->last_stream == st) return 0;
+  if (h->last_stream == h->stream)
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  else
+    HIP_TRY(hipDeviceSynchronize());
+  h->has_last = false;  // drained: nothing of this handle is in flight
+  return 0;
+}
+
 // Launch one evaluation of W walkers, ordered on `st`.  Large batches of an SN likelihood run as sub-batches on two
 // streams (h->chunk_first / chunk_rest walkers; chunk c on `st` for even c, on h->aux for odd c), the per-walker kernel
 // of chunk c + 1 beside the solve of chunk c; everything is joined back into `st` before this returns.
 static int launch_path(cf_handle* h, const double* d_theta, int64_t W, double* d_out, int out_kind, hipStream_t st,
                        double* dm_out, double* mucorr_out, double* blocks_out, double* bao_out,
                        double* chi2_sn_out = nullptr, double* fs8_block_out = nullptr, double* fs8_theory_out = nullptr) {
-  // the workspace is shared: an evaluation on another stream than the previous one first waits for that stream (a rare
-  // switch -- host calls run on the handle's stream, a device-resident sampler on its own -- so the wait is a host-side
-  // synchronise at the switch instead of an event record on every evaluation: ~2 us of each small-batch call)
-  if (h->has_last && h->last_stream != st) HIP_TRY(hipStreamSynchronize(h->last_stream));
+  { int rc0 = order_behind_last(h, st); if (rc0) return rc0; }
   const bool parts = dm_out || mucorr_out || blocks_out || bao_out || chi2_sn_out;
   int64_t offs[CF_MAX_CHUNKS + 1];
   int n_chunks = 1;
@@ -1506,8 +1528,17 @@ static int wait_stream(hipStream_t st) {
   return 0;
 }
 
-// Spin on the words the small-batch kernel's last arrivers set (pinned host memory) for up to ~1 ms; false = not seen (the caller
+// Spin on the words the evaluation's last kernel sets (pinned host memory) for up to ~1 ms; false = not seen (the caller
 // then waits for the stream as usual).  CF_DONE_FLAG=0 disables the short cut (A/B).
+// THE EARLY-RETURN CONTRACT.  When every word has been seen, cf_eval returns while the tail of its last kernel (teardown, the
+// completion signal, the runtime's stream bookkeeping) is still draining on h->stream.  What has been ordered: every result of the
+// call is in `stage_out` (the storing wave drained its stores, then released the word at system scope) and has been copied to the
+// caller's `out`.  What the next call may touch meanwhile: only h->stream-ordered work (queued behind the tail) and the pinned
+// staging blocks -- stage_in is no longer read by the finished evaluation (theta is read from the walker kernel's device copy
+// after the first kernel) and stage_out / the words are written only before the release.  Ordering against evaluations on a
+// CALLER's stream does not rely on this path: order_behind_last() drains h->stream at the switch.  A GPU fault in the drained tail
+// is reported by the next HIP call of the handle (launch_path ends in hipGetLastError), i.e. by the following evaluation.
+// The spin holds h->mu (one caller per handle at a time is the documented threading model) and is bounded.
 static bool wait_done_flags(cf_handle* h) {
   static const bool on = [] { const char* e = getenv("CF_DONE_FLAG"); return !e || atoi(e) != 0; }();
   if (!on) return false;
@@ -1669,7 +1700,7 @@ extern "C" int cf_eval_table(cf_handle* h, const double* theta, int64_t W, doubl
   HIP_TRY(hipSetDevice(h->device));
   int rc;
   if ((rc = ensure_workspace(h, W))) return rc;
-  if (h->has_last && h->last_stream != h->stream) HIP_TRY(hipStreamSynchronize(h->last_stream));
+  if ((rc = order_behind_last(h, h->stream))) return rc;
   cf_dev_desc d = h->d;  // a copy without the SN / BAO consumers of the table: only the build runs
   const int G = d.n_grid;
   d.n_sn = 0;
@@ -1706,7 +1737,7 @@ extern "C" int cf_eval_fs8_at(cf_handle* h, const double* theta, const double* z
   HIP_TRY(hipSetDevice(h->device));
   int rc;
   if ((rc = ensure_workspace(h, 1))) return rc;
-  if (h->has_last && h->last_stream != h->stream) HIP_TRY(hipStreamSynchronize(h->last_stream));
+  if ((rc = order_behind_last(h, h->stream))) return rc;
   HIP_TRY(hipMemcpyAsync(h->theta.p, theta, (size_t)h->d.ndim * 8, hipMemcpyHostToDevice, h->stream));
   const int B = CF_MAX_FS8;
   DevBuf dz, dbase, dstep, dorder, dpts, dval, dinv, dfid, nodes, dout, extra;
@@ -1758,7 +1789,7 @@ extern "C" int cf_eval_hz(cf_handle* h, const double* theta, const double* z, in
   HIP_TRY(hipSetDevice(h->device));
   int rc;
   if ((rc = ensure_workspace(h, 1))) return rc;
-  if (h->has_last && h->last_stream != h->stream) HIP_TRY(hipStreamSynchronize(h->last_stream));
+  if ((rc = order_behind_last(h, h->stream))) return rc;
   DevBuf dz, dout;
   if (dz.ensure((size_t)n * 8) || dout.ensure((size_t)n * 8)) return CF_ERR_HIP;
   HIP_TRY(hipMemcpyAsync(h->theta.p, theta, (size_t)h->d.ndim * 8, hipMemcpyHostToDevice, h->stream));
@@ -1783,7 +1814,7 @@ extern "C" int cf_eval_bao_at(cf_handle* h, const double* theta, const double* z
   HIP_TRY(hipSetDevice(h->device));
   int rc;
   if ((rc = ensure_workspace(h, 1))) return rc;
-  if (h->has_last && h->last_stream != h->stream) HIP_TRY(hipStreamSynchronize(h->last_stream));
+  if ((rc = order_behind_last(h, h->stream))) return rc;
   HIP_TRY(hipMemcpyAsync(h->theta.p, theta, (size_t)h->d.ndim * 8, hipMemcpyHostToDevice, h->stream));
   DevBuf dz, dq, dbase, dval, dinv, nodes, dout, extra;
   const int B = CF_MAX_BAO;

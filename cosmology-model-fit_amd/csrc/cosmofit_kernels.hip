@@ -1778,8 +1778,8 @@ extern "C" int cf_debug_gemm_stamps(unsigned long long* out) {
 #define CF_GSTAMP(k)
 #endif
 
-// Workgroup barrier for LDS traffic only: __syncthreads() also drains vmcnt, i.e. waits for global loads that
-// have nothing to do with the exchange.
+// Workgroup barrier for LDS traffic only (no wait on global loads that have nothing to do with the exchange).  Neither this nor
+// s_barrier itself orders a wave's global STORES: a hand-off to another agent needs the storing wave's own s_waitcnt vmcnt(0).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // The last arriver's read-back of a panel's shares: `n` doubles at `src` (written by other workgroups with agent-scope
@@ -2363,7 +2363,11 @@ extern "C" __global__ void finalize_kernel(cf_dev_desc d, const double* __restri
   const int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (w < W) out[w] = finalize_value(d, theta + w * d.ndim, chi2_extra ? chi2_extra[w] : 0.0, out_kind, nonfinite);
   if (done_flag) {  // completion word of this block's 256 walkers for a synchronous zero-copy host call
-    __syncthreads();  // every wave's stores issued and acknowledged
+    // All four waves stored results into the pinned block.  s_barrier does NOT drain vmcnt: each storing wave waits for its own
+    // stores to be acknowledged BEFORE the barrier, so that the flag (released by wave 0 behind the barrier) cannot overtake the
+    // result stores of waves 1-3.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(&done_flag[blockIdx.x], done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }

@@ -191,8 +191,13 @@ class ShardedEnsemble:
         self.world = dist.get_world_size(group) if self.distributed else 1
         self.rank = dist.get_rank(group) if self.distributed else 0
         self.n_total, self.ndim = positions.shape
-        if self.n_total % 2 or self.n_total < 6:
-            raise ValueError("the ensemble needs an even number (>= 6) of walkers")
+        # three splits (the DE move as emcee runs it) need a walker and an ordered pair of partners in the other two thirds: 6;
+        # the two-set moves need 4 (cosmofit_ensemble.hip: ens_check keeps the same two bounds)
+        need = 6 if (de_splits == 3 and any(m == "de" for m, _ in self.moves)) else 4
+        if self.n_total % 2 or self.n_total < need:
+            raise ValueError(f"the ensemble needs an even number (>= {need}) of walkers")
+        if any(m == "kde" for m, _ in self.moves) and self.n_total // 2 <= self.ndim:
+            raise ValueError("the KDE move needs more than ndim walkers in each half (the complementary set's covariance must be regular)")
         self.start, self.stop = shard_bounds(self.n_total, self.world, self.rank)
         counts = [shard_bounds(self.n_total, self.world, r) for r in range(self.world)]
         self.randomize_split = randomize_split

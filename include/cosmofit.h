@@ -328,9 +328,14 @@ void cf_split_rows(int64_t W, int32_t n, int32_t k, int64_t* begin, int64_t* end
 /* Device buffers on the handle's device; asynchronous on `hip_stream` (a hipStream_t; NULL = HIP's
  * default stream, which is what torch.cuda.current_stream().cuda_stream reports as 0), ordered like any
  * other work on that stream. Grows the workspace if needed (then it synchronises once).
- * A handle owns ONE workspace (residual rows, chi^2 shares, arrival counters): evaluations of one handle must be
- * ordered with respect to each other -- same stream, or streams the caller has ordered with events; for concurrent
- * evaluations create one handle per stream. */
+ * A handle owns ONE workspace (residual rows, chi^2 shares, arrival counters): evaluations of one handle are
+ * ordered with respect to each other by the library -- on one stream by that stream; when an evaluation arrives on a
+ * DIFFERENT stream than the handle's previous one (cf_eval and the accessors run on a stream the handle owns), the
+ * library first waits ON THE HOST until the previous evaluation has drained (hipDeviceSynchronize if that one ran on
+ * a caller's stream: the caller's stream handle is never passed back to HIP, so it may be destroyed at any time after
+ * the call that used it).  Hence: calls that stay on one stream are purely asynchronous and capturable into a
+ * hipGraph; the FIRST call after a stream switch blocks the host and is illegal while `hip_stream` is capturing.
+ * For concurrent evaluations create one handle per stream. */
 int cf_eval_device(cf_handle* h, const double* d_theta, int64_t W, double* d_out,
                    int32_t out_kind, void* hip_stream);
 

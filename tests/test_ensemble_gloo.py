@@ -230,6 +230,15 @@ def test_odd_and_tiny_ensembles_are_refused():
     with pytest.raises(ValueError, match="even number"):
         E.ShardedEnsemble(gauss_logp, _init_positions(9), moves_impl=_tensor_moves())
     with pytest.raises(ValueError, match="even number"):
-        E.ShardedEnsemble(gauss_logp, _init_positions(4), moves_impl=_tensor_moves())
+        E.ShardedEnsemble(gauss_logp, _init_positions(2), moves_impl=_tensor_moves())
     with pytest.raises(ValueError, match="de_splits"):
         E.ShardedEnsemble(gauss_logp, _init_positions(8), moves_impl=_tensor_moves(), de_splits=4)
+    # only the three-split DE move needs 6 walkers: the two-set moves run on 4, as the library's own check (ens_check) allows
+    for kw in (dict(moves=(("stretch", 1.0),)), dict(moves=(("de", 1.0),), de_splits=2)):
+        ens = E.ShardedEnsemble(gauss_logp, _init_positions(4), seed=3, moves_impl=_tensor_moves(), **kw)
+        ens.run(2)
+        assert ens.n_proposed == 8
+    with pytest.raises(ValueError, match=">= 6"):
+        E.ShardedEnsemble(gauss_logp, _init_positions(4), moves=(("de", 1.0),), moves_impl=_tensor_moves())
+    with pytest.raises(ValueError, match="KDE move needs"):
+        E.ShardedEnsemble(gauss_logp, _init_positions(4), moves=(("kde", 1.0),), moves_impl=_tensor_moves())

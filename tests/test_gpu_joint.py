@@ -58,6 +58,25 @@ def test_bao_desi_cmb_golden(gpu):
     lk.engine.close()
 
 
+def test_no_sn_random_batches_soak_completion_word(gpu):
+    """A likelihood WITHOUT an SN block ends in finalize_kernel, whose four waves each store 64 results into the pinned block ahead of
+    the block's completion word (synchronous zero-copy calls up to 4096 walkers).  2000 calls of random sizes at random offsets, every
+    result the same bits as in one 4096-walker batch: a completion word that overtakes the stores of waves 1-3 hands back the
+    previous call's numbers for walkers 64..255 of a block (tools/soak_small_batches.py WORKLOAD=desi_cmb runs 10^5s)."""
+    g = golden("bao_desi_cmb")
+    lk = gpu.likelihoods.DesiCmb(*_bao_args(g), bounds=g["bounds"])
+    theta = gpu.synthetic.walkers(np.asarray(g["bounds"]), 4096, seed=0)
+    full = np.array(lk.log_probs_vectorized(theta), copy=True)
+    assert np.all(np.isfinite(full)) and np.unique(full).size > 4000
+    rng = np.random.default_rng(5)
+    sizes = np.concatenate([rng.integers(65, 600, 1700), rng.integers(600, 4097, 300)])
+    rng.shuffle(sizes)
+    for W in sizes:
+        o = int(rng.integers(0, len(theta) - W + 1))
+        np.testing.assert_array_equal(lk.log_probs_vectorized(theta[o:o + W]), full[o:o + W], err_msg=f"W={W} offset={o}")
+    lk.engine.close()
+
+
 def test_bao_desi_fs_lya_cmb_golden(gpu):
     g = golden("bao_desi_fs_lya_cmb")
     lk = gpu.likelihoods.DesiFsLyaCmb(*_bao_args(g))

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Soak test of the small-batch paths: thousands of synchronous cf_eval calls of random batch sizes (random offsets into a fixed set of
 walkers), every result compared BITWISE with the same walker's result from one 4096-walker batch.  An intermittent hand-off or
-completion-word race would show as a mismatch.  WORKLOAD=pantheon (default) | desi_cmb_des5y[:cpl];  CALLS (default 6000)."""
+completion-word race would show as a mismatch.  WORKLOAD=pantheon (default) | desi_cmb_des5y[:cpl] | desi_cmb (no SN block: the
+per-walker kernels + finalize_kernel, whose four waves all store results ahead of the block's completion word);  CALLS (default 6000)."""
 import importlib, os, sys, time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,6 +14,11 @@ if wl == "pantheon":
     syn = pkg.synthetic.pantheon_like(n_sn=1701, seed=0)
     th = pkg.synthetic.walkers(pkg.sn_pantheon.bounds, 4096, seed=0)
     lk = pkg.sn_pantheon.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"])
+    f = lk.log_probs_vectorized
+elif wl == "desi_cmb":  # bao/desi_cmb.py: BAO + compressed CMB, no SN block -> walker + small blocks + finalize_kernel
+    g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "bao_desi_cmb.npz"))
+    lk = pkg.likelihoods.DesiCmb(g["bao_z"], g["bao_val"], g["bao_qty"], g["bao_inv_cov"], bounds=g["bounds"])
+    th = pkg.synthetic.walkers(np.asarray(g["bounds"]), 4096, seed=0)
     f = lk.log_probs_vectorized
 else:
     fde = "cpl" if wl.endswith(":cpl") else "lcdm"
