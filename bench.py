@@ -278,7 +278,6 @@ def main():
                 (f"bao/desi_des5y_bbn_theta_star.py joint log P: {args.n_sn} SNe + 13 BAO (exact D_H) + l_A + BBN prior, "
                  f"physical-density E(z) with thawing dark energy, {Wl} walkers per GPU per step"),
                 "workload_key": args.workload if args.fde == "lcdm" else f"{args.workload}:{args.fde}",
-                "dispatches_per_step": None if os.environ.get("CF_CHUNKS") else 1,
                 "walkers_per_gpu": Wl, "walkers_total": W_total, "n_sn": args.n_sn, "n_grid": 4000, "ndim": ndim,
                 "parallelism": f"walkers sharded over {world} GPU(s)" + (
                     "" if not use_dist else

@@ -30,6 +30,20 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define CF_YPK_SLACK 8192
 #define CF_DELTA_SLACK 4096  // the inverse-GEMM pipeline prefetches a few K-step pairs past the last residual row
 
+// Tuning overrides, ONE environment string read once per process: CF_TUNE="key=value,key=value,..." (integers).  None of them
+// changes a result; the table of keys is in DESIGN.md ("Knobs").  The three settings a user may need have their own variables
+// (CF_HOST_WAIT, CF_ZEROCOPY_MAX here; COSMOFIT_LIB in the Python loader).
+static long long cf_tune(const char* key, long long dflt) {
+  static const std::string env = [] { const char* e = getenv("CF_TUNE"); return std::string(e ? e : ""); }();
+  const size_t kl = strlen(key);
+  for (size_t pos = 0; pos < env.size();) {
+    const size_t end = std::min(env.find(',', pos), env.size());
+    if (end - pos > kl + 1 && env.compare(pos, kl, key) == 0 && env[pos + kl] == '=') return atoll(env.c_str() + pos + kl + 1);
+    pos = end + 1;
+  }
+  return dflt;
+}
+
 #define CF_BAO_NODES 6  // table nodes copied out per BAO datum (cosmofit_kernels.hip)
 #define CF_SN_PARTS_MAX 4                         // workgroups per walker of a small batch (walker_fast_kernel)
 #define CF_SN_REC_SLACK (512 * CF_SN_PARTS_MAX)   // spare SN records behind the last one
@@ -78,10 +92,24 @@ static walker_fast_fn pick_walker_fast(int model, int fde) {
   return table[model][fde];
 }
 // The lean kernel arguments of the production per-walker kernel, and whether this descriptor may take it: register path of the
-// table build (<= 4096 grid nodes), an SN block that fits sn_fast_loop.  CF_WALKER_GENERIC=1 forces the generic kernel (A/B).
+// table build (<= 4096 grid nodes), an SN block that fits sn_fast_loop.  CF_TUNE walker_generic=1 forces the generic kernel (A/B).
 static bool walker_fast_ok(const cf_dev_desc& d) {
-  static const bool off = [] { const char* e = getenv("CF_WALKER_GENERIC"); return e && atoi(e) != 0; }();
+  static const bool off = cf_tune("walker_generic", 0) != 0;
   return !off && d.chunk_shift == 3 && d.ndim <= 64 && !d.sn_fixed_mu && !d.sn_dir && !d.sn_vel_mult && (!d.sn_lin || d.lin_in_rec);
+}
+// What finalize_value reads of the descriptor (cosmofit_device.h: cf_epilogue).
+static cf_epilogue epilogue_of(const cf_dev_desc& d) {
+  cf_epilogue e{};
+  e.ndim = d.ndim; e.has_bounds = d.has_bounds; e.n_gauss = d.n_gauss; e.n_chi2_gauss = d.n_chi2_gauss;
+  e.cpl_wall = d.cpl_wall; e.n_fs8 = d.n_fs8; e.n_cc = d.n_cc; e.cc_f_inverse = d.cc_f_inverse;
+  e.log_norm = d.log_norm; e.logl_const = d.logl_const; e.cc_logdet = d.cc_logdet;
+  e.w0 = d.slot[CF_P_W0_D]; e.wa = d.slot[CF_P_WA_D]; e.fs8err = d.slot[CF_P_FS8ERR_D]; e.fcc = d.slot[CF_P_FCC_D];
+  for (int k = 0; k < CF_MAX_NDIM; ++k) { e.lo[k] = d.lo[k]; e.hi[k] = d.hi[k]; }
+  for (int k = 0; k < CF_MAX_GAUSS; ++k) {
+    e.gauss_idx[k] = d.gauss_idx[k]; e.gauss_mean[k] = d.gauss_mean[k]; e.gauss_sigma[k] = d.gauss_sigma[k];
+    e.chi2_gauss_idx[k] = d.chi2_gauss_idx[k]; e.chi2_gauss_mean[k] = d.chi2_gauss_mean[k]; e.chi2_gauss_sigma[k] = d.chi2_gauss_sigma[k];
+  }
+  return e;
 }
 static cf_walker_args walker_args_of(const cf_dev_desc& d) {
   cf_walker_args a{};
@@ -123,55 +151,37 @@ static growth_fn pick_growth(int model, int fde, int steps) {  // steps = 256 C,
   return table[c == 1 ? 0 : c == 2 ? 1 : c == 4 ? 2 : 3][model][fde];
 }
 template <int KS, int TC>
-__global__ void trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* theta, int64_t W, const double* delta,
-                                 d2* ypk, const double* chi2_extra, double* out, int out_kind,
+__global__ void trsm_chi2_kernel(const cf_epilogue* epi, int n_pad, int n_ld, int ndim, cf_dev_pack pk, const double* theta, int64_t W,
+                                 const double* delta, d2* ypk, const double* chi2_extra, double* out, int out_kind,
                                  unsigned long long* nonfinite, double* chi2_sn_out);
-#define CF_DECLARE_TRSM(KS, TC)                                                                                       \
-  extern template __global__ void trsm_chi2_kernel<KS, TC>(cf_dev_desc, cf_dev_pack, const double*, int64_t,          \
-                                                           const double*, d2*, const double*, double*, int,           \
-                                                           unsigned long long*, double*);
-CF_DECLARE_TRSM(1, 4)
-CF_DECLARE_TRSM(2, 4)
-CF_DECLARE_TRSM(4, 4)
-CF_DECLARE_TRSM(2, 8)
+extern template __global__ void trsm_chi2_kernel<2, 4>(const cf_epilogue*, int, int, int, cf_dev_pack, const double*, int64_t, const double*,
+                                                       d2*, const double*, double*, int, unsigned long long*, double*);
 template <int NP, int PF>
-__global__ void tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* theta, int64_t W, const double* delta,
-                                     int64_t w_pad, double* partial, unsigned int* arrivals, const double* chi2_extra,
-                                     double* out, int out_kind, unsigned long long* nonfinite, double* chi2_sn_out,
-                                     int panels_per_group, unsigned long long* done_flag, unsigned long long done_seq, int snake);
+__global__ void tri_gemm_chi2_kernel(const cf_epilogue* epi, const d2* frags, int n_ld, int ndim, int n_rb, const double* theta, int64_t W,
+                                     const double* delta, int64_t w_pad, double* partial, unsigned int* arrivals, const double* chi2_extra,
+                                     double* out, int out_kind, unsigned long long* nonfinite, double* chi2_sn_out, int panels_per_group,
+                                     unsigned int n_units, unsigned int* queue, unsigned long long* done_flag, unsigned long long done_seq);
 template <int PF, bool FRAG, int TPW>
-__global__ void tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* theta, int64_t W, const double* delta,
-                                      double* partial4, unsigned int* arrivals, const double* chi2_extra, double* out, int out_kind,
-                                      unsigned long long* nonfinite, double* chi2_sn_out, int units_pad,
+__global__ void tri_gemm_small_kernel(const cf_epilogue* epi, const d2* frags, int n_ld, int ndim, int n_rb, const double* theta, int64_t W,
+                                      const double* delta, double* partial4, unsigned int* arrivals, const double* chi2_extra, double* out,
+                                      int out_kind, unsigned long long* nonfinite, double* chi2_sn_out, int units_pad,
                                       unsigned long long* done_flag, unsigned long long done_seq);
-#define CF_DECLARE_TRIGEMM_SMALL(PF, FRAG, TPW)                                                                                        \
-  extern template __global__ void tri_gemm_small_kernel<PF, FRAG, TPW>(cf_dev_desc, cf_dev_invpack, const double*, int64_t, const double*, \
-                                                                       double*, unsigned int*, const double*, double*, int,                \
+#define CF_DECLARE_TRIGEMM_SMALL(PF, FRAG, TPW)                                                                                          \
+  extern template __global__ void tri_gemm_small_kernel<PF, FRAG, TPW>(const cf_epilogue*, const d2*, int, int, int, const double*, int64_t, \
+                                                                       const double*, double*, unsigned int*, const double*, double*, int, \
                                                                        unsigned long long*, double*, int, unsigned long long*, unsigned long long);
-CF_DECLARE_TRIGEMM_SMALL(4, false, 1)
-CF_DECLARE_TRIGEMM_SMALL(8, false, 1)
-CF_DECLARE_TRIGEMM_SMALL(16, false, 1)
-CF_DECLARE_TRIGEMM_SMALL(4, true, 1)
-CF_DECLARE_TRIGEMM_SMALL(8, true, 1)
 CF_DECLARE_TRIGEMM_SMALL(16, true, 1)
-CF_DECLARE_TRIGEMM_SMALL(4, false, 2)
-CF_DECLARE_TRIGEMM_SMALL(8, false, 2)
-CF_DECLARE_TRIGEMM_SMALL(4, true, 2)
+CF_DECLARE_TRIGEMM_SMALL(16, false, 1)
 CF_DECLARE_TRIGEMM_SMALL(8, true, 2)
-CF_DECLARE_TRIGEMM_SMALL(4, false, 4)
-CF_DECLARE_TRIGEMM_SMALL(4, true, 4)
-#define CF_DECLARE_TRIGEMM(NP, PF)                                                                                       \
-  extern template __global__ void tri_gemm_chi2_kernel<NP, PF>(cf_dev_desc, cf_dev_invpack, const double*, int64_t,     \
-                                                               const double*, int64_t, double*, unsigned int*,          \
-                                                               const double*, double*, int, unsigned long long*, double*, int,  \
-                                                               unsigned long long*, unsigned long long, int);
+CF_DECLARE_TRIGEMM_SMALL(8, false, 2)
+#define CF_DECLARE_TRIGEMM(NP, PF)                                                                                                       \
+  extern template __global__ void tri_gemm_chi2_kernel<NP, PF>(const cf_epilogue*, const d2*, int, int, int, const double*, int64_t,     \
+                                                               const double*, int64_t, double*, unsigned int*, const double*, double*,  \
+                                                               int, unsigned long long*, double*, int, unsigned int, unsigned int*,      \
+                                                               unsigned long long*, unsigned long long);
 CF_DECLARE_TRIGEMM(1, 2)
-CF_DECLARE_TRIGEMM(1, 4)
 CF_DECLARE_TRIGEMM(2, 2)
-CF_DECLARE_TRIGEMM(2, 3)
-CF_DECLARE_TRIGEMM(2, 4)
-CF_DECLARE_TRIGEMM(4, 2)
-extern "C" __global__ void finalize_kernel(cf_dev_desc d, const double* theta, int64_t W, const double* chi2_extra,
+extern "C" __global__ void finalize_kernel(cf_epilogue d, const double* theta, int64_t W, const double* chi2_extra,
                                            double* out, int out_kind, unsigned long long* nonfinite, unsigned long long* done_flag,
                                            unsigned long long done_seq);
 extern "C" __global__ void interp_kernel(const double* xq, int64_t nq, const double* x, const double* y,
@@ -182,38 +192,18 @@ extern "C" __global__ void pad_rhs_kernel(const double* b, int64_t nrhs, int64_t
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
 
-// Shape of the solve kernel's workgroup: ksplit x tclasses waves (see cf_dev_pack).  Default 2x4 =
-// 8 waves, two per SIMD; CF_SOLVE_SHAPE=1x4|2x4|4x4|2x8 in the environment overrides it (tuning / tests).
+// Shape of the blocked solve kernel's workgroup: ksplit x tclasses = 2 x 4 waves, two per SIMD (see cf_dev_pack).
 static void default_shape(int& ks, int& tc) {
   ks = 2;
   tc = 4;
-  const char* e = getenv("CF_SOLVE_SHAPE");
-  if (e) {
-    int a = 0, b = 0;
-    if (sscanf(e, "%dx%d", &a, &b) == 2 && ((b == 4 && (a == 1 || a == 2 || a == 4)) || (a == 2 && b == 8))) {
-      ks = a;
-      tc = b;
-    }
-  }
 }
 #define CF_PROBE_LIMIT 1e-11
-// default sub-batches of a large evaluation (see create_one); 0 = one batch
-#ifndef CF_DEFAULT_CHUNK_FIRST
-#define CF_DEFAULT_CHUNK_FIRST 0
-#define CF_DEFAULT_CHUNK_REST 0
-#endif
 
 static int pack_default(const double* L, int64_t n, int64_t ld, cf_host_pack& hp, double* probe_rel = nullptr) {
   int ks, tc;
   default_shape(ks, tc);
   int rc = cf_pack_cholesky(L, n, ld, hp, ks, tc);
   if (rc == 0 && probe_rel) *probe_rel = cf_pack_probe(hp, L, ld);
-#ifdef CF_DEBUG
-  // TIMING EXPERIMENT ONLY (wrong results; debug builds: make EXTRA=-DCF_DEBUG): fold every update stream onto the
-  // first 64 KiB so that all factor loads hit L1/L2 -- tells an operand-delivery bound from an MFMA-issue bound.
-  if (rc == 0 && getenv("CF_DEBUG_ALIAS_STREAMS"))
-    for (auto& o : hp.upd_off) o = o % 32;
-#endif
   return rc;
 }
 
@@ -318,7 +308,6 @@ struct PinnedBuf {
 #ifndef CF_NP2_FROM
 #define CF_NP2_FROM 512  // walkers: 32-walker panels in the throughput solve kernel beyond this batch size, 16-walker panels up to it
 #endif
-#define CF_MAX_CHUNKS 8  // sub-batches of one evaluation (walker kernel of chunk c + 1 beside the solve of chunk c)
 
 // A host thread that evaluates one replica's slice of a multi-device cf_eval (one per replica beyond the first).
 struct cf_worker {
@@ -340,17 +329,17 @@ struct cf_handle {
   InversePack ipack;
   DevBuf partial, arrivals;  // inverse-GEMM solve: chi^2 shares per (row block, walker); arrival counters per panel
   DevBuf partial4;           // small-batch solve: shares per (panel, row block, tile, walker), CF_SMALL_MAX_PANELS panels
+  DevBuf queue;              // throughput solve: {next unit, workgroups that have left} of the persistent grid (re-armed by the kernel)
+  DevBuf epi;                // device copy of `epi_host`: what the solve kernels' last arrivers read of the prior / output epilogue
+  cf_epilogue epi_host{};
   hipStream_t stream = nullptr;  // host-buffer evaluations (cf_eval, cf_eval_parts)
-  hipStream_t aux = nullptr;     // second stream of a chunked evaluation
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_walker[2] = {nullptr, nullptr};
   // the ONE workspace is shared by every evaluation of this handle: an evaluation launched on a different stream
   // than the previous one first waits (on the host) for that stream
   hipStream_t last_stream = nullptr;
   bool has_last = false;
-  // timing ring: per evaluation and chunk 3 events (before the walker kernel, between it and the solve, after the solve)
+  // timing ring: per evaluation 4 events (before the walker kernel, behind it, behind the small-block / growth kernels, behind the solve)
   std::vector<hipEvent_t> ev;
-  std::vector<int> ev_chunks;  // chunks of the evaluation in each ring slot
-  int timing_slots = 0, timing_stride = 1, ev_per_slot = 1;
+  int timing_slots = 0, timing_stride = 1;
   int64_t timed_calls = 0, eval_calls = 0;
   cf_dev_desc d{};
   PackedFactor pack;
@@ -369,7 +358,6 @@ struct cf_handle {
   double pack_probe_rel = 0.0;
   int cu_count = 0;
   char arch[64] = {0};
-  int64_t chunk_first = 0, chunk_rest = 0;  // sub-batch sizes of a chunked evaluation (0: one batch)
   // replicas on further devices (owned by the primary handle) and their worker threads
   std::vector<cf_handle*> peers;
   std::vector<std::unique_ptr<cf_worker>> workers;
@@ -455,8 +443,9 @@ static int ensure_workspace(cf_handle* h, int64_t W) {
     if (h->partial.ensure((size_t)w_pad * h->ipack.dev.n_rowblocks * 8)) return CF_ERR_HIP;
     if (h->arrivals.ensure((size_t)(w_pad / 16) * 4)) return CF_ERR_HIP;
     if (h->partial4.ensure((size_t)CF_SMALL_MAX_PANELS * 4 * h->ipack.dev.n_rowblocks * 16 * 8)) return CF_ERR_HIP;
-
-    HIP_TRY(hipMemsetAsync(h->arrivals.p, 0, (size_t)(w_pad / 16) * 4, h->stream));  // the kernel re-arms them itself
+    if (h->queue.ensure(64)) return CF_ERR_HIP;
+    HIP_TRY(hipMemsetAsync(h->arrivals.p, 0, (size_t)(w_pad / 16) * 4, h->stream));  // the kernels re-arm them themselves
+    HIP_TRY(hipMemsetAsync(h->queue.p, 0, 64, h->stream));
   }
   if (h->d.n_sn > 0) {
     if (h->delta.ensure((size_t)w_pad * n_ld * 8 + CF_DELTA_SLACK)) return CF_ERR_HIP;
@@ -643,23 +632,7 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
   }
   if (strncmp(h->arch, "gfx950", 6) != 0)
     return bail(fail(CF_ERR_UNSUPPORTED, std::string("cf_create: device is ") + h->arch + ", this library is built for gfx950 only"));
-  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess)
-    return bail(fail(CF_ERR_HIP, "hipStreamCreate failed"));
-  for (hipEvent_t* e : {&h->ev_fork, &h->ev_join, &h->ev_walker[0], &h->ev_walker[1]})
-    if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return bail(fail(CF_ERR_HIP, "hipEventCreate failed"));
-  {
-    // sub-batches of a large evaluation (CF_CHUNKS=<first>,<rest>; 0 = one batch): the distance / residual kernel of
-    // chunk c + 1 (FP64 VALU) runs beside the solve of chunk c (FP64 matrix cores); a walker's result does not depend
-    // on the chunking (tests/test_gpu_parity.py: batch invariance)
-    h->chunk_first = CF_DEFAULT_CHUNK_FIRST;
-    h->chunk_rest = CF_DEFAULT_CHUNK_REST;
-    if (const char* e = getenv("CF_CHUNKS")) {
-      long long a = 0, b = 0;
-      const int n = sscanf(e, "%lld,%lld", &a, &b);
-      if (n >= 1 && a >= 0) { h->chunk_first = a / 32 * 32; h->chunk_rest = (n == 2 && b > 0 ? b : a) / 32 * 32; }
-    }
-  }
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(CF_ERR_HIP, "hipStreamCreate failed"));
 
   cf_dev_desc& d = h->d;
   d.ndim = c->ndim;
@@ -981,6 +954,11 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
   if (d.chunk_shift == 3 && ((d.ez_model == CF_EZ_PHYSICAL_D && !d.nu_sw) ||
                              ((d.fde == CF_FDE_WCDM_D || d.fde == CF_FDE_CPL_D) && (!d.ln_sw || !d.exp2_tab))))
     return bail(fail(CF_ERR_INVALID, "cf_create: internal: the table build's neutrino / ln(1 + z) tables are missing"));
+  // the prior / output epilogue's view of the descriptor: by value for finalize_kernel, through its device copy for the solve kernels
+  h->epi_host = epilogue_of(d);
+  if (h->epi.ensure(sizeof(cf_epilogue))) return bail(CF_ERR_HIP);
+  if (hipMemcpy(h->epi.p, &h->epi_host, sizeof(cf_epilogue), hipMemcpyHostToDevice) != hipSuccess)
+    return bail(fail(CF_ERR_HIP, "hipMemcpy of the epilogue block failed"));
   *out = h;
   return CF_OK;
 }
@@ -1054,10 +1032,7 @@ extern "C" void cf_destroy(cf_handle* h) {
   (void)hipDeviceSynchronize();  // evaluations launched on callers' streams may still use the workspace
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
-  for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_walker[0], h->ev_walker[1]})
-    if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
-  if (h->aux) (void)hipStreamDestroy(h->aux);
   delete h;
 }
 
@@ -1092,14 +1067,11 @@ extern "C" int cf_enable_timing(cf_handle* h, int slots) {
   if (slots < 0 || slots > 4096) return fail(CF_ERR_INVALID, "cf_enable_timing: slots must be in 0..4096");
   std::lock_guard<std::mutex> lk(h->mu);
   HIP_TRY(hipSetDevice(h->device));
-  // ring slot = 3 events per sub-batch the handle can run: one sub-batch unless the chunked pipeline is configured
-  h->ev_per_slot = h->chunk_first > 0 ? CF_MAX_CHUNKS : 1;
-  while ((int)h->ev.size() < 4 * h->ev_per_slot * slots) {
+  while ((int)h->ev.size() < 4 * slots) {
     hipEvent_t e;
     HIP_TRY(hipEventCreate(&e));
     h->ev.push_back(e);
   }
-  h->ev_chunks.assign((size_t)slots, 0);
   h->timing_slots = slots;
   h->timed_calls = 0;
   h->eval_calls = 0;  // the sampling phase restarts with the ring
@@ -1124,16 +1096,9 @@ extern "C" int cf_kernel_ms3(cf_handle* h, int64_t call, float t[3]) {
   if (h->timing_slots == 0 || call < 0 || call >= h->timed_calls || call < h->timed_calls - h->timing_slots)
     return fail(CF_ERR_INVALID, "cf_kernel_ms3: that call is not in the timing ring");
   const int slot = (int)(call % h->timing_slots);
-  t[0] = t[1] = t[2] = 0.0f;
-  for (int c = 0; c < h->ev_chunks[slot]; ++c) {  // a chunked evaluation: the sum over its sub-batches
-    hipEvent_t* e = &h->ev[4 * (slot * h->ev_per_slot + c)];
-    HIP_TRY(hipEventSynchronize(e[3]));
-    for (int k = 0; k < 3; ++k) {
-      float a = 0.0f;
-      HIP_TRY(hipEventElapsedTime(&a, e[k], e[k + 1]));
-      t[k] += a;
-    }
-  }
+  hipEvent_t* e = &h->ev[4 * slot];
+  HIP_TRY(hipEventSynchronize(e[3]));
+  for (int k = 0; k < 3; ++k) HIP_TRY(hipEventElapsedTime(&t[k], e[k], e[k + 1]));
   return CF_OK;
 }
 
@@ -1154,98 +1119,104 @@ extern "C" int cf_last_kernel_ms(cf_handle* h, float t[2]) {
   return cf_kernel_ms(h, h->timed_calls - 1, t);
 }
 
-template <int KS, int TC>
-static int launch_trsm_t(const cf_dev_desc& d, const cf_dev_pack& pk, const double* d_theta, int64_t W,
-                         const double* delta, d2* ypk, const double* chi2_extra, double* d_out, int out_kind,
-                         unsigned long long* nf, hipStream_t st, double* chi2_sn_out) {
-  const size_t lds = (size_t)KS * (CF_BLOCK_ROWS / 8 * 64) * sizeof(d2);
+// Blocked solve (fallback): one 512-thread workgroup per 16-walker panel, trsm_chi2_kernel<2, 4>.
+static int launch_trsm(const cf_epilogue* epi, int n_pad, int n_ld, int ndim, const cf_dev_pack& pk, const double* d_theta, int64_t W,
+                       const double* delta, d2* ypk, const double* chi2_extra, double* d_out, int out_kind, unsigned long long* nf,
+                       hipStream_t st, double* chi2_sn_out = nullptr) {
+  if (pk.ksplit != 2 || pk.tclasses != 4) return fail(CF_ERR_INVALID, "bad solve shape");
+  const size_t lds = (size_t)2 * (CF_BLOCK_ROWS / 8 * 64) * sizeof(d2);
   static thread_local int attr_device = -1;  // > 64 KB of dynamic LDS must be allowed once per device
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   if (lds > 64 * 1024 && attr_device != dev) {
-    HIP_TRY(hipFuncSetAttribute((const void*)(&trsm_chi2_kernel<KS, TC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)(&trsm_chi2_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_device = dev;
   }
   const unsigned panels = (unsigned)((W + 15) / 16);
-  hipLaunchKernelGGL((trsm_chi2_kernel<KS, TC>), dim3(panels), dim3(64 * KS * TC), lds, st, d, pk, d_theta, W, delta, ypk,
-                     chi2_extra, d_out, out_kind, nf, chi2_sn_out);
+  hipLaunchKernelGGL((trsm_chi2_kernel<2, 4>), dim3(panels), dim3(512), lds, st, epi, n_pad, n_ld, ndim, pk, d_theta, W, delta, ypk, chi2_extra, d_out, out_kind, nf, chi2_sn_out);
   return 0;
 }
 
-static int launch_trsm(const cf_dev_desc& d, const cf_dev_pack& pk, const double* d_theta, int64_t W,
-                       const double* delta, d2* ypk, const double* chi2_extra, double* d_out, int out_kind,
-                       unsigned long long* nf, hipStream_t st, double* chi2_sn_out = nullptr) {
-  switch (pk.ksplit * 16 + pk.tclasses) {
-    case 1 * 16 + 4: return launch_trsm_t<1, 4>(d, pk, d_theta, W, delta, ypk, chi2_extra, d_out, out_kind, nf, st, chi2_sn_out);
-    case 2 * 16 + 4: return launch_trsm_t<2, 4>(d, pk, d_theta, W, delta, ypk, chi2_extra, d_out, out_kind, nf, st, chi2_sn_out);
-    case 4 * 16 + 4: return launch_trsm_t<4, 4>(d, pk, d_theta, W, delta, ypk, chi2_extra, d_out, out_kind, nf, st, chi2_sn_out);
-    case 2 * 16 + 8: return launch_trsm_t<2, 8>(d, pk, d_theta, W, delta, ypk, chi2_extra, d_out, out_kind, nf, st, chi2_sn_out);
-  }
-  return fail(CF_ERR_INVALID, "bad solve shape");
-}
-
-// Inverse-GEMM solve: panels of 16*NP walkers per workgroup.  NP = 2 halves the factor traffic per flop and is
-// the throughput shape; NP = 1 keeps the latency of small batches short.  CF_GEMM_SHAPE=<NP>x<PF> overrides (tuning).
+// Inverse-GEMM solve.  Panels of 16 NP walkers per unit of work: NP = 2 halves the factor traffic per flop and is the throughput
+// shape; NP = 1 keeps the units of a batch of <= 512 walkers short.
 struct TriGemmArgs {
-  const cf_dev_desc* d;
-  const cf_dev_invpack* pk;
+  const cf_epilogue* epi;
+  const d2* frags;
+  int n_ld, ndim, n_rb, cu_count;
   const double* theta;
   int64_t W;
   const double* delta;
   int64_t w_pad;
   double* partial;
   unsigned int* arrivals;
+  unsigned int* queue;
   const double* chi2_extra;
   double* out;
   int out_kind;
   unsigned long long* nonfinite;
   double* chi2_sn_out;
   double* partial4;
-  unsigned long long* done_flag;  // pinned host words the small-batch kernel's last arrivers set to done_seq, or null
+  unsigned long long* done_flag;  // pinned host words the last arrivers set to done_seq, or null
   unsigned long long done_seq;
   bool frag_b;  // `delta` holds the panels' residuals in the small-batch kernel's fragment order (walker_fast_kernel, frag_b)
 };
 
+// Workgroups per CU of the throughput solve kernel's persistent grid for a batch of `n_units` units (CF_TUNE gemm_wgs=<1..4> forces one).
+// Four is what registers and LDS admit (127 VGPRs, 33 KB).  The grid must be SMALLER than the number of units for the queue to have
+// anything to balance with: a batch whose units would all be resident at once gets fewer workgroups per CU, so that the longest
+// units start first and the short ones fill in behind them.
+static int tri_gemm_wgs_per_cu(int64_t n_units, int cu_count) {
+  static const int forced = (int)cf_tune("gemm_wgs", 0);
+  if (forced >= 1 && forced <= 4) return forced;
+  for (int k = 4; k > 1; --k)
+    if (n_units >= (int64_t)2 * k * cu_count) return k;  // at least half of the units (the short half) come from the queue
+  return n_units >= (int64_t)(3 * cu_count) / 2 ? 2 : 1;
+}
+
 template <int NP, int PF>
 static int launch_tri_gemm_t(const TriGemmArgs& a, hipStream_t st) {
-  const int panels = (int)((a.W + 16 * NP - 1) / (16 * NP));
-  // Panel groups: the grid runs group by group (a group = `ppg` panels x all row blocks), so that a group's residual rows
+  // Panel groups: the units run group by group (a group = `ppg` panels x all row blocks), so that a group's residual rows
   // stay in the 256 MB Infinity Cache while its 27 row blocks pass over them.  Up to 8192 walkers (256 panels of 32: 113 MB
   // of residual rows) one group is best (W = 4096: one group 226 us, two 229 us, four 249 us -- the factor streams are
   // re-read per group); beyond that the rows no longer fit and every row block would stream them from HBM again
   // (W = 65536: 0.9 GB x 14 passes), so larger batches run in groups of 128 panels = 4096 walkers (measured at W = 65536,
   // profiles/r02_panel_groups.txt: one group 3.66 ms = 0.66 of peak, groups of 256 panels 3.05 ms = 0.79, of 128 panels
-  // 2.96 ms = 0.82).  CF_GEMM_GROUP=<panels> overrides (multiples of 8 so that a panel stays on one XCD; 0 = one group).
-  static const int env_group = [] { const char* e = getenv("CF_GEMM_GROUP"); return e ? atoi(e) : -1; }();
-  const int max_group = env_group >= 0 ? env_group : (panels > 256 ? 128 : 0);
-  int ppg = panels;
-  if (max_group > 0 && panels > max_group) {
-    const int n_groups = (panels + max_group - 1) / max_group;
-    ppg = ((panels + n_groups - 1) / n_groups + 7) / 8 * 8;
+  // 2.96 ms = 0.82).  CF_TUNE gemm_group=<panels> overrides (multiples of 8 so that a panel stays on one XCD; 0 = one group).
+  static const int env_group = (int)cf_tune("gemm_group", -1);
+  const int cus = a.cu_count > 0 ? a.cu_count : 256;
+  // One launch takes at most CF_MY_PANELS panels (32768 walkers of 32-walker panels): every workgroup keeps the panels it arrived
+  // last for in an LDS list that must hold them all.  A 65536-walker evaluation is two launches of eight groups.
+  constexpr int64_t per_launch = (int64_t)CF_MY_PANELS * 16 * NP;
+  for (int64_t base = 0; base < a.W; base += per_launch) {
+    const int64_t Wl = std::min(per_launch, a.W - base);
+    const int panels = (int)((Wl + 16 * NP - 1) / (16 * NP));
+    const int max_group = env_group >= 0 ? env_group : (panels > 256 ? 128 : 0);
+    int ppg = panels;
+    if (max_group > 0 && panels > max_group) {
+      const int n_groups = (panels + max_group - 1) / max_group;
+      ppg = ((panels + n_groups - 1) / n_groups + 7) / 8 * 8;
+    }
+    const int n_groups = (panels + ppg - 1) / ppg;
+    const int64_t n_units = (int64_t)n_groups * ppg * a.n_rb;
+    const int64_t grid = std::min<int64_t>(n_units, (int64_t)tri_gemm_wgs_per_cu(n_units, cus) * cus);
+    hipLaunchKernelGGL((tri_gemm_chi2_kernel<NP, PF>), dim3((unsigned)grid), dim3(256), 0, st, a.epi, a.frags, a.n_ld, a.ndim, a.n_rb,
+                       a.theta + base * a.ndim, Wl, a.delta + base * a.n_ld, a.w_pad, a.partial + base, a.arrivals + base / 16,
+                       a.chi2_extra ? a.chi2_extra + base : nullptr, a.out + base, a.out_kind, a.nonfinite,
+                       a.chi2_sn_out ? a.chi2_sn_out + base : nullptr, ppg, (unsigned)n_units, a.queue, a.done_flag, a.done_seq);
   }
-  const int n_groups = (panels + ppg - 1) / ppg;
-  const int n_wgs = n_groups * ppg * a.pk->n_rowblocks;
-  // order of the row blocks inside the grid: descending; for a grid that is resident all at once, alternate blocks of 256 workgroups
-  // ascending (see the kernel).  CF_GEMM_ORDER=0|1 forces one (tuning).
-  static const int order_env = [] { const char* e = getenv("CF_GEMM_ORDER"); return e ? atoi(e) : -1; }();
-  const int snake = order_env >= 0 ? order_env : (n_wgs <= 1024 ? 1 : 0);
-  hipLaunchKernelGGL((tri_gemm_chi2_kernel<NP, PF>), dim3((unsigned)n_wgs), dim3(256), 0, st, *a.d,
-                     *a.pk, a.theta, a.W, a.delta, a.w_pad, a.partial, a.arrivals, a.chi2_extra, a.out, a.out_kind, a.nonfinite,
-                     a.chi2_sn_out, ppg, a.done_flag, a.done_seq, snake);
   return 0;
 }
 
-// Small batches: one workgroup per (panel, row block, 16-row tile), see tri_gemm_small_kernel.  CF_SMALL_MAX=<walkers> moves the
-// switch (0 = never; at most 16 x CF_SMALL_MAX_PANELS), CF_SMALL_PF=4|8|16 the prefetch depth (tuning).
+// Small batches: one workgroup per (panel, row block, 16-row tile), see tri_gemm_small_kernel.
 template <int PF, bool FRAG, int TPW>
 static int launch_tri_gemm_small_t(const TriGemmArgs& a, hipStream_t st) {
   const int panels = (int)((a.W + 15) / 16);
-  const int units_pad = ((4 / TPW) * a.pk->n_rowblocks + 7) / 8 * 8;
+  const int units_pad = ((4 / TPW) * a.n_rb + 7) / 8 * 8;
   // dynamic LDS: the last arriver's shares + row-block sums -- padded so that at most TWO workgroups fit a CU.  With several
   // panels the grid outnumbers the CUs, and left to itself the dispatcher stacks three or four of these bandwidth-bound workgroups
   // on some CUs while others hold one (75 walkers: 33.7-34.6 -> 31.8-32.2 us per call, 150 walkers with two tiles per workgroup:
-  // 44 -> 39 us; profiles/r03_small_batch_solve.txt).  CF_SMALL_LDS_CAP=0 turns the padding off (tuning).
-  static const bool cap2 = [] { const char* e = getenv("CF_SMALL_LDS_CAP"); return !e || atoi(e) != 0; }();
+  // 44 -> 39 us; profiles/r03_small_batch_solve.txt).  CF_TUNE small_lds_cap=0 turns the padding off.
+  static const bool cap2 = cf_tune("small_lds_cap", 1) != 0;
   // the kernel's static LDS and the CU's LDS size as the runtime reports them; 0 = a query failed -> no padding (a guess could push
   // static + dynamic LDS past the 64 KB a workgroup may have, which would only show as a launch failure)
   static const size_t static_lds = [] {
@@ -1259,90 +1230,63 @@ static int launch_tri_gemm_small_t(const TriGemmArgs& a, hipStream_t st) {
     return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? (size_t)pr.maxSharedMemoryPerMultiProcessor
                                                                                                  : (size_t)0;
   }();
-  size_t dyn_lds = 64 * a.pk->n_rowblocks <= 4096 ? (size_t)80 * a.pk->n_rowblocks * 8 : 0;
+  size_t dyn_lds = 64 * a.n_rb <= 4096 ? (size_t)80 * a.n_rb * 8 : 0;
   const size_t third_of_cu = cu_lds / 3 + 1024;  // a third of a CU's LDS and a little: three workgroups no longer fit
   if (cap2 && static_lds > 0 && cu_lds > 0 && static_lds + dyn_lds < third_of_cu && third_of_cu <= 64 * 1024)
     dyn_lds = third_of_cu - static_lds;
-  hipLaunchKernelGGL((tri_gemm_small_kernel<PF, FRAG, TPW>), dim3((unsigned)(panels * units_pad)), dim3(256), dyn_lds, st, *a.d, *a.pk, a.theta, a.W,
-                     a.delta, a.partial4, a.arrivals, a.chi2_extra, a.out, a.out_kind, a.nonfinite, a.chi2_sn_out, units_pad,
-                     a.done_flag, a.done_seq);
+  hipLaunchKernelGGL((tri_gemm_small_kernel<PF, FRAG, TPW>), dim3((unsigned)(panels * units_pad)), dim3(256), dyn_lds, st, a.epi, a.frags, a.n_ld,
+                     a.ndim, a.n_rb, a.theta, a.W, a.delta, a.partial4, a.arrivals, a.chi2_extra, a.out, a.out_kind, a.nonfinite,
+                     a.chi2_sn_out, units_pad, a.done_flag, a.done_seq);
   return 0;
 }
 
+// largest batch of the small-batch solve kernel (CF_TUNE small_max=<walkers>; 0 = never; at most 16 x CF_SMALL_MAX_PANELS)
 static int64_t small_batch_max() {
   static const int64_t v = [] {
-    const char* e = getenv("CF_SMALL_MAX");
-    const long long m = e ? atoll(e) : (long long)CF_SMALL_DEFAULT;
+    const long long m = cf_tune("small_max", CF_SMALL_DEFAULT);
     return (int64_t)(m < 0 ? 0 : (m > 16 * CF_SMALL_MAX_PANELS ? 16 * CF_SMALL_MAX_PANELS : m));
   }();
   return v;
 }
 
+// walkers per panel of the throughput solve kernel for W walkers: 16 up to 512 walkers (48 against 53 us per call), 32 beyond
+// (528-576 walkers 64 against 67-69 us, 768: 71.7 against 77.1, 10 % at 4096; profiles/r03_gemm_stamps_and_pairing.txt).
+// CF_TUNE gemm_np=1|2 forces one.
+static int tri_gemm_panel_width(int64_t W) {
+  static const int forced = (int)cf_tune("gemm_np", 0);
+  return forced == 1 ? 16 : forced == 2 ? 32 : (W > CF_NP2_FROM ? 32 : 16);
+}
+
 static int launch_tri_gemm(const TriGemmArgs& a, hipStream_t st) {
   if (a.W <= small_batch_max() && a.partial4) {
-    // tiles per workgroup (CF_SMALL_TPW=1|2|4 overrides) and prefetch depth (CF_SMALL_PF=4|8|16; at most 8 / 4 for 2 / 4 tiles)
-    static const int pf_env = [] { const char* e = getenv("CF_SMALL_PF"); return e ? atoi(e) : 0; }();
-    static const int tpw_env = [] { const char* e = getenv("CF_SMALL_TPW"); return e ? atoi(e) : 0; }();
-    const int tpw = tpw_env > 0 ? tpw_env : (a.W <= 96 ? 1 : 2);  // measured: one tile up to 96 walkers (75: 32.0 against 34.0 us), two beyond (128: 37 against 38.5)
-    const int pf = pf_env > 0 ? pf_env : (tpw == 1 ? 16 : (tpw == 2 ? 8 : 4));
-    const bool f = a.frag_b;
-    if (tpw == 4) return f ? launch_tri_gemm_small_t<4, true, 4>(a, st) : launch_tri_gemm_small_t<4, false, 4>(a, st);
-    if (tpw == 2) {
-      if (pf <= 4) return f ? launch_tri_gemm_small_t<4, true, 2>(a, st) : launch_tri_gemm_small_t<4, false, 2>(a, st);
-      return f ? launch_tri_gemm_small_t<8, true, 2>(a, st) : launch_tri_gemm_small_t<8, false, 2>(a, st);
-    }
-    switch (pf) {
-      case 4: return f ? launch_tri_gemm_small_t<4, true, 1>(a, st) : launch_tri_gemm_small_t<4, false, 1>(a, st);
-      case 8: return f ? launch_tri_gemm_small_t<8, true, 1>(a, st) : launch_tri_gemm_small_t<8, false, 1>(a, st);
-      default: return f ? launch_tri_gemm_small_t<16, true, 1>(a, st) : launch_tri_gemm_small_t<16, false, 1>(a, st);
-    }
+    // measured: one tile per workgroup up to 96 walkers (75: 32.0 against 34.0 us), two beyond (128: 37 against 38.5)
+    static const int tpw_env = (int)cf_tune("small_tpw", 0);
+    const int tpw = (tpw_env == 1 || tpw_env == 2) ? tpw_env : (a.W <= 96 ? 1 : 2);
+    if (tpw == 2) return a.frag_b ? launch_tri_gemm_small_t<8, true, 2>(a, st) : launch_tri_gemm_small_t<8, false, 2>(a, st);
+    return a.frag_b ? launch_tri_gemm_small_t<16, true, 1>(a, st) : launch_tri_gemm_small_t<16, false, 1>(a, st);
   }
   if (a.frag_b) return fail(CF_ERR_INVALID, "internal: fragment-ordered residuals handed to the throughput solve kernel");
-  static const int shape = [] {
-    const char* e = getenv("CF_GEMM_SHAPE");
-    return (e && strlen(e) == 3 && e[1] == 'x') ? (e[0] - '0') * 16 + (e[2] - '0') : 0;
-  }();
-  int np = a.W > CF_NP2_FROM ? 2 : 1, pf = 2;  // measured: NP = 1 wins up to 512 walkers (48 vs 53 us), NP = 2 beyond (528-576 walkers 64 vs 67-69 us, 768: 71.7 vs 77.1; profiles/r03_gemm_stamps_and_pairing.txt), 10 % at 4096
-  if (shape) { np = shape / 16; pf = shape % 16; }
-  switch (np * 16 + pf) {
-    case 1 * 16 + 2: return launch_tri_gemm_t<1, 2>(a, st);
-    case 1 * 16 + 4: return launch_tri_gemm_t<1, 4>(a, st);
-    case 2 * 16 + 2: return launch_tri_gemm_t<2, 2>(a, st);
-    case 2 * 16 + 3: return launch_tri_gemm_t<2, 3>(a, st);
-    case 2 * 16 + 4: return launch_tri_gemm_t<2, 4>(a, st);
-    case 4 * 16 + 2: return launch_tri_gemm_t<4, 2>(a, st);
-  }
-  return fail(CF_ERR_INVALID, "bad CF_GEMM_SHAPE");
+  return tri_gemm_panel_width(a.W) == 32 ? launch_tri_gemm_t<2, 2>(a, st) : launch_tri_gemm_t<1, 2>(a, st);
 }
 
-// walkers per panel of the throughput solve kernel launch_tri_gemm picks for W walkers (0: an override this file does not model)
-static int tri_gemm_panel_width(int64_t W) {
-  static const bool overridden = getenv("CF_GEMM_SHAPE") != nullptr;
-  return overridden ? 0 : (W > CF_NP2_FROM ? 32 : 16);
-}
-
-// One sub-batch [off, off + Wc) of an evaluation on stream `st`: per-walker kernel (distance table, residuals; the
-// small-blocks kernel of a joint likelihood), then the solve + chi^2 + epilogue (or the bare epilogue for likelihoods
-// without an SN block).  `off` is a multiple of 32, so every per-walker buffer is addressed by plain offsets and a
-// walker's result does not depend on the chunking.  ev: 3 timing events or null; ev_walker_done: recorded after the
-// per-walker kernels (the next chunk's walker kernel waits for it: chunks enter the chip one after the other).
-static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_t Wc, double* d_out, int out_kind, hipStream_t st,
-                        double* dm_out, double* mucorr_out, double* blocks_out, double* bao_out, double* chi2_sn_out,
-                        hipEvent_t* ev, hipEvent_t ev_walker_done, double* fs8_block_out = nullptr, double* fs8_theory_out = nullptr) {
+// One evaluation of W walkers on stream `st`: per-walker kernel (distance table, residuals; the small-blocks / growth kernels of a
+// joint likelihood), then the solve + chi^2 + epilogue (or the bare epilogue for likelihoods without an SN block).
+// ev: 4 timing events or null.
+static int launch_eval(cf_handle* h, const double* th, int64_t Wc, double* out, int out_kind, hipStream_t st,
+                       double* dm_out, double* mucorr_out, double* blocks_out, double* bao_out, double* chi2_sn_out,
+                       hipEvent_t* ev, double* fs8_block_out = nullptr, double* fs8_theory_out = nullptr) {
   const cf_dev_desc& d = h->d;
   unsigned long long* nf = h->nonfinite.as<unsigned long long>();
-  const double* th = d_theta + off * d.ndim;
-  double* out = d_out + off;
-  double* delta = h->delta.as<double>() ? h->delta.as<double>() + off * d.n_ld : nullptr;
-  d2* bao_nodes = h->bao_nodes.as<d2>() ? h->bao_nodes.as<d2>() + off * d.n_aux * CF_BAO_NODES : nullptr;
+  double* delta = h->delta.as<double>();
+  d2* bao_nodes = h->bao_nodes.as<d2>();
   if (ev) HIP_TRY(hipEventRecord(ev[0], st));
   if (ev && !(h->d.n_sn > 0 || h->has_small_blocks || h->has_growth)) HIP_TRY(hipEventRecord(ev[1], st));
   const bool walker_work = d.n_sn > 0 || h->has_small_blocks || h->has_growth;
-  double* extra = (h->has_small_blocks || h->has_growth) ? h->chi2_extra.as<double>() + off : nullptr;
+  double* extra = (h->has_small_blocks || h->has_growth) ? h->chi2_extra.as<double>() : nullptr;
   // a small batch of the production path: walker_fast_kernel writes the residuals in the fragment order the small-batch solve
   // kernel loads them in (one contiguous 1 KiB load per K-step pair instead of a 16-row gather: sn_fast_loop, FRAG)
-  static const bool frag_env = [] { const char* e = getenv("CF_SMALL_FRAG"); return !e || atoi(e) != 0; }();
-  const bool small_solve = d.n_sn > 0 && h->solve_mode == CF_SOLVE_INVERSE_GEMM && !ev_walker_done && h->partial4.p && Wc <= small_batch_max();
+  static const bool frag_env = cf_tune("small_frag", 1) != 0;
+  const bool small_solve = d.n_sn > 0 && h->solve_mode == CF_SOLVE_INVERSE_GEMM && h->partial4.p && Wc <= small_batch_max();
   const bool frag_b = frag_env && small_solve && !dm_out && !mucorr_out && walker_fast_ok(d);
   if (walker_work) {
     // skewed {cum, dh} table: one spare 16-byte slot per 2^chunk_shift nodes
@@ -1351,10 +1295,10 @@ static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_
       // a zero-copy evaluation reads theta from the pinned host block: the walker kernel leaves a copy of each row in device
       // memory and every later kernel of the evaluation (small blocks, growth, the solve's prior / output epilogue) reads THAT --
       // the epilogue's dependent theta reads were microseconds each across the host link
-      double* th_copy = h->theta_on_host ? h->theta.as<double>() + off * d.ndim : nullptr;
+      double* th_copy = h->theta_on_host ? h->theta.as<double>() : nullptr;
       // a small batch leaves most of the chip idle: several workgroups per walker, each with the walker's table and a share of
-      // its SNe (CF_SN_PARTS=1|2|4 overrides)
-      static const int parts_env = [] { const char* e = getenv("CF_SN_PARTS"); return e ? atoi(e) : 0; }();
+      // its SNe (CF_TUNE sn_parts=1|2|4 overrides)
+      static const int parts_env = (int)cf_tune("sn_parts", 0);
       int sn_parts = parts_env > 0 ? parts_env : (Wc <= 64 ? 4 : (Wc <= 160 ? 2 : 1));  // measured: W = 16 26.5 -> 25.3 us, W = 64 31.5 -> 30.1 us per call
       if (sn_parts > CF_SN_PARTS_MAX || d.n_sn == 0) sn_parts = 1;
       hipLaunchKernelGGL(pick_walker_fast(d.ez_model, d.fde), dim3((unsigned)(Wc * sn_parts)), dim3(512), lds, st, walker_args_of(d), th,
@@ -1369,11 +1313,11 @@ static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_
       // chip is not full and the time is the serial chain of a lane: a whole wave per walker then (4 instead of 13 Gauss-Legendre
       // nodes per lane).  Measured on the w0waCDM joint likelihood: 16 walkers 50.7 -> 45.1 us per call, 256: 77 -> 67, 2048: 193 ->
       // 185, 4096: 329 -> 334 (profiles/r03_small_blocks_lanes_ab.txt).  The sums do not depend on the width (VirtualLaneSum): a
-      // walker's result is the same bits either way.  CF_SB_WIDE_MAX=<walkers> moves the switch.
-      static const int64_t wide_max = [] { const char* e = getenv("CF_SB_WIDE_MAX"); return e ? atoll(e) : 2048ll; }();
+      // walker's result is the same bits either way.  CF_TUNE sb_wide_max=<walkers> moves the switch.
+      static const int64_t wide_max = cf_tune("sb_wide_max", 2048);
       // ... and TWO waves per walker: the BAO / cosmic-chronometer blocks beside the powers and the CMB integrals (small_blocks_kernel,
-      // ROLES): 16 walkers 44.6 -> 37.9 us per call, 256: 67 -> 60, 2048: 184 -> 182.  CF_SB_ROLES_MAX=<walkers> (0 = never) moves the switch.
-      static const int64_t roles_max = [] { const char* e = getenv("CF_SB_ROLES_MAX"); return e ? atoll(e) : 2048ll; }();
+      // ROLES): 16 walkers 44.6 -> 37.9 us per call, 256: 67 -> 60, 2048: 184 -> 182.  CF_TUNE sb_roles_max=<walkers> (0 = never).
+      static const int64_t roles_max = cf_tune("sb_roles_max", 2048);
       const int lanes = Wc <= wide_max ? 64 : 16, roles = (lanes == 64 && Wc <= roles_max) ? 2 : 1, per_wg = 256 / (lanes * roles);
       hipLaunchKernelGGL(pick_small_blocks(d.ez_model, d.fde, lanes, roles), dim3((unsigned)((Wc + per_wg - 1) / per_wg)), dim3(256), 0, st, d, th, Wc,
                          (const d2*)bao_nodes, extra, blocks_out, bao_out);
@@ -1383,36 +1327,34 @@ static int launch_chunk(cf_handle* h, const double* d_theta, int64_t off, int64_
                          (size_t)(2 * (d.fs8_steps + 1) + 16 + CF_MAX_FS8 + 2 + 256) * 8, st, d, th, Wc, (const d2*)bao_nodes, extra,
                          h->has_small_blocks ? 1 : 0, fs8_block_out, fs8_theory_out);
   }
-  if (ev_walker_done) HIP_TRY(hipEventRecord(ev_walker_done, st));
   if (ev) HIP_TRY(hipEventRecord(ev[2], st));
   if (d.n_sn > 0 && h->solve_mode == CF_SOLVE_INVERSE_GEMM) {
-    TriGemmArgs a{&d, &h->ipack.dev, th, Wc, delta, h->max_walkers, h->partial.as<double>() + off,
-                        h->arrivals.as<unsigned int>() + off / 16, extra, out, out_kind, nf, chi2_sn_out,
-                        ev_walker_done ? nullptr : h->partial4.as<double>(),  // sub-batches run side by side: one partial4
-                        nullptr, 0ull, frag_b};
+    TriGemmArgs a{h->epi.as<const cf_epilogue>(), h->ipack.dev.frags, d.n_ld, d.ndim, h->ipack.dev.n_rowblocks, h->cu_count, th, Wc, delta,
+                  h->max_walkers, h->partial.as<double>(), h->arrivals.as<unsigned int>(), h->queue.as<unsigned int>(), extra, out,
+                  out_kind, nf, chi2_sn_out, h->partial4.as<double>(), nullptr, 0ull, frag_b};
     // a synchronous zero-copy call: the solve kernel's last arrivers set one word per panel in pinned host memory and the host
     // waits for those instead of the end of the kernel (launch_tri_gemm's own choice of kernel and panel width decides how many)
-    if (h->theta_on_host && !ev_walker_done && off == 0 && h->done_flags.p) {
+    if (h->theta_on_host && h->done_flags.p) {
       a.done_flag = (unsigned long long*)h->done_flags.p;
       a.done_seq = h->done_seq;
       const bool small = Wc <= small_batch_max() && a.partial4;
       const int pw = small ? 16 : tri_gemm_panel_width(Wc);
-      h->done_armed = pw > 0 ? (int)((Wc + pw - 1) / pw) : 0;
-      if (h->done_armed == 0 || h->done_armed > CF_DONE_FLAGS) { a.done_flag = nullptr; h->done_armed = 0; }
+      h->done_armed = (int)((Wc + pw - 1) / pw);
+      if (h->done_armed > CF_DONE_FLAGS) { a.done_flag = nullptr; h->done_armed = 0; }
     }
     int rc = launch_tri_gemm(a, st);
     if (rc) return rc;
   } else if (d.n_sn > 0) {
-    int rc = launch_trsm(d, h->pack.dev, th, Wc, delta, h->ypk.as<d2>() + (off / 16) * (int64_t)(d.n_pad / 8) * 64, extra, out, out_kind,
-                         nf, st, chi2_sn_out);
+    int rc = launch_trsm(h->epi.as<const cf_epilogue>(), d.n_pad, d.n_ld, d.ndim, h->pack.dev, th, Wc, delta, h->ypk.as<d2>(), extra, out,
+                         out_kind, nf, st, chi2_sn_out);
     if (rc) return rc;
   } else {
     unsigned long long* fin_flag = nullptr;
-    if (h->theta_on_host && !ev_walker_done && off == 0 && h->done_flags.p && (Wc + 255) / 256 <= CF_DONE_FLAGS) {
+    if (h->theta_on_host && h->done_flags.p && (Wc + 255) / 256 <= CF_DONE_FLAGS) {
       fin_flag = (unsigned long long*)h->done_flags.p;
       h->done_armed = (int)((Wc + 255) / 256);
     }
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((Wc + 255) / 256)), dim3(256), 0, st, d, th, Wc, (const double*)extra, out,
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((Wc + 255) / 256)), dim3(256), 0, st, h->epi_host, th, Wc, (const double*)extra, out,
                        out_kind, nf, fin_flag, h->done_seq);
   }
   if (ev) HIP_TRY(hipEventRecord(ev[3], st));
@@ -1435,52 +1377,18 @@ static int order_behind_last(cf_handle* h, hipStream_t st) {
   return 0;
 }
 
-// Launch one evaluation of W walkers, ordered on `st`.  Large batches of an SN likelihood run as sub-batches on two
-// streams (h->chunk_first / chunk_rest walkers; chunk c on `st` for even c, on h->aux for odd c), the per-walker kernel
-// of chunk c + 1 beside the solve of chunk c; everything is joined back into `st` before this returns.
+// Launch one evaluation of W walkers, ordered on `st` (and behind the handle's previous evaluation, whatever stream that ran on).
 static int launch_path(cf_handle* h, const double* d_theta, int64_t W, double* d_out, int out_kind, hipStream_t st,
                        double* dm_out, double* mucorr_out, double* blocks_out, double* bao_out,
                        double* chi2_sn_out = nullptr, double* fs8_block_out = nullptr, double* fs8_theory_out = nullptr) {
   { int rc0 = order_behind_last(h, st); if (rc0) return rc0; }
-  const bool parts = dm_out || mucorr_out || blocks_out || bao_out || chi2_sn_out;
-  int64_t offs[CF_MAX_CHUNKS + 1];
-  int n_chunks = 1;
-  offs[0] = 0;
-  if (!parts && h->d.n_sn > 0 && h->chunk_first > 0 && W > h->chunk_first) {
-    n_chunks = 0;
-    int64_t o = 0, size = h->chunk_first;
-    while (o < W && n_chunks < CF_MAX_CHUNKS - 1) {
-      offs[n_chunks++] = o;
-      o += size;
-      size = h->chunk_rest;
-    }
-    if (o < W) offs[n_chunks++] = o;  // the last chunk takes what is left
-  }
-  offs[n_chunks] = W;
   const bool timed = h->timing_slots && (h->eval_calls++ % h->timing_stride) == 0;
   const int slot = timed ? (int)(h->timed_calls % h->timing_slots) : 0;
-  hipEvent_t* ev = timed ? &h->ev[4 * slot * h->ev_per_slot] : nullptr;
-  if (n_chunks == 1) {
-    int rc = launch_chunk(h, d_theta, 0, W, d_out, out_kind, st, dm_out, mucorr_out, blocks_out, bao_out, chi2_sn_out, ev, nullptr,
-                          fs8_block_out, fs8_theory_out);
-    if (rc) return rc;
-  } else {
-    HIP_TRY(hipEventRecord(h->ev_fork, st));
-    HIP_TRY(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
-    for (int c = 0; c < n_chunks; ++c) {
-      hipStream_t sc = (c & 1) ? h->aux : st;
-      if (c > 0) HIP_TRY(hipStreamWaitEvent(sc, h->ev_walker[(c - 1) & 1], 0));  // walker kernels one after the other
-      int rc = launch_chunk(h, d_theta, offs[c], offs[c + 1] - offs[c], d_out, out_kind, sc, nullptr, nullptr, nullptr, nullptr,
-                            nullptr, ev ? ev + 4 * c : nullptr, h->ev_walker[c & 1]);
-      if (rc) return rc;
-    }
-    HIP_TRY(hipEventRecord(h->ev_join, h->aux));
-    HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
-  }
-  if (ev) {
-    h->ev_chunks[slot] = n_chunks;
-    h->timed_calls++;
-  }
+  hipEvent_t* ev = timed ? &h->ev[4 * slot] : nullptr;
+  int rc = launch_eval(h, d_theta, W, d_out, out_kind, st, dm_out, mucorr_out, blocks_out, bao_out, chi2_sn_out, ev, fs8_block_out,
+                       fs8_theory_out);
+  if (rc) return rc;
+  if (ev) h->timed_calls++;
   h->last_stream = st;
   h->has_last = true;
   HIP_TRY(hipGetLastError());
@@ -1901,19 +1809,16 @@ extern "C" int cf_solve_triangular(const double* L, int64_t n, int64_t ld, const
   int rc;
   if ((rc = pf.upload(hp))) return rc;
   const int64_t w_pad = (nrhs + 15) / 16 * 16, n_pad = hp.n_pad, n_ld = (n + 63) / 64 * 64;
-  DevBuf db, delta, ypk, dout, nf, dth;
+  DevBuf db, delta, ypk, dout, nf, dth, epi0;
   if (db.ensure((size_t)nrhs * n * 8) || delta.ensure((size_t)w_pad * n_ld * 8) || ypk.ensure((size_t)w_pad * n_pad * 8 + CF_YPK_SLACK) ||
-      dout.ensure((size_t)w_pad * 8) || nf.ensure(8) || dth.ensure(8))
+      dout.ensure((size_t)w_pad * 8) || nf.ensure(8) || dth.ensure(8) || epi0.ensure(sizeof(cf_epilogue)))
     return CF_ERR_HIP;
+  HIP_TRY(hipMemset(epi0.p, 0, sizeof(cf_epilogue)));  // no prior, no Gaussian terms: out_kind chi^2 returns y . y
   HIP_TRY(hipMemcpy(db.p, b, (size_t)nrhs * n * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(nf.p, 0, 8));
   hipLaunchKernelGGL(pad_rhs_kernel, dim3((unsigned)w_pad), dim3(256), 0, 0, db.as<const double>(), nrhs, n, n_ld,
                      delta.as<double>());
-  cf_dev_desc d{};
-  d.n_sn = (int32_t)n;
-  d.n_pad = (int32_t)n_pad;
-  d.n_ld = (int32_t)n_ld;
-  if ((rc = launch_trsm(d, pf.dev, dth.as<const double>(), nrhs, delta.as<const double>(), ypk.as<d2>(), nullptr,
+  if ((rc = launch_trsm(epi0.as<const cf_epilogue>(), (int)n_pad, (int)n_ld, 0, pf.dev, dth.as<const double>(), nrhs, delta.as<const double>(), ypk.as<d2>(), nullptr,
                         dout.as<double>(), (int)CF_OUT_CHI2, nf.as<unsigned long long>(), (hipStream_t)0, nullptr)))
     return rc;
   HIP_TRY(hipGetLastError());

@@ -156,6 +156,25 @@ struct cf_walker_args {
   const int32_t* bao_base;
 };
 
+// What the prior / output epilogue (finalize_value: sn/pantheon.py:80-97) reads, and nothing else: 0.7 KB.  The solve kernels take
+// a POINTER to the handle's device copy (cf_handle::epi): with the 1.9 KB cf_dev_desc by value they carried 44-46 SGPR spills,
+// because the epilogue of the one last-arriving workgroup kept the whole descriptor live in scalar registers in all of them.
+// Every workgroup fetches one 8-byte word per lane of it beside its hand-off; the last arriver parks them in LDS.
+struct cf_epilogue {
+  int32_t ndim, has_bounds, n_gauss, n_chi2_gauss;
+  int32_t cpl_wall, n_fs8, n_cc, cc_f_inverse;
+  double log_norm, logl_const, cc_logdet;
+  cf_dev_slot w0, wa, fs8err, fcc;  // the four parameter slots the epilogue consults (CPL wall, growth and chronometer error scales)
+  double lo[CF_MAX_NDIM], hi[CF_MAX_NDIM];
+  int32_t gauss_idx[CF_MAX_GAUSS];
+  double gauss_mean[CF_MAX_GAUSS], gauss_sigma[CF_MAX_GAUSS];
+  int32_t chi2_gauss_idx[CF_MAX_GAUSS];
+  double chi2_gauss_mean[CF_MAX_GAUSS], chi2_gauss_sigma[CF_MAX_GAUSS];
+};
+#define CF_EPI_WORDS ((int)((sizeof(cf_epilogue) + 7) / 8))
+// Throughput solve kernel: panels per launch (each workgroup keeps the list of panels it arrived last for in LDS: 4 bytes each)
+#define CF_MY_PANELS 1024
+
 #ifdef __HIPCC__
 typedef double cf_d2 __attribute__((ext_vector_type(2)));
 #else

@@ -107,17 +107,6 @@ __device__ __forceinline__ WalkerCosmo make_cosmo(const D& d, const TH& th) {
 // MODEL / FDE are compile-time: one kernel instantiation per expansion-rate family keeps the hot
 // loops free of the other families' code (the all-in-one kernel was 14 k instructions, well past
 // the instruction cache, and ran its table build 3x slower than its VALU work).
-#ifdef CF_TRSM_STAMPS
-__device__ unsigned long long cf_walker_stamps[8 * 8 * 8];  // [sampled workgroup][wave][phase]
-extern "C" int cf_debug_walker_stamps(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cf_walker_stamps), sizeof(cf_walker_stamps));
-}
-#define CF_WSTAMP(k)                                                                     \
-  if ((blockIdx.x & 511) == 300 && (threadIdx.x & 63) == 0)                               \
-  cf_walker_stamps[((blockIdx.x >> 9) * 8 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime()
-#else
-#define CF_WSTAMP(k)
-#endif
 
 // exp(x) for the dark-energy density of the table build: |x| < ~40 (x = 3 (1 + w0 + wa) ln(1 + z) - 3 wa z / (1 + z) inside any
 // prior box a sampler would draw from), so none of the library routine's overflow / underflow / NaN handling, and a
@@ -127,9 +116,6 @@ extern "C" int cf_debug_walker_stamps(unsigned long long* out) {
 // <= 1.5 ulp; 17 instructions where the library's exp takes ~60 -- the table build of the CPL model was 90 instructions per
 // grid node against 19 for LambdaCDM (profiles/r03_cpl_exp_ab.txt).
 __device__ __forceinline__ double exp_tab(double x, const double* __restrict__ tab) {
-#ifdef CF_LIB_EXP  // A/B build: the library's exp in the table build (round 2)
-  return exp(x);
-#endif
   const double n = __builtin_rint(x * 0x1.71547652b82fep+6);  // 64 / ln 2
   double r = fma(-n, 0x1.62e42fefa39efp-7, x);
   r = fma(-n, 0x1.abc9e3b39803fp-62, r);
@@ -480,14 +466,12 @@ __device__ __forceinline__ void build_distance_table_regs(const D& d, const Walk
   const int wave_last = (tid - lane) * CH + 64 * CH - 1;  // last node of this wave
   const double run = wave_last < G - 1 ? chunk_eval<MODEL, FDE, CH, false>(d, wc, c_over_H0, g0, lane, nu_pre, ln_pre, etab, dh, loc)
                                        : chunk_eval<MODEL, FDE, CH, true>(d, wc, c_over_H0, g0, lane, nu_pre, ln_pre, etab, dh, loc);
-  CF_WSTAMP(2);
   const double incl = wave_inclusive_scan(run);
   // per wave: {sum of its intervals, dh of its first node, dh of its last node}
   const double first_dh = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(dh[0])),
                                            __builtin_amdgcn_readfirstlane(__double2loint(dh[0])));
   if (lane == 63) wave_pub[wave] = (d4){incl, first_dh, dh[CH - 1], 0.0};
   __syncthreads();
-  CF_WSTAMP(3);
   // exclusive prefix inside the wave + the earlier waves' sums + the wave-boundary intervals up to this wave:
   // lane v < 8 forms wave v's contribution, a DPP row reduction adds the eight, lane 7 broadcasts the sum
   double term = 0.0;
@@ -712,8 +696,6 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
   if (w >= W) return;
   const double* th = theta + w * d.ndim;
   const int tid = threadIdx.x;
-
-  CF_WSTAMP(0);
   if (tid < 64 && d.n_sn > 0) log_tab[tid] = reinterpret_cast<const d2*>(d.log10_tab)[tid];
   // tabulated massive-neutrino density of this thread's 8 grid nodes (register path of the table build): fetched
   // before anything else so that the loads fly while theta is read and the cosmology scalars are formed
@@ -738,10 +720,7 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
   T.inv_step = d.inv_step;
   T.inv_last = d.inv_last;
   T.z_max = d.z_max;
-
-  CF_WSTAMP(1);
   if (d.n_sn > 0 || d.n_aux > 0 || table_out) build_distance_table<MODEL, FDE>(d, wc, lds_tab, wave_pub, nu_pre, ln_pre, exp2_tab);
-  CF_WSTAMP(4);
   if (table_out)  // accessor path (cf_eval_table): the walker's whole {cum_dm, dh} table, node order
     for (int g = tid; g < d.n_grid; g += CF_TPB_A) table_out[w * d.n_grid + g] = T.at(g);
   // the table nodes around each BAO redshift go to small_blocks_kernel (the BAO block is evaluated there, one wave
@@ -801,7 +780,6 @@ walker_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, double
       }
     }
   }
-  CF_WSTAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -826,7 +804,6 @@ walker_fast_kernel(cf_walker_args d, const double* __restrict__ theta, int64_t W
   if (w >= W) return;
   const int tid = threadIdx.x, lane = tid & 63;
   double* const exp2_tab = exp2_all[tid >> 6];
-  CF_WSTAMP(0);
   // loads in the order their values are needed: the theta row (the cosmology scalars wait for nothing else), the two small
   // reduction tables, then the theta-independent node tables of the table build
   const ThetaRow th{theta[w * d.ndim + (lane < d.ndim ? lane : 0)]};
@@ -856,9 +833,7 @@ walker_fast_kernel(cf_walker_args d, const double* __restrict__ theta, int64_t W
   T.inv_step = d.inv_step;
   T.inv_last = d.inv_last;
   T.z_max = d.z_max;
-  CF_WSTAMP(1);
   build_distance_table_regs<MODEL, FDE, 8>(d, wc, lds_tab, wave_pub, nu_pre, ln_pre, exp2_tab);
-  CF_WSTAMP(4);
   for (int e = CF_TPB_A - 1 - tid; part == 0 && e < CF_BAO_NODES * d.n_aux; e += CF_TPB_A) {
     const int k = e / CF_BAO_NODES, o = e % CF_BAO_NODES;
     bao_nodes[(w * d.n_aux + k) * CF_BAO_NODES + o] = T.at(d.bao_base[k] + o);
@@ -874,7 +849,6 @@ walker_fast_kernel(cf_walker_args d, const double* __restrict__ theta, int64_t W
     else if (d.step_pm1) sn_fast_loop<true, false, true>(d, T, log_tab, out, off, v100, tid, 0.0, part, sn_parts);
     else sn_fast_loop<false, false, true>(d, T, log_tab, out, off, v100, tid, 0.0, part, sn_parts);
   }
-  CF_WSTAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -954,14 +928,6 @@ __device__ __forceinline__ double group_quadratic_form(const double* __restrict_
   return acc.total(iters);
 }
 
-#ifdef CF_TRSM_STAMPS
-__device__ unsigned long long cf_sb_stamps[16];  // workgroup 0, thread 0: s_memtime per phase of small_blocks_kernel
-extern "C" int cf_debug_sb_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cf_sb_stamps), sizeof(cf_sb_stamps)); }
-#define CF_BSTAMP(k) \
-  if (blockIdx.x == 0 && threadIdx.x == 0) cf_sb_stamps[k] = __builtin_amdgcn_s_memtime()
-#else
-#define CF_BSTAMP(k)
-#endif
 // ROLES = 2 (only with a wave per walker, LANES = 64: batches that leave the chip mostly idle): TWO waves per walker.  Wave A runs the
 // z* / r_drag powers, then the compressed-CMB integrals; wave B the cosmic chronometers and the BAO numerators (table look-ups, the
 // cube root), which need nothing from A but the final division by r_d.  Two workgroup barriers: after the first B reads r_d from LDS
@@ -984,7 +950,6 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
   const int64_t w_raw = (int64_t)blockIdx.x * WALKERS_PER_WG + grp;
   const bool live = w_raw < W;
   const int64_t w = live ? w_raw : W - 1;  // spare groups of the last workgroup shadow the last walker and write nothing
-  CF_BSTAMP(0);
   // the walker's theta row across the lanes of its group: ONE load that waits for nothing (read slot by slot through the pointer,
   // each slot was a load behind the scalar load of its index)
   const ThetaGroup<LANES> th{theta[w * d.ndim + (sl < d.ndim ? sl : 0)]};
@@ -992,7 +957,6 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
   const double Ob = slot_get(d, CF_P_OBH2_D, th), Oc = slot_get(d, CF_P_OCH2_D, th);
   double* dl = delta_s[grp];
   if (Ob == 1.2345e300) dl[0] = wc.H0;  // (stamps: keeps the loads in front of the stamp)
-  CF_BSTAMP(1);
   // dl is written and read by the lanes of one group: a workgroup barrier when a wave holds several groups' neighbours, the wave's
   // own LDS order when the group IS the wave (SPLIT: the other role's waves are not at this point of the program)
   auto group_sync = [&]() {
@@ -1009,7 +973,6 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
     const double base1 = (sl & 1) ? ((sl & 2) ? wm_r : wm_z) : Ob;
     const double exp1 = sl == 0 ? fz[2] : sl == 1 ? fz[3] : sl == 2 ? fr[0] : fr[1];
     const double p1 = sl < 4 ? pow(base1, exp1) : 0.0;
-    CF_BSTAMP(2);
     const double wbz = __shfl(p1, 0, CF_SB_LANES), wmz = __shfl(p1, 1, CF_SB_LANES), wbr = __shfl(p1, 2, CF_SB_LANES),
                  wmr = __shfl(p1, 3, CF_SB_LANES);
     // round 2: lanes 0-4 the z* powers, 5-9 the r_drag powers
@@ -1036,7 +999,6 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
     // cmb/data_planck_act_compression.py:121-124
     const double den = (fr[2] * q[5]) + (fr[4] * q[6] * q[7]) + (fr[7] * q[8]);
     r_d = 1.0 / den - fr[9] / q[9];
-    CF_BSTAMP(3);
   };
 
   double c_cmb = 0.0, vec[3] = {0.0, 0.0, 0.0};
@@ -1053,7 +1015,6 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
       s_rs.push(gw * (d.c / (a * a * H_of_z<MODEL, FDE>(d, wc, z) * sqrt(3.0 * (1.0 + Rb)))));
       s_dm.push(gw * (d.c / H_of_z<MODEL, FDE>(d, wc, half_z * d.gl_x[k] + half_z)));
     }
-    CF_BSTAMP(4);
     const double i_rs = s_rs.total(gl_iters), i_dm = s_dm.total(gl_iters);
     const double rs_star = half_a * i_rs;
     const double DM_star = half_z * i_dm;
@@ -1117,7 +1078,6 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
     if (d.cmb_mode || d.rd_from_fit) pow_block();
     if (!d.rd_from_fit) r_d = slot_get(d, CF_P_RD_D, th);
     if (d.cmb_mode) cmb_block();
-    CF_BSTAMP(5);
     if (d.n_cc > 0) cc_block();
     if (d.n_bao > 0) {
       for (int k = sl; k < d.n_bao; k += CF_SB_LANES) {
@@ -1125,11 +1085,9 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
         bao_num(k, z, DM, DH);
         bao_fin(k, z, DM, DH);
       }
-      CF_BSTAMP(6);
       group_sync();
       c_bao = group_quadratic_form<LANES>(dl, d.bao_inv_cov, d.n_bao, sl);
     }
-    CF_BSTAMP(7);
   } else {
     double bz = 0.0, bDM = 0.0, bDH = 0.0;
     const bool has_datum = sl < d.n_bao;  // CF_MAX_BAO <= LANES: one datum per lane
@@ -1143,7 +1101,6 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
     __syncthreads();  // r_d is in LDS; B's numerators are in its registers
     if (do_a) {
       if (d.cmb_mode) cmb_block();
-      CF_BSTAMP(5);
     } else {
       r_d = xch[grp][0];
       if (d.n_bao > 0) {
@@ -1161,7 +1118,6 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
       c_bao = xch[grp][1];
       c_cc = xch[grp][2];
     }
-    CF_BSTAMP(7);
   }
   if (sl == 0 && live && do_a) {
     chi2_extra[w] = c_cmb + c_bao + c_cc;
@@ -1475,7 +1431,10 @@ CF_INSTANTIATE_WALKER(1, 0) CF_INSTANTIATE_WALKER(1, 1) CF_INSTANTIATE_WALKER(1,
 // ------------------------------------------------------------------------------------------------
 // Prior / output epilogue shared by every likelihood form.   sn/pantheon.py:80-97
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double finalize_value(const cf_dev_desc& d, const double* __restrict__ th, double chi2, int out_kind,
+__device__ __forceinline__ double epi_slot(const cf_dev_slot& sl, const double* __restrict__ th) {
+  return sl.idx >= 0 ? th[sl.idx] * sl.scale : sl.fixed;
+}
+__device__ __forceinline__ double finalize_value(const cf_epilogue& d, const double* __restrict__ th, double chi2, int out_kind,
                                                  unsigned long long* nonfinite) {
   for (int g = 0; g < d.n_chi2_gauss; ++g) {
     double diff = th[d.chi2_gauss_idx[g]] - d.chi2_gauss_mean[g];
@@ -1485,13 +1444,15 @@ __device__ __forceinline__ double finalize_value(const cf_dev_desc& d, const dou
   double lp = 0.0;
   if (out_kind == CF_OUT_LOGP_D) {
     if (d.has_bounds) {
-      // all ndim (<= 16) theta reads issued together, no short-circuit: with `&&` every parameter was a dependent load + branch
-      // in the last arriver of the solve, the one workgroup the evaluation's latency waits for
+      // four parameters' reads issued together, no short-circuit: with `&&` every parameter was a dependent load + branch in the
+      // last arriver of the solve, the one workgroup the evaluation's latency waits for (all 16 at once cost 96 VGPRs)
       bool inbox = true;
+      for (int k0 = 0; k0 < d.ndim; k0 += 4) {
 #pragma unroll
-      for (int k = 0; k < CF_MAX_NDIM; ++k) {
-        const double t = th[k < d.ndim ? k : 0];
-        inbox = inbox & ((k >= d.ndim) | ((d.lo[k] < t) & (t < d.hi[k])));
+        for (int k = k0; k < k0 + 4; ++k) {
+          const double t = th[k < d.ndim ? k : 0];
+          inbox = inbox & ((k >= d.ndim) | ((d.lo[k & (CF_MAX_NDIM - 1)] < t) & (t < d.hi[k & (CF_MAX_NDIM - 1)])));
+        }
       }
       if (!inbox) return -INFINITY;  // the likelihood is not consulted outside the box, sn/pantheon.py:90-92
       lp = d.log_norm;
@@ -1502,17 +1463,17 @@ __device__ __forceinline__ double finalize_value(const cf_dev_desc& d, const dou
     }
   }
   // hard wall of the CPL scripts, part of log L itself: bao/desi_fs_lya_cmb.py:118-121
-  if (d.cpl_wall && slot_get(d, CF_P_W0_D, th) + slot_get(d, CF_P_WA_D, th) >= 0.0) return lp + -1e8;
+  if (d.cpl_wall && epi_slot(d.w0, th) + epi_slot(d.wa, th) >= 0.0) return lp + -1e8;
   if (!isfinite(chi2)) {  // emcee aborts on NaN: map to -inf and count it
     atomicAdd(nonfinite, 1ull);
     return -INFINITY;
   }
   double ll = -0.5 * chi2 + d.logl_const;
   if (d.n_fs8 > 0)  // -0.5 (chi2 - 2 N ln f_err), fs8/fs8.py:123-125 (f_err fixed to 1 where a script has none)
-    ll += d.n_fs8 * log(slot_get(d, CF_P_FS8ERR_D, th));
+    ll += d.n_fs8 * log(epi_slot(d.fs8err, th));
   if (d.n_cc > 0)  // Gaussian normalisation with rescaled errors, bao/desi_union3_cc_theta_star.py:135-139
     ll -= 0.5 * (d.n_cc * 1.8378770664093453 + d.cc_logdet +
-                 (d.cc_f_inverse ? 2 : -2) * d.n_cc * log(slot_get(d, CF_P_FCC_D, th)));  // ohd/cc_pantheon.py:92
+                 (d.cc_f_inverse ? 2 : -2) * d.n_cc * log(epi_slot(d.fcc, th)));  // ohd/cc_pantheon.py:92
   return lp + ll;
 }
 
@@ -1584,22 +1545,11 @@ __device__ __forceinline__ void update_loop(d4 (&acc)[NTU], const d2* __restrict
   }
 }
 
-#ifdef CF_TRSM_STAMPS
-// Debug build only (tools/trsm_stamps.py): s_memtime at the phase boundaries of workgroup 0, [wave][block row][5].
-__device__ unsigned long long cf_trsm_stamps[16 * 16 * 5];
-extern "C" int cf_debug_trsm_stamps(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cf_trsm_stamps), sizeof(cf_trsm_stamps));
-}
-#define CF_STAMP(k)                                                                   \
-  if (blockIdx.x == 0 && lane == 0 && b < 16) cf_trsm_stamps[(wave * 16 + b) * 5 + (k)] = __builtin_amdgcn_s_memtime()
-#else
-#define CF_STAMP(k)
-#endif
 
 template <int KS, int TC>
 __global__ void __launch_bounds__(64 * KS * TC)
-trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* __restrict__ theta, int64_t W,
-                 const double* __restrict__ delta, d2* __restrict__ ypk, const double* __restrict__ chi2_extra,
+trsm_chi2_kernel(const cf_epilogue* __restrict__ epi, int n_pad, int n_ld, int ndim, cf_dev_pack pk, const double* __restrict__ theta,
+                 int64_t W, const double* __restrict__ delta, d2* __restrict__ ypk, const double* __restrict__ chi2_extra,
                  double* __restrict__ out, int out_kind, unsigned long long* nonfinite, double* __restrict__ chi2_sn_out) {
   constexpr int NW = TC * KS;                  // waves per workgroup
   constexpr int NTU = CF_BLOCK_TILES / TC;     // tiles per wave in the update phase
@@ -1614,17 +1564,15 @@ trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* __restrict__ theta
   const int col = lane & 15, kq = lane >> 4;
   const int64_t panel = blockIdx.x;
   const int64_t w0 = panel * 16;
-  const int n_pad = d.n_pad;
   const int T = n_pad / 16;
   d2* Yp = ypk + panel * (int64_t)(n_pad / 8) * 64;
-  const double* dcol = delta + (w0 + col) * (int64_t)d.n_ld;
+  const double* dcol = delta + (w0 + col) * (int64_t)n_ld;
   double chi = 0.0;
 
   for (int b = 0; b < pk.n_blocks; ++b) {
     const int tiles_b = min(CF_BLOCK_TILES, T - b * CF_BLOCK_TILES);
     const int nt = tiles_b > wq ? (tiles_b - wq + TC - 1) / TC : 0;
     const int r0 = b * CF_BLOCK_ROWS;
-    CF_STAMP(0);
     // diagonal-phase stream of this wave: start its first loads now, they land during the update
     int ml[NTD], ml_max = -1;
 #pragma unroll
@@ -1669,7 +1617,6 @@ trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* __restrict__ theta
         else update_loop<1, PF, NTU>(acc, A, Yg, n_s2, lane);
       }
     }
-    CF_STAMP(1);
     // ---- publish this wave's partial right-hand side as B fragments in LDS ----
 #pragma unroll
     for (int j = 0; j < NTU; ++j)
@@ -1679,7 +1626,6 @@ trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* __restrict__ theta
         ldsP[g * PANEL_FRAGS + (2 * t + 1) * 64 + lane] = (d2){acc[j][2], acc[j][3]};
       }
     __syncthreads();
-    CF_STAMP(2);
     // ---- diagonal block through its inverse: y = inv(L_bb) * rhs (lower triangular) ----
     if (ml_max >= 0) {
       // two accumulation chains per tile (even / odd K-steps): the dependent-MFMA latency, not the
@@ -1726,9 +1672,7 @@ trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* __restrict__ theta
           Yp[(int64_t)(2 * mt + 1) * 64 + lane] = (d2){y[j][2], y[j][3]};
         }
     }
-    CF_STAMP(3);
     __syncthreads();  // Y of this block visible to the whole workgroup; ldsP reusable
-    CF_STAMP(4);
   }
 
   // ---- chi^2 per walker column: over the 4 row groups of a wave, then over the NW waves ----
@@ -1743,40 +1687,35 @@ trsm_chi2_kernel(cf_dev_desc d, cf_dev_pack pk, const double* __restrict__ theta
     for (int k = 0; k < NW; ++k) c2 += chi_part[k][tid];
     if (chi2_sn_out) chi2_sn_out[w] = c2;  // the SN block alone (cf_eval_parts)
     if (chi2_extra) c2 += chi2_extra[w];
-    out[w] = finalize_value(d, theta + w * d.ndim, c2, out_kind, nonfinite);
+    out[w] = finalize_value(*epi, theta + w * ndim, c2, out_kind, nonfinite);  // scalar loads from the handle's device copy
   }
 }
 
-#define CF_INSTANTIATE_TRSM(KS, TC)                                                                                  \
-  template __global__ void trsm_chi2_kernel<KS, TC>(cf_dev_desc, cf_dev_pack, const double*, int64_t, const double*, \
-                                                    d2*, const double*, double*, int, unsigned long long*, double*);
-CF_INSTANTIATE_TRSM(1, 4)
-CF_INSTANTIATE_TRSM(2, 4)
-CF_INSTANTIATE_TRSM(4, 4)
-CF_INSTANTIATE_TRSM(2, 8)
+#define CF_INSTANTIATE_TRSM(KS, TC)                                                                                          \
+  template __global__ void trsm_chi2_kernel<KS, TC>(const cf_epilogue*, int, int, int, cf_dev_pack, const double*, int64_t, \
+                                                    const double*, d2*, const double*, double*, int, unsigned long long*, double*);
+CF_INSTANTIATE_TRSM(2, 4)  // the shipped shape: 8 waves, two per SIMD
 
 // ------------------------------------------------------------------------------------------------
 // Inverse-GEMM solve: Y = X Delta with X = L^-1 inverted once on the host (cf_pack.h), a triangular
-// GEMM with no dependency between row blocks.  One 256-thread workgroup per (64-row block rb,
-// panel of 16*NP walkers): the four waves split the K range [0, 64 (rb+1)), each keeps the 4 x NP
-// accumulator tiles of the block in registers (an A fragment feeds NP MFMAs), the quarters meet in
-// LDS, and the workgroup writes its share of chi^2 to partial[rb][walker].  Row blocks are issued
-// largest first (blockIdx.y = 0 is the last block), every panel of one block at the same time, so
-// that each XCD's L2 reads a factor stream once.  NP = 1 is the latency variant for small batches:
-// a single walker already spreads over ~27 CUs (the blocked solve keeps a panel on one CU).
-// The workgroup that arrives last for a panel adds the partials in a fixed order and applies the prior /
-// output epilogue -> one launch, and results do not depend on timing.  B fragments are 16-byte loads straight from the row-major residual rows (cf_inv_col).
+// GEMM with no dependency between row blocks.  The UNIT of work is one (64-row block rb, panel of 16*NP walkers): the
+// four waves of a 256-thread workgroup split the K range [0, 64 (rb+1)), each keeps the 4 x NP accumulator tiles of the
+// block in registers (an A fragment feeds NP MFMAs), the quarters meet in LDS, and the unit's share of chi^2 goes to
+// partial[rb][walker].  The workgroup that arrives last for a panel adds the shares in a fixed order and applies the prior /
+// output epilogue -> one launch, and results do not depend on timing.  B fragments are 16-byte loads straight from the
+// row-major residual rows.
+//
+// SCHEDULING (round 4): a PERSISTENT grid.  The launch holds at most `wgs per CU` x CUs workgroups; workgroup b starts with unit b
+// and then pulls further units from ONE agent-scope counter (`queue`), in the order unit 0, 1, 2, ...: panel group (its residual
+// rows stay in the Infinity Cache while the group's row blocks pass) > row block, LARGEST FIRST > panel inside the group
+// (consecutive units = different XCDs on the same factor stream).  Longest-first from a shared queue is what balances the CUs:
+// the round-3 kernel mapped blockIdx -> unit statically, and a grid that is resident all at once (<= 1024 workgroups: up to
+// 1024 walkers) put workgroups i, i + 256, ... on one CU whatever their lengths -- 36 to 60 units of work per CU around a mean
+// of 47 at 512-1024 walkers (0.57 of the FP64 matrix peak at 1024 walkers against 0.81 at 4096, where the hardware dispatcher
+// refills CUs as workgroups retire).  The pull rides on the hand-off's own round trip to memory (wave 0 issues the arrival add and
+// the queue add together), so a unit costs no extra latency; the per-unit arithmetic and the ordered last-arriver sum are
+// unchanged, hence the same bits as before for every batch size.  The workgroup that leaves last re-arms the two counters.
 // ------------------------------------------------------------------------------------------------
-#ifdef CF_TRSM_STAMPS
-__device__ unsigned long long cf_gemm_stamps[64 * 4 * 4];  // [rb][wave][start, loop start, loop end, end] of panel 5
-extern "C" int cf_debug_gemm_stamps(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cf_gemm_stamps), sizeof(cf_gemm_stamps));
-}
-#define CF_GSTAMP(k) \
-  if (px == 5 && lane == 0 && rb < 64) cf_gemm_stamps[(rb * 4 + g) * 4 + (k)] = __builtin_amdgcn_s_memtime()
-#else
-#define CF_GSTAMP(k)
-#endif
 
 // Workgroup barrier for LDS traffic only (no wait on global loads that have nothing to do with the exchange).  Neither this nor
 // s_barrier itself orders a wave's global STORES: a hand-off to another agent needs the storing wave's own s_waitcnt vmcnt(0).
@@ -1785,8 +1724,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // The last arriver's read-back of a panel's shares: `n` doubles at `src` (written by other workgroups with agent-scope
 // write-through stores) into LDS.  Every thread first ISSUES its (up to eight) agent-scope loads, then stores them: written as
 // one load + one LDS store per loop iteration, each iteration waited for its own round trip to memory (~1.2 us; the loads
-// bypass this XCD's L2) -- seven serialised round trips, 9 of the small-batch kernel's 20 us (truncated builds under
-// rocprofv3: profiles/r03_small_batch_solve.txt).
+// bypass this XCD's L2) -- seven serialised round trips, 9 of the small-batch kernel's 20 us (profiles/r03_small_batch_solve.txt).
 // n <= 4096: two straight-line stages of eight loads, not a loop -- at a loop head hipcc waits for every load in flight (vmcnt(0)).
 __device__ __forceinline__ void fetch_shares_stage(const double* src, int n, double* __restrict__ sh, int tid, int base) {
   double v[8];
@@ -1820,193 +1758,55 @@ __device__ __forceinline__ double tile_chi2_share(const d4& p0, const d4& p1, co
 // a row block's share from its four tiles' shares, in tile order
 __device__ __forceinline__ double rowblock_share(double t0, double t1, double t2, double t3) { return ((t0 + t1) + t2) + t3; }
 
-template <int NP, int PF>
-__global__ void __launch_bounds__(256)
-tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict__ theta, int64_t W,
-                     const double* __restrict__ delta, int64_t w_pad, double* partial, unsigned int* arrivals,
-                     const double* __restrict__ chi2_extra, double* __restrict__ out, int out_kind,
-                     unsigned long long* nonfinite, double* __restrict__ chi2_sn_out, int panels_per_group,
-                     unsigned long long* done_flag, unsigned long long done_seq, int snake) {
-  __shared__ __align__(16) d4 part[4][4][64];  // [wave][tile][lane] of one 16-walker panel: 32 KB
-  __shared__ double chi_tile[4][16 * NP];
-  __shared__ unsigned int arrived_before;
-  const int n_ld = d.n_ld;
-  const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
-  const int col = lane & 15, kq = lane >> 4;
-  // 1-D grid, issued in this order: panel group (its residual rows stay in the XCDs' L2s while the group's row
-  // blocks pass) > row block, largest first > panel inside the group (consecutive ids = different XCDs, all on the
-  // same factor stream)
-  const int per_group = panels_per_group * pk.n_rowblocks;
-  const int grp = (int)blockIdx.x / per_group;
-  int rem_id = (int)blockIdx.x % per_group;
-  // `snake`: a grid that is resident all at once (<= 1024 workgroups) is placed statically, workgroups i, i + 256, i + 512, ... on the
-  // same CU: in plain descending order some CUs then hold 60 row-block units and others 36 (512 walkers).  Alternate blocks of 256
-  // workgroups run ascending instead: 256 walkers 46.4 -> 43.0 us per call, 512: 58.9 -> 55.5, 1024: 94.5 -> 87.3; a grid that
-  // arrives in waves (4096 walkers) is better off descending (254 against 257.5 us).  profiles/r03_gemm_stamps_and_pairing.txt
-  if (snake) {
-    const int b = rem_id >> 8, len = (per_group - (b << 8)) < 256 ? per_group - (b << 8) : 256;
-    if (b & 1) rem_id = (b << 8) + (len - 1 - (rem_id & 255));
-  }
-  // largest row blocks first (alternating large / small, or mixing the first 1024-workgroup wave, measured no better: 0.744 /
-  // 0.776 of peak against 0.778; profiles/r02_dispatch_order_ab.txt)
-  const int rb = pk.n_rowblocks - 1 - rem_id / panels_per_group;
+// The last arriver's epilogue when a panel's shares do not fit the LDS copy (more than ~109 row blocks: N > 6976): a loop of
+// dependent agent-scope loads and the epilogue's fields as scalar loads from the handle's device copy.  Out of line: nothing of
+// it may cost the production path a register.
+__device__ __attribute__((noinline)) void panel_epilogue_from_memory(const cf_epilogue* epi, const double* theta, int ndim, const double* partial,
+                                                                      int64_t w_pad, int n_rb, int64_t w, const double* chi2_extra, double* out,
+                                                                      int out_kind, unsigned long long* nonfinite, double* chi2_sn_out) {
+  double c2 = 0.0;
+  for (int r = 0; r < n_rb; ++r) c2 += __hip_atomic_load(&partial[(int64_t)r * w_pad + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (chi2_sn_out) chi2_sn_out[w] = c2;
+  if (chi2_extra) c2 += chi2_extra[w];
+  out[w] = finalize_value(*epi, theta + w * ndim, c2, out_kind, nonfinite);
+}
 
-  const int px = grp * panels_per_group + rem_id % panels_per_group;
-  const int64_t w0 = (int64_t)px * (16 * NP);
-  if (w0 >= W) return;  // the last group may be partly empty
-  const int nq = 2 * (rb + 1);  // K-step pairs per wave
-  CF_GSTAMP(0);
-  const d2* A = pk.frags + pk.off[rb * 4 + g] * 64 + lane;
-  // B fragments: 16 bytes per lane from the walker's residual row; panel c is 16 rows (8 n_ld d2) further on
-#ifdef CF_DEBUG_FRAG_B  // TIMING EXPERIMENT (wrong results): the residual loads as contiguous 1 KiB fragments (the small-batch kernel's FRAG order)
-#define CF_BQ 64
-  const d2* Bq = reinterpret_cast<const d2*>(delta) + ((w0 / 16) * (int64_t)(n_ld / 8) + (int64_t)g * nq) * 64 + lane;
-#else
-#define CF_BQ 4
-  const d2* Bq = reinterpret_cast<const d2*>(delta) + ((w0 + col) * (int64_t)n_ld + 8 * (int64_t)g * nq + 2 * kq) / 2;
-#endif
-  const int64_t bstride = 8 * (int64_t)n_ld;
-#ifdef CF_DEBUG_ALIAS_A  // TIMING EXPERIMENT (wrong results): every factor load hits the same 16 KiB
-#define CF_A_ADV 0
-  A = pk.frags + (g * 16) * 64 + lane;
-#else
-#define CF_A_ADV 1
-#endif
-#ifdef CF_DEBUG_ALIAS_B  // TIMING EXPERIMENT (wrong results): every residual load hits the first K-steps of the panel
-#define CF_B_ADV 0
-#else
-#define CF_B_ADV 1
-#endif
-  d4 acc[NP][4];
-#pragma unroll
-  for (int c = 0; c < NP; ++c)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[c][j] = (d4){0.0, 0.0, 0.0, 0.0};
-  // PF-deep software pipeline over the nq K-step pairs.  Nothing is loaded past the wave's K range (but for row
-  // block 0, covered by the buffers' slack): a load that nobody consumes still has to land before the wave may
-  // retire, and it misses every cache.
-  d2 a[PF][4], bf[PF][NP];
-  auto load_stage = [&](int p) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) a[p][j] = A[(p * 4 + j) * 64];
-#pragma unroll
-    for (int c = 0; c < NP; ++c) bf[p][c] = Bq[c * bstride + p * CF_BQ];
-  };
-  auto mfma_stage = [&](int p) {
-#pragma unroll
-    for (int c = 0; c < NP; ++c)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[c][j] = mfma_f64(a[p][j].x, bf[p][c].x, acc[c][j]);
-#pragma unroll
-    for (int c = 0; c < NP; ++c)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[c][j] = mfma_f64(a[p][j].y, bf[p][c].y, acc[c][j]);
-  };
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int p = 0; p < PF; ++p) {
-    load_stage(p);  // unconditional (a guard costs hipcc its exact vmcnt bookkeeping); only row block 0 has nq < PF
-    __builtin_amdgcn_sched_barrier(0);  // stage 0 must be the oldest load
-  }
-  A += CF_A_ADV * PF * 4 * 64;
-  Bq += CF_B_ADV * PF * CF_BQ;
-  const int n_groups = nq / PF, rem = nq - n_groups * PF;
-  CF_GSTAMP(1);
-  for (int grp = 0; grp + 1 < n_groups; ++grp) {  // branch-free body: a guard around the MFMAs makes hipcc drain vmcnt(0) per stage
-#pragma unroll
-    for (int p = 0; p < PF; ++p) {
-      mfma_stage(p);
-      __builtin_amdgcn_sched_barrier(0);
-      load_stage(p);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    A += CF_A_ADV * PF * 4 * 64;
-    Bq += CF_B_ADV * PF * CF_BQ;
-  }
-  if (n_groups > 0) {  // last full group: only the nq % PF pairs of the tail are still to be fetched
-#pragma unroll
-    for (int p = 0; p < PF; ++p) {
-      mfma_stage(p);
-      __builtin_amdgcn_sched_barrier(0);
-      if (p < rem) load_stage(p);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-#pragma unroll
-  for (int p = 0; p < PF - 1; ++p)
-    if (p < rem) mfma_stage(p);
-  CF_GSTAMP(2);
-  // the four K quarters meet in LDS, one 16-walker panel at a time; wave g owns tile g: y, then the column sums of y^2
-#pragma unroll
-  for (int c = 0; c < NP; ++c) {
-    if (c > 0) lds_barrier();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) part[g][j][lane] = acc[c][j];
-    lds_barrier();
-    const double v = tile_chi2_share(part[0][g][lane], part[1][g][lane], part[2][g][lane], part[3][g][lane]);
-    if (lane < 16) chi_tile[g][c * 16 + lane] = v;
-  }
-  lds_barrier();
-  // Hand-off between workgroups on different XCDs (their L2s are not coherent), in the form MI355X_MICROARCH.md lists as
-  // valid for gfx950 (Workgroup dispatch, XCD placement & inter-workgroup visibility: "Valid forms", first table row):
-  // producer -- wave 0 stores the workgroup's shares with agent-scope (sc1, write-through) stores, drains them with
-  // s_waitcnt vmcnt(0) (inline asm with a memory clobber: the compiler may not move the stores or the add across it),
-  // then ONE lane bumps the panel's arrival counter with an agent-scope atomic add.  Consumer -- the workgroup whose
-  // add returned n_rowblocks - 1 came last: behind the workgroup barrier its lanes issue an agent-scope ACQUIRE fence
-  // and read every share back with agent-scope (sc1) loads, add the row blocks in a fixed order (the result does not
-  // depend on which workgroup it was) and re-arm the counter for the next launch.
-  // The add is RELAXED unless CF_HANDOFF_RELEASE is defined: an agent-scope release lowers to buffer_wbl2 (write back
-  // this XCD's L2) + vmcnt(0) in EVERY workgroup; with write-through stores there is nothing for it to write back, and
-  // 3456 of them per launch were measured to cost 15 % of the kernel (profiles/r02_handoff_ab.txt).
-#ifdef CF_HANDOFF_RELEASE
-#define CF_ARRIVE_ORDER __ATOMIC_RELEASE
-#else
-#define CF_ARRIVE_ORDER __ATOMIC_RELAXED
-#endif
-  if (g == 0) {
-    if (lane < 16 * NP)
-      __hip_atomic_store(&partial[(int64_t)rb * w_pad + w0 + lane],
-                         rowblock_share(chi_tile[0][lane], chi_tile[1][lane], chi_tile[2][lane], chi_tile[3][lane]), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of every lane of this wave have reached memory
-    if (lane == 0)
-      arrived_before = __hip_atomic_fetch_add(&arrivals[px], 1u, CF_ARRIVE_ORDER, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  CF_GSTAMP(3);
-  lds_barrier();
-  if (arrived_before != (unsigned)pk.n_rowblocks - 1u) return;
+// The workgroup that arrived last for panel `px`: the panel's shares summed in row-block order, the prior / output epilogue, the
+// completion word.  `sh`: 4096 doubles of LDS (the K-quarter exchange buffer, free at this point).  The persistent kernel runs it
+// BEHIND its unit loop (see there): inside the loop its temporaries cost the K loop its register budget -- 236 VGPRs and 129 SGPR
+// spills against 127 / 0, i.e. two workgroups per CU instead of four; as a real call, 146 VGPRs.
+template <int NP>
+__device__ __forceinline__ void panel_last_arriver(double* sh, const cf_epilogue* __restrict__ epi, int ndim, int n_rb,
+                                                             const double* __restrict__ theta, int64_t W, int64_t w_pad, double* partial,
+                                                             unsigned int* arrivals, const double* __restrict__ chi2_extra,
+                                                             double* __restrict__ out, int out_kind, unsigned long long* nonfinite,
+                                                             double* __restrict__ chi2_sn_out, int px, unsigned long long* done_flag,
+                                                             unsigned long long done_seq) {
+  constexpr int PW = 16 * NP;
+  // an opaque copy of the thread index: everything below that depends only on it (share and theta addresses: ~100 VGPRs) would
+  // otherwise be hoisted out of the persistent kernel's unit loop as loop-invariant and stay live across the K loop
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int64_t w0 = (int64_t)px * PW;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   if (tid == 0) __hip_atomic_store(&arrivals[px], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // The shares come back through LDS: 256 threads fetch the (row block, walker) entries side by side, then thread w adds its
-  // walker's shares in row-block order -- the same additions as a loop of dependent loads, without its n_rowblocks round
+  // walker's shares in row-block order -- the same additions as a loop of dependent loads, without its n_rb round
   // trips to memory (27 x ~0.7 us: two thirds of a one-panel solve; profiles/r02_epilogue_loads_ab.txt).  With them come one
-  // load per lane of the descriptor (from the kernel-argument segment: `d` is the first argument) and the panel's theta rows,
-  // parked in LDS for finalize_value: as scalar loads from the argument segment and dependent vector loads, one basic block each,
-  // the prior / output stage was 5 k cycles of the last arriver (tri_gemm_small_kernel, profiles/r03_small_batch_solve.txt).
-  // Straight-line code: at a loop head hipcc drains every load in flight.
-  constexpr int PW = 16 * NP;
-  constexpr int DW = (int)((sizeof(cf_dev_desc) + 7) / 8);
-  static_assert(DW <= 256, "one descriptor word per thread");
-  double* sh = reinterpret_cast<double*>(part);  // 4096 doubles; the K-quarter exchange is over
-  const int n_rb = pk.n_rowblocks, n_sh = n_rb * PW, n_th = PW * d.ndim;
-#ifdef CF_EPILOGUE_SERIAL  // A/B build: the loop of dependent loads
-  const bool via_lds = false;
-#else
-  const bool via_lds = n_sh + DW + PW * CF_MAX_NDIM <= 4096;  // shares, descriptor words, theta rows
-#endif
-  if (via_lds) {
-    unsigned long long* desc_lds = reinterpret_cast<unsigned long long*>(sh + n_sh);
-    double* th_lds = sh + n_sh + DW;
-    const unsigned long long __attribute__((address_space(4)))* ka =
-        (const unsigned long long __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+  // load per lane of the epilogue's fields (the handle's device copy) and the panel's theta rows, parked in LDS for
+  // finalize_value.  Straight-line code: at a loop head hipcc drains every load in flight.
+  const int n_sh = n_rb * PW, n_th = PW * ndim;
+  if (n_sh + CF_EPI_WORDS + PW * CF_MAX_NDIM <= 4096) {  // shares, epilogue words, theta rows
+    unsigned long long* epi_lds = reinterpret_cast<unsigned long long*>(sh + n_sh);
+    double* th_lds = sh + n_sh + CF_EPI_WORDS;
     unsigned long long dv = 0ull;
     double tv[NP];
-    if (tid < DW) dv = ka[tid];
+    if (tid < CF_EPI_WORDS) dv = reinterpret_cast<const unsigned long long*>(epi)[tid];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {  // PW * CF_MAX_NDIM = 256 NP entries at most
       const int idx = k * 256 + tid;
-      const int64_t ti = w0 * d.ndim + idx;
-      tv[k] = (idx < n_th && ti < W * d.ndim) ? theta[ti] : 0.0;
+      const int64_t ti = w0 * ndim + idx;
+      tv[k] = (idx < n_th && ti < W * ndim) ? theta[ti] : 0.0;
     }
     auto stage = [&](int base) {
       double v[8];
@@ -2023,36 +1823,30 @@ tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict_
     };
     stage(0);
     if (n_sh > 8 * 256) stage(8 * 256);
-    if (tid < DW) desc_lds[tid] = dv;
+    if (tid < CF_EPI_WORDS) epi_lds[tid] = dv;
 #pragma unroll
     for (int k = 0; k < NP; ++k)
       if (k * 256 + tid < n_th) th_lds[k * 256 + tid] = tv[k];
     lds_barrier();
     if (tid < PW && w0 + tid < W) {
-      const cf_dev_desc& dl = *reinterpret_cast<const cf_dev_desc*>(desc_lds);
+      const cf_epilogue& el = *reinterpret_cast<const cf_epilogue*>(epi_lds);
       const int64_t w = w0 + tid;
       const double extra = chi2_extra ? chi2_extra[w] : 0.0;
       double c2 = 0.0;
-      for (int r0 = 0; r0 < n_rb; r0 += 32) {  // in row-block order, 32 LDS reads in flight
-        double v[32];
+      for (int r0 = 0; r0 < n_rb; r0 += 16) {  // in row-block order, 16 LDS reads in flight
+        double v[16];
 #pragma unroll
-        for (int k = 0; k < 32; ++k) v[k] = sh[(r0 + k < n_rb ? r0 + k : n_rb - 1) * PW + tid];
+        for (int k = 0; k < 16; ++k) v[k] = sh[(r0 + k < n_rb ? r0 + k : n_rb - 1) * PW + tid];
 #pragma unroll
-        for (int k = 0; k < 32; ++k)
+        for (int k = 0; k < 16; ++k)
           if (r0 + k < n_rb) c2 += v[k];
       }
       if (chi2_sn_out) chi2_sn_out[w] = c2;  // the SN block alone (cf_eval_parts)
       if (chi2_extra) c2 += extra;
-      out[w] = finalize_value(dl, th_lds + tid * dl.ndim, c2, out_kind, nonfinite);
+      out[w] = finalize_value(el, th_lds + tid * ndim, c2, out_kind, nonfinite);
     }
   } else if (tid < PW && w0 + tid < W) {
-    const int64_t w = w0 + tid;
-    double c2 = 0.0;
-    for (int r = 0; r < n_rb; ++r)
-      c2 += __hip_atomic_load(&partial[(int64_t)r * w_pad + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (chi2_sn_out) chi2_sn_out[w] = c2;
-    if (chi2_extra) c2 += chi2_extra[w];
-    out[w] = finalize_value(d, theta + w * d.ndim, c2, out_kind, nonfinite);
+    panel_epilogue_from_memory(epi, theta, ndim, partial, w_pad, n_rb, w0 + tid, chi2_extra, out, out_kind, nonfinite, chi2_sn_out);
   }
   // the panel's completion word for a synchronous zero-copy host call (see tri_gemm_small_kernel): PW <= 32 lanes of wave 0 stored
   if (done_flag && tid < 64) {
@@ -2061,16 +1855,204 @@ tri_gemm_chi2_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict_
   }
 }
 
-#define CF_INSTANTIATE_TRIGEMM(NP, PF)                                                                                   \
-  template __global__ void tri_gemm_chi2_kernel<NP, PF>(cf_dev_desc, cf_dev_invpack, const double*, int64_t, const double*, \
-                                                        int64_t, double*, unsigned int*, const double*, double*, int,   \
-                                                        unsigned long long*, double*, int, unsigned long long*, unsigned long long, int);
-CF_INSTANTIATE_TRIGEMM(1, 2)
-CF_INSTANTIATE_TRIGEMM(1, 4)
-CF_INSTANTIATE_TRIGEMM(2, 2)
-CF_INSTANTIATE_TRIGEMM(2, 3)
-CF_INSTANTIATE_TRIGEMM(2, 4)
-CF_INSTANTIATE_TRIGEMM(4, 2)
+#ifdef CF_DIAG_CLOCK
+// DIAGNOSTIC BUILD ONLY (tools/build_variant.sh clock -DCF_DIAG_CLOCK; tools/solve_clock.py): per workgroup the shader-clock and
+// real-time (100 MHz) counters at entry and exit, and the cycles its waves spent inside K loops -- the clock the chip holds under
+// this kernel is d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back (6)).  The stamps go to a buffer
+// of their own; no output value depends on them.
+__device__ unsigned long long cf_solve_clock[4096 * 4];  // [workgroup][memtime in, realtime in, memtime out, realtime out]
+extern "C" int cf_debug_solve_clock(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cf_solve_clock), sizeof(cf_solve_clock));
+}
+#define CF_CLOCK_STAMP(k)                                                                     \
+  if (tid == 0 && blockIdx.x < 4096) {                                                        \
+    cf_solve_clock[blockIdx.x * 4 + 2 * (k)] = __builtin_amdgcn_s_memtime();                  \
+    cf_solve_clock[blockIdx.x * 4 + 2 * (k) + 1] = __builtin_amdgcn_s_memrealtime();          \
+  }
+#else
+#define CF_CLOCK_STAMP(k)
+#endif
+
+// The add is RELAXED unless CF_HANDOFF_RELEASE is defined (tests/test_gpu_handoff.py compares the two builds bit for bit): an
+// agent-scope release lowers to buffer_wbl2 (write back this XCD's L2) + vmcnt(0) in EVERY workgroup; with write-through stores
+// there is nothing for it to write back, and 3456 of them per launch were measured to cost 20 % of the kernel
+// (profiles/r02_handoff_and_traffic_ab.txt).
+#ifdef CF_HANDOFF_RELEASE
+#define CF_ARRIVE_ORDER __ATOMIC_RELEASE
+#else
+#define CF_ARRIVE_ORDER __ATOMIC_RELAXED
+#endif
+
+template <int NP, int PF>
+__global__ void __launch_bounds__(256, 4)  // four workgroups per CU: 128 VGPRs
+tri_gemm_chi2_kernel(const cf_epilogue* __restrict__ epi, const d2* __restrict__ frags, int n_ld, int ndim, int n_rb,
+                     const double* __restrict__ theta, int64_t W, const double* __restrict__ delta, int64_t w_pad, double* partial,
+                     unsigned int* arrivals, const double* __restrict__ chi2_extra, double* __restrict__ out, int out_kind,
+                     unsigned long long* nonfinite, double* __restrict__ chi2_sn_out, int panels_per_group, unsigned int n_units,
+                     unsigned int* queue, unsigned long long* done_flag, unsigned long long done_seq) {
+  __shared__ __align__(16) d4 part[4][4][64];  // [wave][tile][lane] of one 16-walker panel: 32 KB
+  __shared__ double chi_tile[4][16 * NP];
+  __shared__ unsigned int arrived_before, next_unit;
+  __shared__ int my_panels[CF_MY_PANELS];
+  const int tid = threadIdx.x;
+  const int g = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave's K quarter, in a scalar register: its address arithmetic too
+  const int per_group = panels_per_group * n_rb;
+  const int64_t bstride = 8 * (int64_t)n_ld;
+  constexpr int PW = 16 * NP;
+  CF_CLOCK_STAMP(0);
+  // The panels this workgroup arrived last for are worked off BEHIND the unit loop, not inside it: inside, everything of the
+  // epilogue that does not change from unit to unit (per-lane share and theta addresses, the constants of its log) is hoisted in
+  // front of the loop and stays live across the K loop -- 158-236 VGPRs instead of 127, i.e. two or three workgroups per CU
+  // instead of four.  Units are pulled longest first, so a panel's last arrival is one of its shortest row blocks, at the tail
+  // of the queue: the epilogues wait microseconds.  The list holds every panel of the launch (the launcher cuts an evaluation into
+  // launches of at most CF_MY_PANELS panels), so it cannot overflow.
+  int n_mine = 0;
+  unsigned int unit = blockIdx.x;  // the grid never exceeds n_units
+  while (unit < n_units) {
+    const int grp = (int)unit / per_group, rem_id = (int)unit % per_group;
+    const int rb = n_rb - 1 - rem_id / panels_per_group;  // largest row blocks first
+    const int px = grp * panels_per_group + rem_id % panels_per_group;
+    const int w0 = px * PW;
+    if (w0 >= (int)W) {  // the last group may be partly empty: nothing to compute, only the next unit to fetch
+      if (tid == 0) next_unit = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + gridDim.x;
+      lds_barrier();
+      unit = next_unit;
+      lds_barrier();
+      continue;
+    }
+    const int nq = 2 * (rb + 1);  // K-step pairs per wave
+    // Lane-dependent addresses are formed from an OPAQUE copy of the lane index, per unit and again behind the K loop: left to
+    // itself the compiler hoists everything that depends only on the lane out of the unit loop, keeps it live across the K loop
+    // and spills it to scratch to stay within 128 VGPRs.
+    int lane = tid & 63;
+    asm volatile("" : "+v"(lane));
+    const int col = lane & 15, kq = lane >> 4;
+    // the stream of (row block, K quarter) in closed form (cf_inv_stream_off): no dependent load in front of the first fragment
+    const d2* A = frags + cf_inv_stream_off(rb, g) * 64 + lane;
+    // B fragments: 16 bytes per lane from the walker's residual row; panel c is 16 rows (8 n_ld d2) further on
+    const d2* Bq = reinterpret_cast<const d2*>(delta) + ((int64_t)(w0 + col) * n_ld + 8 * g * nq + 2 * kq) / 2;
+    d4 acc[NP][4];
+#pragma unroll
+    for (int c = 0; c < NP; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[c][j] = (d4){0.0, 0.0, 0.0, 0.0};
+    // PF-deep software pipeline over the nq K-step pairs.  Nothing is loaded past the wave's K range (but for row
+    // block 0, covered by the buffers' slack): a load that nobody consumes still has to land before the wave may
+    // go on, and it misses every cache.
+    d2 a[PF][4], bf[PF][NP];
+    auto load_stage = [&](int p) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[p][j] = A[(p * 4 + j) * 64];
+#pragma unroll
+      for (int c = 0; c < NP; ++c) bf[p][c] = Bq[c * bstride + p * 4];
+    };
+    auto mfma_stage = [&](int p) {
+#pragma unroll
+      for (int c = 0; c < NP; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[c][j] = mfma_f64(a[p][j].x, bf[p][c].x, acc[c][j]);
+#pragma unroll
+      for (int c = 0; c < NP; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[c][j] = mfma_f64(a[p][j].y, bf[p][c].y, acc[c][j]);
+    };
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      load_stage(p);  // unconditional (a guard costs hipcc its exact vmcnt bookkeeping); only row block 0 has nq < PF
+      __builtin_amdgcn_sched_barrier(0);  // stage 0 must be the oldest load
+    }
+    A += PF * 4 * 64;
+    Bq += PF * 4;
+    const int n_groups = nq / PF, rem = nq - n_groups * PF;
+    for (int kg = 0; kg + 1 < n_groups; ++kg) {  // branch-free body: a guard around the MFMAs makes hipcc drain vmcnt(0) per stage
+#pragma unroll
+      for (int p = 0; p < PF; ++p) {
+        mfma_stage(p);
+        __builtin_amdgcn_sched_barrier(0);
+        load_stage(p);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      A += PF * 4 * 64;
+      Bq += PF * 4;
+    }
+    if (n_groups > 0) {  // last full group: only the nq % PF pairs of the tail are still to be fetched
+#pragma unroll
+      for (int p = 0; p < PF; ++p) {
+        mfma_stage(p);
+        __builtin_amdgcn_sched_barrier(0);
+        if (p < rem) load_stage(p);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < PF - 1; ++p)
+      if (p < rem) mfma_stage(p);
+    // the four K quarters meet in LDS, one 16-walker panel at a time; wave g owns tile g: y, then the column sums of y^2
+    lane = tid & 63;
+    asm volatile("" : "+v"(lane));
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+      if (c > 0) lds_barrier();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) part[g][j][lane] = acc[c][j];
+      lds_barrier();
+      const double v = tile_chi2_share(part[0][g][lane], part[1][g][lane], part[2][g][lane], part[3][g][lane]);
+      if (lane < 16) chi_tile[g][c * 16 + lane] = v;
+    }
+    lds_barrier();
+    // Hand-off between workgroups on different XCDs (their L2s are not coherent), in the form MI355X_MICROARCH.md lists as
+    // valid for gfx950 (Workgroup dispatch, XCD placement & inter-workgroup visibility: "Valid forms", first table row):
+    // producer -- wave 0 stores the unit's shares with agent-scope (sc1, write-through) stores, drains them with
+    // s_waitcnt vmcnt(0) (inline asm with a memory clobber: the compiler may not move the stores or the add across it),
+    // then ONE lane bumps the panel's arrival counter with an agent-scope atomic add -- and, in the same round trip to memory,
+    // pulls the workgroup's next unit from the queue.  Consumer -- the workgroup whose add returned n_rb - 1 came last:
+    // behind the workgroup barrier its lanes issue an agent-scope ACQUIRE fence and read every share back with agent-scope
+    // (sc1) loads, add the row blocks in a fixed order (the result does not depend on which workgroup it was) and re-arm the
+    // counter for the next launch.
+    if (g == 0) {
+      if (lane < PW)
+        __hip_atomic_store(&partial[(int64_t)rb * w_pad + w0 + lane],
+                           rowblock_share(chi_tile[0][lane], chi_tile[1][lane], chi_tile[2][lane], chi_tile[3][lane]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of every lane of this wave have reached memory
+      if (lane == 0) {
+        const unsigned int ab = __hip_atomic_fetch_add(&arrivals[px], 1u, CF_ARRIVE_ORDER, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int nu = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        arrived_before = ab;
+        next_unit = nu + gridDim.x;
+      }
+    }
+    lds_barrier();
+    unit = next_unit;
+    if (arrived_before != (unsigned)n_rb - 1u) continue;  // (the next write of the two words lies behind the K-quarter barriers)
+    // this workgroup came last for panel px: the shares' sum in row-block order, the prior / output epilogue, the completion word
+    // ... all of which waits until this workgroup has left the unit loop: the panel goes on the workgroup's list
+    if (tid == 0) my_panels[n_mine] = px;
+    ++n_mine;
+  }
+  lds_barrier();
+  for (int i = 0; i < n_mine; ++i) {
+    panel_last_arriver<NP>(reinterpret_cast<double*>(part), epi, ndim, n_rb, theta, W, w_pad, partial, arrivals, chi2_extra, out, out_kind,
+                           nonfinite, chi2_sn_out, my_panels[i], done_flag, done_seq);
+    lds_barrier();  // the LDS copies are read: the next panel's may overwrite them
+  }
+  CF_CLOCK_STAMP(1);
+  // the workgroup that leaves last re-arms the queue for the next launch: every pull of this launch lies before some workgroup's
+  // add to queue[1]
+  if (tid == 0 && __hip_atomic_fetch_add(queue + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
+    __hip_atomic_store(queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(queue + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+#define CF_INSTANTIATE_TRIGEMM(NP, PF)                                                                                              \
+  template __global__ void tri_gemm_chi2_kernel<NP, PF>(const cf_epilogue*, const d2*, int, int, int, const double*, int64_t,       \
+                                                        const double*, int64_t, double*, unsigned int*, const double*, double*, int, \
+                                                        unsigned long long*, double*, int, unsigned int, unsigned int*,               \
+                                                        unsigned long long*, unsigned long long);
+CF_INSTANTIATE_TRIGEMM(1, 2)  // up to 512 walkers
+CF_INSTANTIATE_TRIGEMM(2, 2)  // beyond: an A fragment feeds two MFMAs
 
 // ------------------------------------------------------------------------------------------------
 // The same solve for SMALL batches (W <= a few panels of 16 walkers: emcee's 16-walker half-steps of BASELINE configs[0],
@@ -2088,34 +2070,10 @@ CF_INSTANTIATE_TRIGEMM(4, 2)
 // same XCD and share its factor fragments in that L2; units in descending row-block order (longest chains first); over a
 // sequence of small calls unit u stays on XCD u % 8, whose 4 MB L2 keeps its eighth of the 11.8 MB factor.
 // ------------------------------------------------------------------------------------------------
-#ifdef CF_TRSM_STAMPS
-__device__ unsigned long long cf_small_stamps[128 * 4 * 8];  // [unit][wave][phase] of panel 0; phase 6, 7: wall_clock64 at entry / exit
-extern "C" int cf_debug_small_stamps(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cf_small_stamps), sizeof(cf_small_stamps));
-}
-#define CF_SSTAMP(k) \
-  if (px == 0 && lane == 0 && unit < 128) cf_small_stamps[(unit * 4 + g) * 8 + (k)] = __builtin_amdgcn_s_memtime()
-#define CF_SWALL(k) \
-  if (px == 0 && lane == 0 && unit < 128) cf_small_stamps[(unit * 4 + g) * 8 + (k)] = wall_clock64()
-__device__ unsigned long long cf_small_epi[16];  // the last arriver of panel 0, wave 0: s_memtime per epilogue phase; [15] wall_clock64 at the end
-extern "C" int cf_debug_small_epi(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cf_small_epi), sizeof(cf_small_epi));
-}
-#define CF_ESTAMP(k) \
-  if (px == 0 && tid == 0) cf_small_epi[k] = __builtin_amdgcn_s_memtime()
-#define CF_EWALL(k) \
-  if (px == 0 && tid == 0) cf_small_epi[k] = wall_clock64()
-#else
-#define CF_SSTAMP(k)
-#define CF_SWALL(k)
-#define CF_ESTAMP(k)
-#define CF_EWALL(k)
-#endif
-
 template <int PF, bool FRAG, int TPW>
 __global__ void __launch_bounds__(256)
-tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict__ theta, int64_t W,
-                      const double* __restrict__ delta, double* partial4, unsigned int* arrivals,
+tri_gemm_small_kernel(const cf_epilogue* __restrict__ epi, const d2* __restrict__ frags, int n_ld, int ndim, int n_rb,
+                      const double* __restrict__ theta, int64_t W, const double* __restrict__ delta, double* partial4, unsigned int* arrivals,
                       const double* __restrict__ chi2_extra, double* __restrict__ out, int out_kind,
                       unsigned long long* nonfinite, double* __restrict__ chi2_sn_out, int units_pad,
                       unsigned long long* done_flag, unsigned long long done_seq) {
@@ -2127,11 +2085,10 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
   // many-panel batch fit four to a CU
   extern __shared__ double small_dyn[];
   double* const sh = small_dyn;
-  double* const rbs = small_dyn + 64 * pk.n_rowblocks;
-  __shared__ __align__(16) unsigned long long desc_lds[(sizeof(cf_dev_desc) + 7) / 8];  // the last arriver's copy of `d` (see below)
+  double* const rbs = small_dyn + 64 * n_rb;
+  __shared__ __align__(16) unsigned long long desc_lds[CF_EPI_WORDS];  // the last arriver's copy of the epilogue's fields (see below)
   __shared__ double th_lds[16 * CF_MAX_NDIM];                                           // ... and of the panel's theta rows
   __shared__ unsigned int arrived_before;
-  const int n_ld = d.n_ld, n_rb = pk.n_rowblocks;
   const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
   const int col = lane & 15, kq = lane >> 4;
   const int unit = (int)blockIdx.x % units_pad, px = (int)blockIdx.x / units_pad;
@@ -2143,14 +2100,9 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
   const int64_t w0 = (int64_t)px * 16;
   if (w0 >= W) return;
   const int nq = 2 * (rb + 1);  // K-step pairs per wave
-#if defined(CF_DBG_SMALL) && CF_DBG_SMALL == 1  // TIMING EXPERIMENTS (wrong results): 1 = empty kernel, 2 = no hand-off, 3 = no epilogue
-  return;
-#endif
-  CF_SSTAMP(0);
-  CF_SWALL(6);
   // K-step pair q of this wave's quarter: factor fragment of tile j (1 KiB, stride 4 KiB), residual fragment (16 B per lane)
   // (the stream offset in closed form, cf_inv_stream_off: one dependent load less in front of every wave's first fragment)
-  const d2* A = pk.frags + cf_inv_stream_off(rb, g) * 64 + j * 64 + lane;
+  const d2* A = frags + cf_inv_stream_off(rb, g) * 64 + j * 64 + lane;
   // FRAG: walker_fast_kernel left the panel's residuals in fragment order (delta_index): a K-step pair is 1 KiB in a row, like
   // the factor's -- the row form's 16 B per lane from 16 walker rows 8 n_ld bytes apart is sixteen cache lines per load, and those
   // gathers, not the matrix pipe (64 cycles per MFMA of a dependent chain, tools/mfma_chain_latency.hip) or the factor stream, set
@@ -2173,24 +2125,14 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
 #pragma unroll
     for (int t = 0; t < TPW; ++t) acc[t] = mfma_f64(a[p][t].y, bf[p].y, acc[t]);
   };
-#ifdef CF_SMALL_ALIAS_A  // TIMING EXPERIMENTS (wrong results): every factor / residual load of a wave hits its first PF pairs
-#define CF_SA_ADV 0
-#else
-#define CF_SA_ADV 1
-#endif
-#ifdef CF_SMALL_ALIAS_B
-#define CF_SB_ADV 0
-#else
-#define CF_SB_ADV 1
-#endif
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int p = 0; p < PF; ++p) {  // a short stream (nq < PF) re-reads its last pair: nothing outside the wave's range is touched
     load_pair(p, p < nq ? p : nq - 1);
     __builtin_amdgcn_sched_barrier(0);  // stage 0 must be the oldest load
   }
-  A += CF_SA_ADV * PF * 256;
-  Bq += CF_SB_ADV * PF * BS;
+  A += PF * 256;
+  Bq += PF * BS;
   const int n_groups = nq / PF, rem = nq - n_groups * PF;
   for (int grp = 0; grp + 1 < n_groups; ++grp) {  // branch-free body, as in the throughput kernel
 #pragma unroll
@@ -2200,8 +2142,8 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
       load_pair(p, p);
       __builtin_amdgcn_sched_barrier(0);
     }
-    A += CF_SA_ADV * PF * 256;
-    Bq += CF_SB_ADV * PF * BS;
+    A += PF * 256;
+    Bq += PF * BS;
   }
   if (n_groups > 0) {  // last full group: only the nq % PF pairs of the tail are still to be fetched
 #pragma unroll
@@ -2215,32 +2157,24 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
 #pragma unroll
   for (int p = 0; p < PF - 1; ++p)
     if (p < rem) mfma_pair(p);
-  CF_SSTAMP(1);
-  // The prior / output epilogue of the LAST ARRIVER reads a dozen fields of `d` and the walkers' theta rows: as scalar loads from the
-  // kernel-argument segment and dependent vector loads, each in its own basic block, they were 5 k cycles of the one workgroup the
-  // whole call waits for.  Instead every workgroup issues, HERE, one load per lane of the descriptor (from the kernel-argument
-  // segment: `d` is the first argument) and of the panel's theta rows -- they return behind the hand-off's own wait -- and the last
-  // arriver parks them in LDS, where finalize_value reads them.
-  constexpr int DW = (int)((sizeof(cf_dev_desc) + 7) / 8);
-  static_assert(DW <= 256, "one descriptor word per thread");
-  const int n_th = 16 * d.ndim;
+  // The prior / output epilogue of the LAST ARRIVER reads a dozen of the epilogue's fields and the walkers' theta rows: as scalar
+  // loads and dependent vector loads, each in its own basic block, they were 5 k cycles of the one workgroup the whole call waits
+  // for.  Instead every workgroup issues, HERE, one load per lane of the handle's device copy of the epilogue block and of the
+  // panel's theta rows -- they return behind the hand-off's own wait -- and the last arriver parks them in LDS, where
+  // finalize_value reads them.
+  constexpr int DW = CF_EPI_WORDS;
+  static_assert(DW <= 256, "one epilogue word per thread");
+  const int n_th = 16 * ndim;
   unsigned long long dv = 0ull;
   double tv = 0.0;
   {
-    const unsigned long long __attribute__((address_space(4)))* ka =
-        (const unsigned long long __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
-    const int64_t ti = w0 * d.ndim + tid;
-    if (tid < DW) dv = ka[tid];
-    if (tid < n_th && ti < W * d.ndim) tv = theta[ti];
+    const int64_t ti = w0 * ndim + tid;
+    if (tid < DW) dv = reinterpret_cast<const unsigned long long*>(epi)[tid];
+    if (tid < n_th && ti < W * ndim) tv = theta[ti];
   }
 #pragma unroll
   for (int t = 0; t < TPW; ++t) part[g][t][lane] = acc[t];
   lds_barrier();
-  CF_SSTAMP(2);
-#if defined(CF_DBG_SMALL) && CF_DBG_SMALL == 2
-  if (acc[0][0] == 1.2345e300) out[0] = acc[0][1];  // keeps the loop alive
-  return;
-#endif
   // hand-off as in the throughput kernel (agent-scope write-through stores, vmcnt(0), one relaxed agent-scope add, the last
   // arriver's acquire fence); one counter per panel counts the 4 n_rb (row block, tile) shares, TPW per workgroup
   double* mine = partial4 + (int64_t)px * (4 * n_rb * 16);
@@ -2264,25 +2198,17 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
       arrived_before = __hip_atomic_fetch_add(&arrivals[px], (unsigned)TPW, CF_ARRIVE_ORDER, __HIP_MEMORY_SCOPE_AGENT);
   }
   lds_barrier();
-  CF_SSTAMP(3);
-  CF_SWALL(7);
   if (arrived_before != 4u * (unsigned)n_rb - (unsigned)TPW) return;
-  CF_ESTAMP(0);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   if (tid == 0) __hip_atomic_store(&arrivals[px], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#if defined(CF_DBG_SMALL) && CF_DBG_SMALL == 3
-  return;
-#endif
-  CF_ESTAMP(1);
   const int n_sh = 4 * n_rb * 16;
   const bool via_lds = n_sh <= 4096;
   if (tid < DW) desc_lds[tid] = dv;  // the descriptor and theta copies fetched before the hand-off (see above)
   if (tid < n_th) th_lds[tid] = tv;
   if (via_lds) fetch_shares_to_lds(mine, n_sh, sh, tid);
-  const cf_dev_desc& dl = *reinterpret_cast<const cf_dev_desc*>(desc_lds);
+  const cf_epilogue& dl = *reinterpret_cast<const cf_epilogue*>(desc_lds);
   if (via_lds) {
     lds_barrier();
-    CF_ESTAMP(2);
     // the (row block, walker) shares from their four tile shares, 256 threads side by side; thread w then adds its walker's
     // n_rb row-block shares in order -- the throughput kernel's additions, one short dependent chain instead of 4 n_rb
     for (int i = tid; i < n_rb * 16; i += 256) {
@@ -2293,7 +2219,6 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
   }
   else
     lds_barrier();  // desc_lds, th_lds
-  CF_ESTAMP(3);
   if (tid < 16 && w0 + tid < W) {
     const int64_t w = w0 + tid;
     const double extra = chi2_extra ? chi2_extra[w] : 0.0;
@@ -2319,9 +2244,7 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
     }
     if (chi2_sn_out) chi2_sn_out[w] = c2;  // the SN block alone (cf_eval_parts)
     if (chi2_extra) c2 += extra;
-    CF_ESTAMP(4);
-    out[w] = finalize_value(dl, th_lds + tid * dl.ndim, c2, out_kind, nonfinite);
-    CF_ESTAMP(5);
+    out[w] = finalize_value(dl, th_lds + tid * ndim, c2, out_kind, nonfinite);
   }
   // A synchronous host call (zero-copy: `out` is the pinned staging block) does not wait for the END of this kernel -- its
   // teardown, the completion signal and the runtime's stream query are microseconds of a 40 us call -- but for this word in pinned
@@ -2329,34 +2252,24 @@ tri_gemm_small_kernel(cf_dev_desc d, cf_dev_invpack pk, const double* __restrict
   // release store of the call's sequence number.  Writes to the host travel in order.
   if (done_flag && tid < 64) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    CF_ESTAMP(6);
     if (tid == 0) __hip_atomic_store(&done_flag[px], done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  CF_ESTAMP(7);
-  CF_EWALL(15);
-  CF_SSTAMP(4);
 }
-#define CF_INSTANTIATE_TRIGEMM_SMALL(PF, FRAG, TPW)                                                                                     \
-  template __global__ void tri_gemm_small_kernel<PF, FRAG, TPW>(cf_dev_desc, cf_dev_invpack, const double*, int64_t, const double*, double*, \
-                                                                unsigned int*, const double*, double*, int, unsigned long long*, double*, int, \
-                                                                unsigned long long*, unsigned long long);
-CF_INSTANTIATE_TRIGEMM_SMALL(4, false, 1)
-CF_INSTANTIATE_TRIGEMM_SMALL(8, false, 1)
-CF_INSTANTIATE_TRIGEMM_SMALL(16, false, 1)
-CF_INSTANTIATE_TRIGEMM_SMALL(4, true, 1)
-CF_INSTANTIATE_TRIGEMM_SMALL(8, true, 1)
+#define CF_INSTANTIATE_TRIGEMM_SMALL(PF, FRAG, TPW)                                                                                       \
+  template __global__ void tri_gemm_small_kernel<PF, FRAG, TPW>(const cf_epilogue*, const d2*, int, int, int, const double*, int64_t,     \
+                                                                const double*, double*, unsigned int*, const double*, double*, int,       \
+                                                                unsigned long long*, double*, int, unsigned long long*, unsigned long long);
+// one tile per workgroup with a 16-deep prefetch (up to 96 walkers), two tiles with an 8-deep one (97-160 walkers); FRAG = the
+// per-walker kernel wrote the residuals in fragment order (the production path), row order for the accessor / generic paths
 CF_INSTANTIATE_TRIGEMM_SMALL(16, true, 1)
-CF_INSTANTIATE_TRIGEMM_SMALL(4, false, 2)
-CF_INSTANTIATE_TRIGEMM_SMALL(8, false, 2)
-CF_INSTANTIATE_TRIGEMM_SMALL(4, true, 2)
+CF_INSTANTIATE_TRIGEMM_SMALL(16, false, 1)
 CF_INSTANTIATE_TRIGEMM_SMALL(8, true, 2)
-CF_INSTANTIATE_TRIGEMM_SMALL(4, false, 4)
-CF_INSTANTIATE_TRIGEMM_SMALL(4, true, 4)
+CF_INSTANTIATE_TRIGEMM_SMALL(8, false, 2)
 
 // ------------------------------------------------------------------------------------------------
 // Likelihoods without an SN block: only the epilogue.
 // ------------------------------------------------------------------------------------------------
-extern "C" __global__ void finalize_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W,
+extern "C" __global__ void finalize_kernel(cf_epilogue d, const double* __restrict__ theta, int64_t W,
                                            const double* __restrict__ chi2_extra, double* __restrict__ out,
                                            int out_kind, unsigned long long* nonfinite, unsigned long long* done_flag,
                                            unsigned long long done_seq) {

@@ -475,12 +475,11 @@ def test_auto_mode_falls_back_to_the_blocked_solve(gpu, config2):
 
 
 @pytest.mark.parametrize("solve", ["auto", "blocked"])
-def test_replicas_and_chunks_do_not_change_a_walkers_result(gpu, solve, monkeypatch):
+def test_replicas_do_not_change_a_walkers_result(gpu, solve):
     """one handle over several devices splits the rows of theta over its replicas (one host thread + one
     stream each).  On a one-GPU box the ordinals repeat -- two / three replicas on the same device exercise the same
     split, threads and streams; where more GPUs are visible, "all" spreads over them.  Results are bit-identical to the
-    single-device handle, and so are those of a chunked evaluation (CF_CHUNKS: walker kernel of chunk c + 1 beside the
-    solve of chunk c)."""
+    single-device handle."""
     syn = gpu.synthetic.pantheon_like(n_sn=531, seed=4)
     mk = lambda **kw: gpu.sn_pantheon.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"], solve=solve, **kw)
     theta = gpu.synthetic.walkers(gpu.sn_pantheon.bounds, 3000, seed=5)
@@ -500,13 +499,6 @@ def test_replicas_and_chunks_do_not_change_a_walkers_result(gpu, solve, monkeypa
             with pytest.raises(gpu.CosmofitError, match="several devices"):
                 lk.engine.eval_device(t.data_ptr(), 64, t.data_ptr(), gpu.CF_OUT_LOGP, 0)
         lk.engine.close()
-    for chunks in ("512", "256,1024", "1024,512"):
-        monkeypatch.setenv("CF_CHUNKS", chunks)
-        lk = mk()
-        for W in (3000, 513, 2048):
-            assert np.array_equal(lk.log_probs_vectorized(theta[:W]), want[:W]), (chunks, W)
-        lk.engine.close()
-    monkeypatch.delenv("CF_CHUNKS")
     one.engine.close()
 
 
