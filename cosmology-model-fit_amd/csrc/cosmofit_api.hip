@@ -159,8 +159,8 @@ extern template __global__ void trsm_chi2_kernel<2, 4>(const cf_epilogue*, int, 
 template <int NP, int PF>
 __global__ void tri_gemm_chi2_kernel(const cf_epilogue* epi, const d2* frags, int n_ld, int ndim, int n_rb, const double* theta, int64_t W,
                                      const double* delta, int64_t w_pad, double* partial, unsigned int* arrivals, const double* chi2_extra,
-                                     double* out, int out_kind, unsigned long long* nonfinite, double* chi2_sn_out, int panels_per_group,
-                                     unsigned int n_units, unsigned int* queue, unsigned long long* done_flag, unsigned long long done_seq);
+                                     double* out, int out_kind, unsigned long long* nonfinite, double* chi2_sn_out, int panels,
+                                     int panels_per_group, int cls_shift, unsigned int* queue, unsigned long long* done_flag, unsigned long long done_seq);
 template <int PF, bool FRAG, int TPW>
 __global__ void tri_gemm_small_kernel(const cf_epilogue* epi, const d2* frags, int n_ld, int ndim, int n_rb, const double* theta, int64_t W,
                                       const double* delta, double* partial4, unsigned int* arrivals, const double* chi2_extra, double* out,
@@ -177,10 +177,13 @@ CF_DECLARE_TRIGEMM_SMALL(8, false, 2)
 #define CF_DECLARE_TRIGEMM(NP, PF)                                                                                                       \
   extern template __global__ void tri_gemm_chi2_kernel<NP, PF>(const cf_epilogue*, const d2*, int, int, int, const double*, int64_t,     \
                                                                const double*, int64_t, double*, unsigned int*, const double*, double*,  \
-                                                               int, unsigned long long*, double*, int, unsigned int, unsigned int*,      \
+                                                               int, unsigned long long*, double*, int, int, int, unsigned int*,          \
                                                                unsigned long long*, unsigned long long);
 CF_DECLARE_TRIGEMM(1, 2)
 CF_DECLARE_TRIGEMM(2, 2)
+CF_DECLARE_TRIGEMM(1, 4)
+CF_DECLARE_TRIGEMM(2, 4)
+CF_DECLARE_TRIGEMM(2, 6)
 extern "C" __global__ void finalize_kernel(cf_epilogue d, const double* theta, int64_t W, const double* chi2_extra,
                                            double* out, int out_kind, unsigned long long* nonfinite, unsigned long long* done_flag,
                                            unsigned long long done_seq);
@@ -443,9 +446,9 @@ static int ensure_workspace(cf_handle* h, int64_t W) {
     if (h->partial.ensure((size_t)w_pad * h->ipack.dev.n_rowblocks * 8)) return CF_ERR_HIP;
     if (h->arrivals.ensure((size_t)(w_pad / 16) * 4)) return CF_ERR_HIP;
     if (h->partial4.ensure((size_t)CF_SMALL_MAX_PANELS * 4 * h->ipack.dev.n_rowblocks * 16 * 8)) return CF_ERR_HIP;
-    if (h->queue.ensure(64)) return CF_ERR_HIP;
+    if (h->queue.ensure(2048)) return CF_ERR_HIP;  // eight queue heads 128 bytes apart + the leave counter
     HIP_TRY(hipMemsetAsync(h->arrivals.p, 0, (size_t)(w_pad / 16) * 4, h->stream));  // the kernels re-arm them themselves
-    HIP_TRY(hipMemsetAsync(h->queue.p, 0, 64, h->stream));
+    HIP_TRY(hipMemsetAsync(h->queue.p, 0, 2048, h->stream));
   }
   if (h->d.n_sn > 0) {
     if (h->delta.ensure((size_t)w_pad * n_ld * 8 + CF_DELTA_SLACK)) return CF_ERR_HIP;
@@ -1196,13 +1199,18 @@ static int launch_tri_gemm_t(const TriGemmArgs& a, hipStream_t st) {
       const int n_groups = (panels + max_group - 1) / max_group;
       ppg = ((panels + n_groups - 1) / n_groups + 7) / 8 * 8;
     }
-    const int n_groups = (panels + ppg - 1) / ppg;
-    const int64_t n_units = (int64_t)n_groups * ppg * a.n_rb;
-    const int64_t grid = std::min<int64_t>(n_units, (int64_t)tri_gemm_wgs_per_cu(n_units, cus) * cus);
+    const int64_t n_units = (int64_t)panels * a.n_rb;
+    // eight classes of panels (panel px served by the workgroups b = px mod 8, one XCD under round-robin placement) once every class
+    // holds at least eight panels; one class for the small batches, whose classes would be uneven (CF_TUNE gemm_classes=0|1 forces)
+    static const int cls_env = (int)cf_tune("gemm_classes", -1);
+    const int cls_shift = (cls_env >= 0 ? cls_env != 0 : panels >= 64) ? 3 : 0;
+    if (ppg == panels) ppg = (panels + 7) / 8 * 8;  // one group: any number >= panels whose eighth is whole
+    int64_t grid = std::min<int64_t>(n_units, (int64_t)tri_gemm_wgs_per_cu(n_units, cus) * cus);
+    if (cls_shift) grid = std::max<int64_t>(8, grid / 8 * 8);
     hipLaunchKernelGGL((tri_gemm_chi2_kernel<NP, PF>), dim3((unsigned)grid), dim3(256), 0, st, a.epi, a.frags, a.n_ld, a.ndim, a.n_rb,
                        a.theta + base * a.ndim, Wl, a.delta + base * a.n_ld, a.w_pad, a.partial + base, a.arrivals + base / 16,
                        a.chi2_extra ? a.chi2_extra + base : nullptr, a.out + base, a.out_kind, a.nonfinite,
-                       a.chi2_sn_out ? a.chi2_sn_out + base : nullptr, ppg, (unsigned)n_units, a.queue, a.done_flag, a.done_seq);
+                       a.chi2_sn_out ? a.chi2_sn_out + base : nullptr, panels, ppg, cls_shift, a.queue, a.done_flag, a.done_seq);
   }
   return 0;
 }
@@ -1266,6 +1274,9 @@ static int launch_tri_gemm(const TriGemmArgs& a, hipStream_t st) {
     return a.frag_b ? launch_tri_gemm_small_t<16, true, 1>(a, st) : launch_tri_gemm_small_t<16, false, 1>(a, st);
   }
   if (a.frag_b) return fail(CF_ERR_INVALID, "internal: fragment-ordered residuals handed to the throughput solve kernel");
+  static const int pf = (int)cf_tune("gemm_pf", 2);
+  if (pf == 6) return launch_tri_gemm_t<2, 6>(a, st);
+  if (pf == 4) return tri_gemm_panel_width(a.W) == 32 ? launch_tri_gemm_t<2, 4>(a, st) : launch_tri_gemm_t<1, 4>(a, st);
   return tri_gemm_panel_width(a.W) == 32 ? launch_tri_gemm_t<2, 2>(a, st) : launch_tri_gemm_t<1, 2>(a, st);
 }
 

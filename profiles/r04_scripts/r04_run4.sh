@@ -1,0 +1,18 @@
+#!/bin/bash
+# round 4, GPU call 4: work-queue solve kernel v3 (per-class queues: a panel stays on one XCD): parity, then the sweep against the
+# round-3 kernel on the same box; classes on / off
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04_4; mkdir -p $O
+timeout -k 10 240 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "config2_full or batch_invariance or golden or configs3_shape" > $O/pytest_first.log 2>&1; rc=$?; tail -3 $O/pytest_first.log
+[ $rc -ne 0 ] && { tail -40 $O/pytest_first.log; exit $rc; }
+timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; rc=$?; tail -3 $O/pytest.log
+[ $rc -ne 0 ] && { tail -40 $O/pytest.log; exit $rc; }
+for rep in 1 2; do
+  for W in 1024 2048 3072 4096 8192; do
+    BENCH_ARGS="--walkers-per-gpu $W" tools/quick_ab.sh q_w${W}_base_$rep COSMOFIT_LIB=$PWD/cosmology-model-fit_amd/libcosmofit_hip_r04base.so
+    for k in 2 3 4; do
+      BENCH_ARGS="--walkers-per-gpu $W" tools/quick_ab.sh q_w${W}_c1k${k}_$rep CF_TUNE=gemm_wgs=$k,gemm_classes=1
+      BENCH_ARGS="--walkers-per-gpu $W" tools/quick_ab.sh q_w${W}_c0k${k}_$rep CF_TUNE=gemm_wgs=$k,gemm_classes=0
+    done
+  done
+done 2>&1 | tee $O/queue_sizes.txt
