@@ -159,8 +159,8 @@ extern template __global__ void trsm_chi2_kernel<2, 4>(const cf_epilogue*, int, 
 template <int NP, int PF>
 __global__ void tri_gemm_chi2_kernel(const cf_epilogue* epi, const d2* frags, int n_ld, int ndim, int n_rb, const double* theta, int64_t W,
                                      const double* delta, int64_t w_pad, double* partial, unsigned int* arrivals, const double* chi2_extra,
-                                     double* out, int out_kind, unsigned long long* nonfinite, double* chi2_sn_out, int panels,
-                                     int panels_per_group, int cls_shift, unsigned int* queue, unsigned long long* done_flag, unsigned long long done_seq);
+                                     double* out, int out_kind, unsigned long long* nonfinite, double* chi2_sn_out, int panels_per_group,
+                                     int snake, unsigned long long* done_flag, unsigned long long done_seq);
 template <int PF, bool FRAG, int TPW>
 __global__ void tri_gemm_small_kernel(const cf_epilogue* epi, const d2* frags, int n_ld, int ndim, int n_rb, const double* theta, int64_t W,
                                       const double* delta, double* partial4, unsigned int* arrivals, const double* chi2_extra, double* out,
@@ -177,13 +177,10 @@ CF_DECLARE_TRIGEMM_SMALL(8, false, 2)
 #define CF_DECLARE_TRIGEMM(NP, PF)                                                                                                       \
   extern template __global__ void tri_gemm_chi2_kernel<NP, PF>(const cf_epilogue*, const d2*, int, int, int, const double*, int64_t,     \
                                                                const double*, int64_t, double*, unsigned int*, const double*, double*,  \
-                                                               int, unsigned long long*, double*, int, int, int, unsigned int*,          \
-                                                               unsigned long long*, unsigned long long);
+                                                               int, unsigned long long*, double*, int, int, unsigned long long*,        \
+                                                               unsigned long long);
 CF_DECLARE_TRIGEMM(1, 2)
 CF_DECLARE_TRIGEMM(2, 2)
-CF_DECLARE_TRIGEMM(1, 4)
-CF_DECLARE_TRIGEMM(2, 4)
-CF_DECLARE_TRIGEMM(2, 6)
 extern "C" __global__ void finalize_kernel(cf_epilogue d, const double* theta, int64_t W, const double* chi2_extra,
                                            double* out, int out_kind, unsigned long long* nonfinite, unsigned long long* done_flag,
                                            unsigned long long done_seq);
@@ -332,7 +329,6 @@ struct cf_handle {
   InversePack ipack;
   DevBuf partial, arrivals;  // inverse-GEMM solve: chi^2 shares per (row block, walker); arrival counters per panel
   DevBuf partial4;           // small-batch solve: shares per (panel, row block, tile, walker), CF_SMALL_MAX_PANELS panels
-  DevBuf queue;              // throughput solve: {next unit, workgroups that have left} of the persistent grid (re-armed by the kernel)
   DevBuf epi;                // device copy of `epi_host`: what the solve kernels' last arrivers read of the prior / output epilogue
   cf_epilogue epi_host{};
   hipStream_t stream = nullptr;  // host-buffer evaluations (cf_eval, cf_eval_parts)
@@ -446,9 +442,7 @@ static int ensure_workspace(cf_handle* h, int64_t W) {
     if (h->partial.ensure((size_t)w_pad * h->ipack.dev.n_rowblocks * 8)) return CF_ERR_HIP;
     if (h->arrivals.ensure((size_t)(w_pad / 16) * 4)) return CF_ERR_HIP;
     if (h->partial4.ensure((size_t)CF_SMALL_MAX_PANELS * 4 * h->ipack.dev.n_rowblocks * 16 * 8)) return CF_ERR_HIP;
-    if (h->queue.ensure(2048)) return CF_ERR_HIP;  // eight queue heads 128 bytes apart + the leave counter
     HIP_TRY(hipMemsetAsync(h->arrivals.p, 0, (size_t)(w_pad / 16) * 4, h->stream));  // the kernels re-arm them themselves
-    HIP_TRY(hipMemsetAsync(h->queue.p, 0, 2048, h->stream));
   }
   if (h->d.n_sn > 0) {
     if (h->delta.ensure((size_t)w_pad * n_ld * 8 + CF_DELTA_SLACK)) return CF_ERR_HIP;
@@ -1145,14 +1139,13 @@ static int launch_trsm(const cf_epilogue* epi, int n_pad, int n_ld, int ndim, co
 struct TriGemmArgs {
   const cf_epilogue* epi;
   const d2* frags;
-  int n_ld, ndim, n_rb, cu_count;
+  int n_ld, ndim, n_rb;
   const double* theta;
   int64_t W;
   const double* delta;
   int64_t w_pad;
   double* partial;
   unsigned int* arrivals;
-  unsigned int* queue;
   const double* chi2_extra;
   double* out;
   int out_kind;
@@ -1164,21 +1157,10 @@ struct TriGemmArgs {
   bool frag_b;  // `delta` holds the panels' residuals in the small-batch kernel's fragment order (walker_fast_kernel, frag_b)
 };
 
-// Workgroups per CU of the throughput solve kernel's persistent grid for a batch of `n_units` units (CF_TUNE gemm_wgs=<1..4> forces one).
-// Four is what registers and LDS admit (127 VGPRs, 33 KB).  The grid must be SMALLER than the number of units for the queue to have
-// anything to balance with: a batch whose units would all be resident at once gets fewer workgroups per CU, so that the longest
-// units start first and the short ones fill in behind them.
-static int tri_gemm_wgs_per_cu(int64_t n_units, int cu_count) {
-  static const int forced = (int)cf_tune("gemm_wgs", 0);
-  if (forced >= 1 && forced <= 4) return forced;
-  for (int k = 4; k > 1; --k)
-    if (n_units >= (int64_t)2 * k * cu_count) return k;  // at least half of the units (the short half) come from the queue
-  return n_units >= (int64_t)(3 * cu_count) / 2 ? 2 : 1;
-}
-
 template <int NP, int PF>
 static int launch_tri_gemm_t(const TriGemmArgs& a, hipStream_t st) {
-  // Panel groups: the units run group by group (a group = `ppg` panels x all row blocks), so that a group's residual rows
+  const int panels = (int)((a.W + 16 * NP - 1) / (16 * NP));
+  // Panel groups: the grid runs group by group (a group = `ppg` panels x all row blocks), so that a group's residual rows
   // stay in the 256 MB Infinity Cache while its 27 row blocks pass over them.  Up to 8192 walkers (256 panels of 32: 113 MB
   // of residual rows) one group is best (W = 4096: one group 226 us, two 229 us, four 249 us -- the factor streams are
   // re-read per group); beyond that the rows no longer fit and every row block would stream them from HBM again
@@ -1186,32 +1168,21 @@ static int launch_tri_gemm_t(const TriGemmArgs& a, hipStream_t st) {
   // profiles/r02_panel_groups.txt: one group 3.66 ms = 0.66 of peak, groups of 256 panels 3.05 ms = 0.79, of 128 panels
   // 2.96 ms = 0.82).  CF_TUNE gemm_group=<panels> overrides (multiples of 8 so that a panel stays on one XCD; 0 = one group).
   static const int env_group = (int)cf_tune("gemm_group", -1);
-  const int cus = a.cu_count > 0 ? a.cu_count : 256;
-  // One launch takes at most CF_MY_PANELS panels (32768 walkers of 32-walker panels): every workgroup keeps the panels it arrived
-  // last for in an LDS list that must hold them all.  A 65536-walker evaluation is two launches of eight groups.
-  constexpr int64_t per_launch = (int64_t)CF_MY_PANELS * 16 * NP;
-  for (int64_t base = 0; base < a.W; base += per_launch) {
-    const int64_t Wl = std::min(per_launch, a.W - base);
-    const int panels = (int)((Wl + 16 * NP - 1) / (16 * NP));
-    const int max_group = env_group >= 0 ? env_group : (panels > 256 ? 128 : 0);
-    int ppg = panels;
-    if (max_group > 0 && panels > max_group) {
-      const int n_groups = (panels + max_group - 1) / max_group;
-      ppg = ((panels + n_groups - 1) / n_groups + 7) / 8 * 8;
-    }
-    const int64_t n_units = (int64_t)panels * a.n_rb;
-    // eight classes of panels (panel px served by the workgroups b = px mod 8, one XCD under round-robin placement) once every class
-    // holds at least eight panels; one class for the small batches, whose classes would be uneven (CF_TUNE gemm_classes=0|1 forces)
-    static const int cls_env = (int)cf_tune("gemm_classes", -1);
-    const int cls_shift = (cls_env >= 0 ? cls_env != 0 : panels >= 64) ? 3 : 0;
-    if (ppg == panels) ppg = (panels + 7) / 8 * 8;  // one group: any number >= panels whose eighth is whole
-    int64_t grid = std::min<int64_t>(n_units, (int64_t)tri_gemm_wgs_per_cu(n_units, cus) * cus);
-    if (cls_shift) grid = std::max<int64_t>(8, grid / 8 * 8);
-    hipLaunchKernelGGL((tri_gemm_chi2_kernel<NP, PF>), dim3((unsigned)grid), dim3(256), 0, st, a.epi, a.frags, a.n_ld, a.ndim, a.n_rb,
-                       a.theta + base * a.ndim, Wl, a.delta + base * a.n_ld, a.w_pad, a.partial + base, a.arrivals + base / 16,
-                       a.chi2_extra ? a.chi2_extra + base : nullptr, a.out + base, a.out_kind, a.nonfinite,
-                       a.chi2_sn_out ? a.chi2_sn_out + base : nullptr, panels, ppg, cls_shift, a.queue, a.done_flag, a.done_seq);
+  const int max_group = env_group >= 0 ? env_group : (panels > 256 ? 128 : 0);
+  int ppg = panels;
+  if (max_group > 0 && panels > max_group) {
+    const int n_groups = (panels + max_group - 1) / max_group;
+    ppg = ((panels + n_groups - 1) / n_groups + 7) / 8 * 8;
   }
+  const int n_groups = (panels + ppg - 1) / ppg;
+  const int n_wgs = n_groups * ppg * a.n_rb;
+  // order of the row blocks inside the grid: descending; for a grid that is resident all at once, alternate blocks of 256 workgroups
+  // ascending (see the kernel).  CF_TUNE gemm_order=0|1 forces one.
+  static const int order_env = (int)cf_tune("gemm_order", -1);
+  const int snake = order_env >= 0 ? order_env : (n_wgs <= 1024 ? 1 : 0);
+  hipLaunchKernelGGL((tri_gemm_chi2_kernel<NP, PF>), dim3((unsigned)n_wgs), dim3(256), 0, st, a.epi, a.frags, a.n_ld, a.ndim, a.n_rb, a.theta,
+                     a.W, a.delta, a.w_pad, a.partial, a.arrivals, a.chi2_extra, a.out, a.out_kind, a.nonfinite, a.chi2_sn_out, ppg, snake,
+                     a.done_flag, a.done_seq);
   return 0;
 }
 
@@ -1274,9 +1245,6 @@ static int launch_tri_gemm(const TriGemmArgs& a, hipStream_t st) {
     return a.frag_b ? launch_tri_gemm_small_t<16, true, 1>(a, st) : launch_tri_gemm_small_t<16, false, 1>(a, st);
   }
   if (a.frag_b) return fail(CF_ERR_INVALID, "internal: fragment-ordered residuals handed to the throughput solve kernel");
-  static const int pf = (int)cf_tune("gemm_pf", 2);
-  if (pf == 6) return launch_tri_gemm_t<2, 6>(a, st);
-  if (pf == 4) return tri_gemm_panel_width(a.W) == 32 ? launch_tri_gemm_t<2, 4>(a, st) : launch_tri_gemm_t<1, 4>(a, st);
   return tri_gemm_panel_width(a.W) == 32 ? launch_tri_gemm_t<2, 2>(a, st) : launch_tri_gemm_t<1, 2>(a, st);
 }
 
@@ -1340,8 +1308,8 @@ static int launch_eval(cf_handle* h, const double* th, int64_t Wc, double* out, 
   }
   if (ev) HIP_TRY(hipEventRecord(ev[2], st));
   if (d.n_sn > 0 && h->solve_mode == CF_SOLVE_INVERSE_GEMM) {
-    TriGemmArgs a{h->epi.as<const cf_epilogue>(), h->ipack.dev.frags, d.n_ld, d.ndim, h->ipack.dev.n_rowblocks, h->cu_count, th, Wc, delta,
-                  h->max_walkers, h->partial.as<double>(), h->arrivals.as<unsigned int>(), h->queue.as<unsigned int>(), extra, out,
+    TriGemmArgs a{h->epi.as<const cf_epilogue>(), h->ipack.dev.frags, d.n_ld, d.ndim, h->ipack.dev.n_rowblocks, th, Wc, delta,
+                  h->max_walkers, h->partial.as<double>(), h->arrivals.as<unsigned int>(), extra, out,
                   out_kind, nf, chi2_sn_out, h->partial4.as<double>(), nullptr, 0ull, frag_b};
     // a synchronous zero-copy call: the solve kernel's last arrivers set one word per panel in pinned host memory and the host
     // waits for those instead of the end of the kernel (launch_tri_gemm's own choice of kernel and panel width decides how many)

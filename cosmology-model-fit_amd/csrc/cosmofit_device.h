@@ -172,8 +172,6 @@ struct cf_epilogue {
   double chi2_gauss_mean[CF_MAX_GAUSS], chi2_gauss_sigma[CF_MAX_GAUSS];
 };
 #define CF_EPI_WORDS ((int)((sizeof(cf_epilogue) + 7) / 8))
-// Throughput solve kernel: panels per launch (each workgroup keeps the list of panels it arrived last for in LDS: 4 bytes each)
-#define CF_MY_PANELS 1024
 
 #ifdef __HIPCC__
 typedef double cf_d2 __attribute__((ext_vector_type(2)));

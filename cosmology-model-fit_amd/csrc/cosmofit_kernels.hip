@@ -1698,23 +1698,25 @@ CF_INSTANTIATE_TRSM(2, 4)  // the shipped shape: 8 waves, two per SIMD
 
 // ------------------------------------------------------------------------------------------------
 // Inverse-GEMM solve: Y = X Delta with X = L^-1 inverted once on the host (cf_pack.h), a triangular
-// GEMM with no dependency between row blocks.  The UNIT of work is one (64-row block rb, panel of 16*NP walkers): the
-// four waves of a 256-thread workgroup split the K range [0, 64 (rb+1)), each keeps the 4 x NP accumulator tiles of the
-// block in registers (an A fragment feeds NP MFMAs), the quarters meet in LDS, and the unit's share of chi^2 goes to
-// partial[rb][walker].  The workgroup that arrives last for a panel adds the shares in a fixed order and applies the prior /
-// output epilogue -> one launch, and results do not depend on timing.  B fragments are 16-byte loads straight from the
-// row-major residual rows.
+// GEMM with no dependency between row blocks.  One 256-thread workgroup per UNIT = (64-row block rb, panel of 16*NP walkers): the
+// four waves split the K range [0, 64 (rb+1)), each keeps the 4 x NP accumulator tiles of the block in registers (an A fragment
+// feeds NP MFMAs), the quarters meet in LDS, and the unit's share of chi^2 goes to partial[rb][walker].  The workgroup that
+// arrives last for a panel adds the shares in a fixed order and applies the prior / output epilogue -> one launch, and results do
+// not depend on timing.  B fragments are 16-byte loads straight from the row-major residual rows.
 //
-// SCHEDULING (round 4): a PERSISTENT grid.  The launch holds at most `wgs per CU` x CUs workgroups; workgroup b starts with unit b
-// and then pulls further units from ONE agent-scope counter (`queue`), in the order unit 0, 1, 2, ...: panel group (its residual
-// rows stay in the Infinity Cache while the group's row blocks pass) > row block, LARGEST FIRST > panel inside the group
-// (consecutive units = different XCDs on the same factor stream).  Longest-first from a shared queue is what balances the CUs:
-// the round-3 kernel mapped blockIdx -> unit statically, and a grid that is resident all at once (<= 1024 workgroups: up to
-// 1024 walkers) put workgroups i, i + 256, ... on one CU whatever their lengths -- 36 to 60 units of work per CU around a mean
-// of 47 at 512-1024 walkers (0.57 of the FP64 matrix peak at 1024 walkers against 0.81 at 4096, where the hardware dispatcher
-// refills CUs as workgroups retire).  The pull rides on the hand-off's own round trip to memory (wave 0 issues the arrival add and
-// the queue add together), so a unit costs no extra latency; the per-unit arithmetic and the ordered last-arriver sum are
-// unchanged, hence the same bits as before for every batch size.  The workgroup that leaves last re-arms the two counters.
+// SCHEDULING: a plain grid, blockIdx -> unit in the order panel group (its residual rows stay in the Infinity Cache while the
+// group's row blocks pass) > row block, LARGEST FIRST > panel inside the group (consecutive workgroups = different XCDs on the same
+// factor stream; with 8 | panels per group, panel px always lands on XCD px % 8, whose L2 keeps its residual rows).  The hardware
+// dispatcher refills a CU as its workgroups retire, which IS longest-first list scheduling.  Round 4 built the alternative the
+// round-3 review asked for -- a persistent grid pulling units from agent-scope queues, in three forms (units pulled at the
+// hand-off; software-pipelined units whose next fragments are requested before the exchange and whose queue / arrival adds are
+// never waited for; per-XCD queues that keep a panel on one XCD), each bit-identical and parity-green: 3-5 % SLOWER than this
+// grid from 2048 walkers up, even at 1024, slower below (profiles/r04_queue_v*_sizes_raw.txt, the kernel:
+// profiles/r04_work_queue_kernel_v3.patch).  Its in-kernel timeline says why scheduling is not where the time is
+// (profiles/r04_solve_timeline_v3.txt): a wave spends 24 % of its life outside K loops, 12 us per unit, waiting at the exchange
+// barrier for its workgroup's three other waves -- they sit on four SIMDs that each arbitrate four workgroups' waves and drift
+// apart over a 50-100 us K loop -- and the kernel's ragged end (CUs finish 174-187 us into a 190 us kernel) is set by the
+// (rb + 1)-sized units in flight when the queue runs dry, which a queue cannot shorten.
 // ------------------------------------------------------------------------------------------------
 
 // Workgroup barrier for LDS traffic only (no wait on global loads that have nothing to do with the exchange).  Neither this nor
@@ -1772,9 +1774,7 @@ __device__ __attribute__((noinline)) void panel_epilogue_from_memory(const cf_ep
 }
 
 // The workgroup that arrived last for panel `px`: the panel's shares summed in row-block order, the prior / output epilogue, the
-// completion word.  `sh`: 4096 doubles of LDS (the K-quarter exchange buffer, free at this point).  The persistent kernel runs it
-// BEHIND its unit loop (see there): inside the loop its temporaries cost the K loop its register budget -- 236 VGPRs and 129 SGPR
-// spills against 127 / 0, i.e. two workgroups per CU instead of four; as a real call, 146 VGPRs.
+// completion word.  `sh`: 4096 doubles of LDS (the K-quarter exchange buffer, free at this point).
 template <int NP>
 __device__ __forceinline__ void panel_last_arriver(double* sh, const cf_epilogue* __restrict__ epi, int ndim, int n_rb,
                                                              const double* __restrict__ theta, int64_t W, int64_t w_pad, double* partial,
@@ -1783,10 +1783,7 @@ __device__ __forceinline__ void panel_last_arriver(double* sh, const cf_epilogue
                                                              double* __restrict__ chi2_sn_out, int px, unsigned long long* done_flag,
                                                              unsigned long long done_seq) {
   constexpr int PW = 16 * NP;
-  // an opaque copy of the thread index: everything below that depends only on it (share and theta addresses: ~100 VGPRs) would
-  // otherwise be hoisted out of the persistent kernel's unit loop as loop-invariant and stay live across the K loop
-  int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));
+  const int tid = threadIdx.x;
   const int64_t w0 = (int64_t)px * PW;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   if (tid == 0) __hip_atomic_store(&arrivals[px], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1857,7 +1854,7 @@ __device__ __forceinline__ void panel_last_arriver(double* sh, const cf_epilogue
 
 #ifdef CF_DIAG_CLOCK
 // DIAGNOSTIC BUILD ONLY (tools/build_variant.sh clock -DCF_DIAG_CLOCK; tools/solve_clock.py): per workgroup the shader-clock and
-// real-time (100 MHz) counters at entry, behind the unit loop and at exit, the units it worked and the panels it came last for --
+// real-time (100 MHz) counters at entry, behind the hand-off and behind the last arriver's epilogue, where it ran (XCC_ID, HW_ID) --
 // the clock the chip holds under this kernel is d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back
 // (6)).  The stamps go to a buffer of their own; no output value depends on them.
 __device__ unsigned long long cf_solve_clock[4096 * 8];  // [workgroup][mt0, rt0, mt1, rt1, mt2, rt2, units, panels]
@@ -1873,6 +1870,12 @@ extern "C" int cf_debug_solve_clock(unsigned long long* out) {
   if (tid == 0 && blockIdx.x < 4096) cf_solve_clock[blockIdx.x * 8 + (k)] = (unsigned long long)(v)
 // wave 0's cycles inside K loops, its K-step pairs and its units, per workgroup
 __device__ unsigned long long cf_solve_kloop[4096 * 4];
+__device__ unsigned long long cf_solve_phase[4096 * 16];  // [workgroup][K loop begin / end of waves 0-3 (8), first exchange barrier passed, shares formed, stores acknowledged, arrival add returned]
+extern "C" int cf_debug_solve_phase(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cf_solve_phase), sizeof(cf_solve_phase));
+}
+#define CF_PHASE(k) \
+  if (blockIdx.x < 4096) cf_solve_phase[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime()
 extern "C" int cf_debug_solve_kloop(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cf_solve_kloop), sizeof(cf_solve_kloop));
 }
@@ -1895,6 +1898,7 @@ extern "C" int cf_debug_solve_kloop(unsigned long long* out) {
 #define CF_KLOOP_BEGIN
 #define CF_KLOOP_END(nq)
 #define CF_KLOOP_STORE
+#define CF_PHASE(k)
 #endif
 
 // The add is RELAXED unless CF_HANDOFF_RELEASE is defined (tests/test_gpu_handoff.py compares the two builds bit for bit): an
@@ -1908,74 +1912,66 @@ extern "C" int cf_debug_solve_kloop(unsigned long long* out) {
 #endif
 
 template <int NP, int PF>
-__global__ void __launch_bounds__(256, PF <= 2 ? 4 : 2)  // PF = 2: four workgroups per CU (128 VGPRs); deeper pipelines: two
+__global__ void __launch_bounds__(256, 4)  // four workgroups per CU: 128 VGPRs
 tri_gemm_chi2_kernel(const cf_epilogue* __restrict__ epi, const d2* __restrict__ frags, int n_ld, int ndim, int n_rb,
                      const double* __restrict__ theta, int64_t W, const double* __restrict__ delta, int64_t w_pad, double* partial,
                      unsigned int* arrivals, const double* __restrict__ chi2_extra, double* __restrict__ out, int out_kind,
-                     unsigned long long* nonfinite, double* __restrict__ chi2_sn_out, int panels, int panels_per_group, int cls_shift,
-                     unsigned int* queue, unsigned long long* done_flag, unsigned long long done_seq) {
+                     unsigned long long* nonfinite, double* __restrict__ chi2_sn_out, int panels_per_group, int snake,
+                     unsigned long long* done_flag, unsigned long long done_seq) {
   __shared__ __align__(16) d4 part[4][4][64];  // [wave][tile][lane] of one 16-walker panel: 32 KB
   __shared__ double chi_tile[4][16 * NP];
-  __shared__ unsigned int next_unit;
-  __shared__ int n_mine_all;
-  __shared__ int my_panels[CF_MY_PANELS];
+  __shared__ unsigned int arrived_before;
   constexpr int PW = 16 * NP;
-  constexpr int STAGE_LOADS = 4 + NP;  // vector-memory instructions of one pipeline stage
-  constexpr int TAIL_GROUPS = 2;       // the next unit is pulled this many PF-groups before the K loop ends
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int g = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave's K quarter, in a scalar register: its address arithmetic too
-  const int64_t bstride = 8 * (int64_t)n_ld;
-  // CLASSES.  With cls_shift = 3 the panels fall into 8 classes, panel px in class px % 8, and workgroup b serves class b % 8
-  // only, from that class's own queue: workgroups b, b + 8, ... share an XCD (round-robin placement: observed, not promised -- it
-  // costs speed, never correctness, if it does not hold), so a panel's residual rows are read by ONE XCD's L2 for all its 27 row
-  // blocks, as in the static grid of round 3 (unit = row block x 128 + panel put panel px on XCD px % 8 by accident of the
-  // numbering).  Handing units to whichever workgroup asks first scatters a panel over the XCDs: every row block then fetches the
-  // rows from the Infinity Cache again.  cls_shift = 0: one class (batches of a few panels, where the classes would be uneven).
-  // Units of a class: panel group > row block, largest first > the class's panels of the group; the last group may be shorter.
-  const int cls = (int)blockIdx.x & ((1 << cls_shift) - 1), n_local_wgs = (int)gridDim.x >> cls_shift;
-  unsigned int* const my_queue = queue + 32 * cls;  // the queues lie 128 bytes apart
-  const int cls_panels = (panels - cls + (1 << cls_shift) - 1) >> cls_shift, cls_ppg = panels_per_group >> cls_shift;
-  const int full_groups = cls_panels / cls_ppg, last_ppg = cls_panels - full_groups * cls_ppg;
-  const unsigned int units_full = (unsigned)(full_groups * cls_ppg * n_rb), n_units = (unsigned)(cls_panels * n_rb);
-  auto decode = [&](unsigned int u, int& rb_, int& px_) {
-    int lp;
-    if (u < units_full) {
-      const int per_group = cls_ppg * n_rb, grp = (int)u / per_group, rem = (int)u % per_group;
-      rb_ = n_rb - 1 - rem / cls_ppg;
-      lp = grp * cls_ppg + rem % cls_ppg;
-    } else {
-      const int rem = (int)(u - units_full);
-      rb_ = n_rb - 1 - rem / last_ppg;
-      lp = full_groups * cls_ppg + rem % last_ppg;
-    }
-    px_ = (lp << cls_shift) + cls;
-  };
-  // the wave's fragment pointers of a unit: the factor stream of (row block, K quarter) in closed form (cf_inv_stream_off), 16
-  // bytes per lane of the walker's residual row (panel c is 16 rows = 8 n_ld d2 further on).  Formed from an OPAQUE copy of
-  // the lane index: left to itself the compiler hoists everything that depends only on the lane out of the unit loop, keeps it
-  // live across the K loop and spills it to scratch to stay within 128 VGPRs.
-  auto unit_pointers = [&](int rb_, int px_, const d2*& A_, const d2*& Bq_) {
-    int lane = tid & 63;
-    asm volatile("" : "+v"(lane));
-    const int col = lane & 15, kq = lane >> 4, nq_ = 2 * (rb_ + 1);
-    A_ = frags + cf_inv_stream_off(rb_, g) * 64 + lane;
-    Bq_ = reinterpret_cast<const d2*>(delta) + ((int64_t)(px_ * PW + col) * n_ld + 8 * g * nq_ + 2 * kq) / 2;
-  };
+  const int col = lane & 15, kq = lane >> 4;
+  const int per_group = panels_per_group * n_rb;
+  const int grp = (int)blockIdx.x / per_group;
+  int rem_id = (int)blockIdx.x % per_group;
+  // `snake`: a grid that is resident all at once (<= 1024 workgroups) is placed statically, workgroups i, i + 256, i + 512, ... on the
+  // same CU: in plain descending order some CUs then hold 60 row-block units and others 36 (512 / 1024 walkers; the mean is 47.25).
+  // Alternate blocks of 256 workgroups run ascending instead (43 .. 51 per CU; a longest-first assignment computed on the host
+  // would reach 46 .. 50): 256 walkers 46.4 -> 43.0 us per call, 512: 58.9 -> 55.5, 1024: 94.5 -> 87.3; a grid that arrives in
+  // waves (4096 walkers) is better off descending (254 against 257.5 us).  profiles/r03_gemm_stamps_and_pairing.txt
+  if (snake) {
+    const int b = rem_id >> 8, len = (per_group - (b << 8)) < 256 ? per_group - (b << 8) : 256;
+    if (b & 1) rem_id = (b << 8) + (len - 1 - (rem_id & 255));
+  }
+  const int rb = n_rb - 1 - rem_id / panels_per_group;  // largest row blocks first
+  const int px = grp * panels_per_group + rem_id % panels_per_group;
+  const int64_t w0 = (int64_t)px * PW;
+  if (w0 >= W) return;  // the last group may be partly empty
   CF_CLOCK_STAMP(0);
-  int rb, px;
-  const d2 *A, *Bq;
-  const unsigned int first_unit = blockIdx.x >> cls_shift;
-  const bool has_work = first_unit < n_units;  // (a class may hold fewer units than it has workgroups)
-  decode(has_work ? first_unit : 0u, rb, px);
-  unit_pointers(rb, px, A, Bq);
-  // PF-deep software pipeline over the wave's K-step pairs.  Nothing is loaded past the wave's K range (but for row block 0,
-  // covered by the buffers' slack): a load that nobody consumes still has to land before the wave may go on.
+  const int nq = 2 * (rb + 1);  // K-step pairs per wave
+  // the factor stream of (row block, K quarter) in closed form (cf_inv_stream_off): no dependent load in front of the first fragment
+  const d2* A = frags + cf_inv_stream_off(rb, g) * 64 + lane;
+  // B fragments: 16 bytes per lane from the walker's residual row; panel c is 16 rows (8 n_ld d2) further on
+  const d2* Bq = reinterpret_cast<const d2*>(delta) + ((w0 + col) * (int64_t)n_ld + 8 * g * nq + 2 * kq) / 2;
+  const int64_t bstride = 8 * (int64_t)n_ld;
+  d4 acc[NP][4];
+#pragma unroll
+  for (int c = 0; c < NP; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[c][j] = (d4){0.0, 0.0, 0.0, 0.0};
+  // PF-deep software pipeline over the nq K-step pairs.  Nothing is loaded past the wave's K range (but for row
+  // block 0, covered by the buffers' slack): a load that nobody consumes still has to land before the wave may
+  // retire, and it misses every cache.
   d2 a[PF][4], bf[PF][NP];
   auto load_stage = [&](int p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) a[p][j] = A[(p * 4 + j) * 64];
 #pragma unroll
     for (int c = 0; c < NP; ++c) bf[p][c] = Bq[c * bstride + p * 4];
+  };
+  auto mfma_stage = [&](int p) {
+#pragma unroll
+    for (int c = 0; c < NP; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[c][j] = mfma_f64(a[p][j].x, bf[p][c].x, acc[c][j]);
+#pragma unroll
+    for (int c = 0; c < NP; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[c][j] = mfma_f64(a[p][j].y, bf[p][c].y, acc[c][j]);
   };
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1985,187 +1981,84 @@ tri_gemm_chi2_kernel(const cf_epilogue* __restrict__ epi, const d2* __restrict__
   }
   A += PF * 4 * 64;
   Bq += PF * 4;
-  // Wave 0, lane 0 keeps the workgroup's dealings with the other workgroups (all agent-scope atomics, none of them waited for
-  // where it is issued):
-  //   sig_px  panel of the unit whose shares are stored but not yet signalled (arrival add pending), -1: none
-  //   ab      the arrival add in flight: this workgroup came last for that panel (parked in my_panels[n_mine]) if ab == n_rb - 1
-  //   tk      the queue add in flight: the workgroup's next unit is tk + gridDim.x
-  int sig_px = -1, n_mine = 0;
-  unsigned int ab = 0, tk = 0;
+  const int n_groups = nq / PF, rem = nq - n_groups * PF;
   CF_KLOOP_DECL;
-  // SERVICE: signal the previous unit, pull the next one.  `in_flight`: vector-memory instructions of this wave younger than the
-  // previous unit's share stores that may still be pending -- counters complete in issue order, so vmcnt(in_flight) says the
-  // stores are acknowledged (MI355X_MICROARCH.md, hand-off rule (3)) without draining the loads of the pipeline.
-  auto service = [&](bool mid_loop) {
-    if (mid_loop)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF * STAGE_LOADS) : "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tid == 0) {
-      ab = 0xffffffffu;
-      if (sig_px >= 0) {
-        my_panels[n_mine] = sig_px;  // kept if the add's answer says so
-        ab = __hip_atomic_fetch_add(&arrivals[sig_px], 1u, CF_ARRIVE_ORDER, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      sig_px = -1;
-      tk = __hip_atomic_fetch_add(my_queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  };
-  while (has_work) {
-    const int nq = 2 * (rb + 1);  // K-step pairs per wave
-    d4 acc[NP][4];
-#pragma unroll
-    for (int c = 0; c < NP; ++c)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[c][j] = (d4){0.0, 0.0, 0.0, 0.0};
-    auto mfma_stage = [&](int p) {
-#pragma unroll
-      for (int c = 0; c < NP; ++c)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[c][j] = mfma_f64(a[p][j].x, bf[p][c].x, acc[c][j]);
-#pragma unroll
-      for (int c = 0; c < NP; ++c)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[c][j] = mfma_f64(a[p][j].y, bf[p][c].y, acc[c][j]);
-    };
-    auto main_group = [&]() {  // branch-free body: a guard around the MFMAs makes hipcc drain vmcnt(0) per stage
-#pragma unroll
-      for (int p = 0; p < PF; ++p) {
-        mfma_stage(p);
-        __builtin_amdgcn_sched_barrier(0);
-        load_stage(p);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      A += PF * 4 * 64;
-      Bq += PF * 4;
-    };
-    const int n_groups = nq / PF, rem = nq - n_groups * PF;
-    const int n_main = n_groups - 1, n_first = n_main > TAIL_GROUPS ? n_main - TAIL_GROUPS : 0;
-    CF_KLOOP_BEGIN;
-    for (int kg = 0; kg < n_first; ++kg) main_group();
-    // the queue is consulted LATE in the unit (what is handed out early is handed out statically, and a batch of 512-2048 walkers
-    // has few units per workgroup), yet TAIL_GROUPS groups of MFMAs before the answer is needed
-    if (g == 0 && n_first > 0) service(true);
-    for (int kg = n_first; kg < n_main; ++kg) main_group();
-    if (n_groups > 0) {  // last full group: only the nq % PF pairs of the tail are still to be fetched
-#pragma unroll
-      for (int p = 0; p < PF; ++p) {
-        mfma_stage(p);
-        __builtin_amdgcn_sched_barrier(0);
-        if (p < rem) load_stage(p);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-#pragma unroll
-    for (int p = 0; p < PF - 1; ++p)
-      if (p < rem) mfma_stage(p);
-    CF_KLOOP_END(nq);
-    if (g == 0) {
-      if (n_first == 0) service(false);  // a short unit: every load has been consumed, the answers are waited for right here
-      if (tid == 0) {
-        next_unit = tk + n_local_wgs;
-        if (ab == (unsigned)n_rb - 1u) ++n_mine;
-      }
-    }
-    // the four K quarters meet in LDS, one 16-walker panel at a time; wave g owns tile g: y, then the column sums of y^2
-    int lane = tid & 63;
-    asm volatile("" : "+v"(lane));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) part[g][j][lane] = acc[0][j];
-    lds_barrier();
-    // the next unit is known to every wave now: its first fragments are requested BEFORE the rest of this unit's exchange and
-    // hand-off, whose barriers and round trips to memory they then overlap (the stage registers are free: the K loop is over)
-    const unsigned int nu = next_unit;
-    const bool has_next = nu < n_units;
-    int rb2, px2;
-    decode(has_next ? nu : 0u, rb2, px2);
-    unit_pointers(rb2, px2, A, Bq);
-    __builtin_amdgcn_sched_barrier(0);
+  CF_KLOOP_BEGIN;
+  if (lane == 0) { CF_PHASE(2 * g); }
+  for (int kg = 0; kg + 1 < n_groups; ++kg) {  // branch-free body: a guard around the MFMAs makes hipcc drain vmcnt(0) per stage
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
-      load_stage(p);  // unconditional: a workgroup without a next unit re-reads unit 0's first fragments (L2 hits) once
+      mfma_stage(p);
+      __builtin_amdgcn_sched_barrier(0);
+      load_stage(p);
       __builtin_amdgcn_sched_barrier(0);
     }
     A += PF * 4 * 64;
     Bq += PF * 4;
-    {
-      const double v = tile_chi2_share(part[0][g][lane], part[1][g][lane], part[2][g][lane], part[3][g][lane]);
-      if (lane < 16) chi_tile[g][lane] = v;
-    }
+  }
+  if (n_groups > 0) {  // last full group: only the nq % PF pairs of the tail are still to be fetched
 #pragma unroll
-    for (int c = 1; c < NP; ++c) {
-      lds_barrier();
-#pragma unroll
-      for (int j = 0; j < 4; ++j) part[g][j][lane] = acc[c][j];
-      lds_barrier();
-      const double v = tile_chi2_share(part[0][g][lane], part[1][g][lane], part[2][g][lane], part[3][g][lane]);
-      if (lane < 16) chi_tile[g][c * 16 + lane] = v;
+    for (int p = 0; p < PF; ++p) {
+      mfma_stage(p);
+      __builtin_amdgcn_sched_barrier(0);
+      if (p < rem) load_stage(p);
+      __builtin_amdgcn_sched_barrier(0);
     }
+  }
+#pragma unroll
+  for (int p = 0; p < PF - 1; ++p)
+    if (p < rem) mfma_stage(p);
+  CF_KLOOP_END(nq);
+  if (lane == 0) { CF_PHASE(2 * g + 1); }
+  // the four K quarters meet in LDS, one 16-walker panel at a time; wave g owns tile g: y, then the column sums of y^2
+#pragma unroll
+  for (int c = 0; c < NP; ++c) {
+    if (c > 0) lds_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[g][j][lane] = acc[c][j];
     lds_barrier();
-    // Hand-off between workgroups on different XCDs (their L2s are not coherent), in the form MI355X_MICROARCH.md lists as
-    // valid for gfx950 (Workgroup dispatch, XCD placement & inter-workgroup visibility: "Valid forms", first table row):
-    // producer -- wave 0 stores the unit's shares with agent-scope (sc1, write-through) stores HERE; its next service point
-    // waits until they are acknowledged (vmcnt, in issue order) and only then bumps the panel's arrival counter with an
-    // agent-scope atomic add by ONE lane.  Consumer -- the workgroup whose add returned n_rb - 1 came last: behind a workgroup
-    // barrier its lanes issue an agent-scope ACQUIRE fence and read every share back with agent-scope (sc1) loads
-    // (panel_last_arriver).  Nothing here waits for memory: the next K loop starts at once.
-    if (g == 0) {
-      if (lane < PW)
-        __hip_atomic_store(&partial[(int64_t)rb * w_pad + px * PW + lane],
-                           rowblock_share(chi_tile[0][lane], chi_tile[1][lane], chi_tile[2][lane], chi_tile[3][lane]), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      sig_px = px;
-    }
-    if (!has_next) break;
-    rb = rb2;
-    px = px2;
+    if (c == 0 && tid == 0) { CF_PHASE(8); }
+    const double v = tile_chi2_share(part[0][g][lane], part[1][g][lane], part[2][g][lane], part[3][g][lane]);
+    if (lane < 16) chi_tile[g][c * 16 + lane] = v;
   }
-  // drain: the last unit's signal, the last answer
-  if (g == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tid == 0) {
-      if (sig_px >= 0 &&
-          __hip_atomic_fetch_add(&arrivals[sig_px], 1u, CF_ARRIVE_ORDER, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)n_rb - 1u)
-        my_panels[n_mine++] = sig_px;
-      n_mine_all = n_mine;
-    }
-  }
-  // The panels this workgroup arrived last for are worked off BEHIND the unit loop, not inside it: inside, everything of the
-  // epilogue that does not change from unit to unit (per-lane share and theta addresses, the constants of its log) is hoisted in
-  // front of the loop and stays live across the K loop -- 158-236 VGPRs instead of 126, i.e. two or three workgroups per CU
-  // instead of four.  Units are pulled longest first, so a panel's last arrival is one of its shortest row blocks, at the tail
-  // of the queue: the epilogues wait microseconds.  The list holds every panel of the launch (the launcher cuts an evaluation into
-  // launches of at most CF_MY_PANELS panels), so it cannot overflow.
   lds_barrier();
+  if (tid == 0) { CF_PHASE(9); }
+  // Hand-off between workgroups on different XCDs (their L2s are not coherent), in the form MI355X_MICROARCH.md lists as
+  // valid for gfx950 (Workgroup dispatch, XCD placement & inter-workgroup visibility: "Valid forms", first table row):
+  // producer -- wave 0 stores the workgroup's shares with agent-scope (sc1, write-through) stores, drains them with
+  // s_waitcnt vmcnt(0) (inline asm with a memory clobber: the compiler may not move the stores or the add across it),
+  // then ONE lane bumps the panel's arrival counter with an agent-scope atomic add.  Consumer -- the workgroup whose
+  // add returned n_rb - 1 came last: behind the workgroup barrier its lanes issue an agent-scope ACQUIRE fence
+  // and read every share back with agent-scope (sc1) loads, add the row blocks in a fixed order (the result does not
+  // depend on which workgroup it was) and re-arm the counter for the next launch (panel_last_arriver).
+  if (g == 0) {
+    if (lane < PW)
+      __hip_atomic_store(&partial[(int64_t)rb * w_pad + w0 + lane],
+                         rowblock_share(chi_tile[0][lane], chi_tile[1][lane], chi_tile[2][lane], chi_tile[3][lane]), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of every lane of this wave have reached memory
+    if (tid == 0) { CF_PHASE(10); }
+    if (lane == 0)
+      arrived_before = __hip_atomic_fetch_add(&arrivals[px], 1u, CF_ARRIVE_ORDER, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  lds_barrier();
+  if (tid == 0) { CF_PHASE(11); }
   CF_CLOCK_STAMP(1);
   CF_KLOOP_STORE;
-  const int n_all = n_mine_all;
-  CF_CLOCK_COUNT(7, n_all);
   CF_CLOCK_COUNT(6, ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4));  // XCC_ID, HW_ID
-  for (int i = 0; i < n_all; ++i) {
-    panel_last_arriver<NP>(reinterpret_cast<double*>(part), epi, ndim, n_rb, theta, W, w_pad, partial, arrivals, chi2_extra, out, out_kind,
-                           nonfinite, chi2_sn_out, my_panels[i], done_flag, done_seq);
-    lds_barrier();  // the LDS copies are read: the next panel's may overwrite them
-  }
+  CF_CLOCK_COUNT(7, arrived_before == (unsigned)n_rb - 1u);
+  if (arrived_before != (unsigned)n_rb - 1u) return;
+  panel_last_arriver<NP>(reinterpret_cast<double*>(part), epi, ndim, n_rb, theta, W, w_pad, partial, arrivals, chi2_extra, out, out_kind,
+                         nonfinite, chi2_sn_out, px, done_flag, done_seq);
   CF_CLOCK_STAMP(2);
-  // the workgroup that leaves last re-arms the queues for the next launch: every pull of this launch lies before some workgroup's
-  // add to the leave counter (queue[256])
-  if (tid == 0 && __hip_atomic_fetch_add(queue + 256, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
-    for (int c = 0; c < 8; ++c) __hip_atomic_store(queue + 32 * c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(queue + 256, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
 }
 
 #define CF_INSTANTIATE_TRIGEMM(NP, PF)                                                                                              \
   template __global__ void tri_gemm_chi2_kernel<NP, PF>(const cf_epilogue*, const d2*, int, int, int, const double*, int64_t,       \
                                                         const double*, int64_t, double*, unsigned int*, const double*, double*, int, \
-                                                        unsigned long long*, double*, int, int, int, unsigned int*,                   \
-                                                        unsigned long long*, unsigned long long);
+                                                        unsigned long long*, double*, int, int, unsigned long long*, unsigned long long);
 CF_INSTANTIATE_TRIGEMM(1, 2)  // up to 512 walkers
 CF_INSTANTIATE_TRIGEMM(2, 2)  // beyond: an A fragment feeds two MFMAs
-CF_INSTANTIATE_TRIGEMM(1, 4)
-CF_INSTANTIATE_TRIGEMM(2, 4)
-CF_INSTANTIATE_TRIGEMM(2, 6)
 
 // ------------------------------------------------------------------------------------------------
 // The same solve for SMALL batches (W <= a few panels of 16 walkers: emcee's 16-walker half-steps of BASELINE configs[0],
