@@ -14,10 +14,12 @@ already resident in HBM; for N > 1 the step first all-gathers the walker positio
 to pick partners from the complementary set).  Rank 0 prints ONE JSON line.
 
 Workloads (BASELINE.json configs):
-  N = 1          configs[1]: Pantheon+ 1701-SN full-cov flat-LambdaCDM, 4096 walkers.
-  N = 2, 4       the same, 4096 walkers per GPU (weak scaling).
-  N = 8          configs[3]: 65536 walkers sharded over 8 GPUs = 8192 per GPU (override with --walkers-per-gpu).
-  --scaling strong: 65536 walkers in total at every N (65536 / N per GPU).
+  N = 1, 2, 4, 8   configs[1]: Pantheon+ 1701-SN full-cov flat-LambdaCDM, 4096 walkers PER GPU at every N (weak scaling: one
+                   per-GPU shape, so value_N / (N value_1) is one workload).
+  --scaling strong configs[3]: 65536 walkers in total at every N (65536 / N per GPU; at N = 8 that is 8192 per GPU).
+  --mode inprocess SURVEY 8e form (1): ONE host process, one handle over k devices (`--devices all` or a list of ordinals; an
+                   ordinal may repeat: a rehearsal on a one-GPU box, labelled as such), host numpy buffers through cf_eval,
+                   --walkers-total walkers per call (default 65536) -- how the reference's own scripts would run (sn/pantheon.py:119-125).
 Data are synthetic (the real covariance is not in the reference snapshot): see cosmology-model-fit_amd/synthetic.py.
 All arithmetic float64.
 """
@@ -40,13 +42,47 @@ def flops_per_eval_solve(n):
     return n * (n - 1) + 3 * n
 
 
+def plan(mode, scaling, world, walkers_per_gpu=None, walkers_total=65536, devices="all"):
+    """Walkers per GPU / in total, and the label of the run.  Pure arithmetic (tests/test_bench_cpu.py).
+    ranks + weak: `walkers_per_gpu` (default 4096) on every rank at EVERY world size -- one per-GPU shape across N.
+    ranks + strong: `walkers_total` over the ranks, whole 32-walker panels per rank.
+    inprocess: `walkers_total` per call of ONE handle over `devices`."""
+    if mode == "inprocess":
+        if world != 1:
+            raise ValueError("--mode inprocess is ONE process (do not start it under torch.distributed.run)")
+        devs = "all" if devices == "all" else [int(x) for x in str(devices).split(",") if x != ""]
+        if devs != "all" and (not devs or min(devs) < 0):
+            raise ValueError("--devices must be 'all' or a comma-separated list of HIP ordinals")
+        if walkers_total < 32:
+            raise ValueError("--walkers-total must be at least one 32-walker panel")
+        return {"mode": "inprocess", "devices": devs, "walkers_total": walkers_total, "walkers_per_gpu": None, "scaling": "strong",
+                "rehearsal": devs != "all" and len(set(devs)) < len(devs)}
+    if scaling == "strong":
+        if walkers_total % (32 * world):
+            raise ValueError("--walkers-total must be a multiple of 32 x the number of GPUs")
+        wl = walkers_total // world
+    else:
+        wl = walkers_per_gpu or 4096
+    return {"mode": "ranks", "devices": None, "walkers_total": wl * world, "walkers_per_gpu": wl, "scaling": scaling, "rehearsal": False}
+
+
+def executed_mfmas_solve(n_sn, walkers):
+    """v_mfma_f64_16x16x4_f64 instructions one launch of the inverse-GEMM solve executes: per 16-walker panel and 64-row block rb,
+    4 tiles x 16 (rb + 1) K-steps (the diagonal blocks and the rows N .. n_ld - 1 are computed in full: DESIGN 3.2)."""
+    n_rb = (n_sn + 63) // 64
+    return ((walkers + 15) // 16) * 64 * n_rb * (n_rb + 1) // 2
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--walkers-per-gpu", type=int, default=None,
-                    help="default: 4096 (BASELINE configs[1]); 8192 at N = 8 (configs[3]: 65536 walkers over 8 GPUs)")
+    ap.add_argument("--walkers-per-gpu", type=int, default=None, help="weak scaling: walkers per GPU, default 4096 (BASELINE configs[1]) at every N")
+    ap.add_argument("--mode", default="ranks", choices=["ranks", "inprocess"],
+                    help="ranks: one process per GPU (torch.distributed / RCCL), theta resident in HBM (the bench contract); inprocess: one "
+                         "process, one handle over --devices, host buffers through cf_eval (SURVEY 8e form 1)")
+    ap.add_argument("--devices", default="all", help='--mode inprocess: "all" or comma-separated HIP ordinals, e.g. 0,0,0,0 (rehearsal on one GPU)')
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: fixed walkers per GPU; strong: 65536 walkers in total (--walkers-total) at every N")
     ap.add_argument("--walkers-total", type=int, default=65536, help="ensemble size of --scaling strong")
@@ -69,6 +105,8 @@ def main():
                          "would batch it); both on the committed fixture data")
     args = ap.parse_args()
 
+    if args.mode == "inprocess":
+        return run_inprocess(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         # `python bench.py --gpus N`: this parent starts one child per GPU and never initialises a GPU itself
         import socket
@@ -126,13 +164,11 @@ def main():
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
     sn = pkg.sn_pantheon
-    if args.scaling == "strong":
-        if args.walkers_total % (32 * world):
-            sys.exit("--walkers-total must be a multiple of 32 x the number of GPUs")
-        Wl = args.walkers_total // world
-    else:
-        Wl = args.walkers_per_gpu or (8192 if world == 8 else 4096)
-    W_total = Wl * world
+    try:
+        shape = plan("ranks", args.scaling, world, args.walkers_per_gpu, args.walkers_total)
+    except ValueError as e:
+        sys.exit(str(e))
+    Wl, W_total = shape["walkers_per_gpu"], shape["walkers_total"]
 
     solve_kw = {} if args.solve == "default" else {"solve": args.solve}
     if args.workload == "desi_cmb_des5y":
@@ -222,12 +258,27 @@ def main():
     n_warm_samples = (args.warmup + stride - 1) // stride  # samples that fell into the W warm-up steps
     kms = kms[n_warm_samples:] or kms
     eng.enable_timing(0)
+    dt_by_rank, allgather_ms = [dt], None
     if use_dist:
+        # every rank's own clock around the K steps (value uses the MAX), and the exchange alone: K all-gathers with nothing else
+        own = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        per_rank = [torch.zeros_like(own) for _ in range(world)]
+        dist.all_gather(per_rank, own)
+        dt_by_rank = [float(x.item()) for x in per_rank]
         t = torch.tensor([dt, dt_idle or 0.0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, dt_idle = float(t[0].item()), (float(t[1].item()) if dt_idle is not None else None)
         got = theta_all.cpu().numpy()
         assert np.array_equal(got, theta_all_host), "all-gather of walker positions is wrong"
+        if backend == "nccl":
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                dist.all_gather_into_tensor(theta_all, theta_local)
+            fence()
+            ag = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(ag, op=dist.ReduceOp.MAX)
+            allgather_ms = float(ag.item()) / args.steps * 1e3
 
     result = logp.cpu().numpy()
     assert np.all(np.isfinite(result)), "in-box walkers must give a finite log-probability"
@@ -263,6 +314,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_by_rank": [x / args.steps * 1e3 for x in dt_by_rank],
+            "allgather_ms_per_step": allgather_ms,  # K all-gathers of the positions alone, max over ranks (None: no RCCL in this run)
+            "mode": "ranks",
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
@@ -302,7 +356,9 @@ def main():
             },
             "kernels_ms": {"walker_kernel": walker_ms, "small_blocks_kernel": blocks_ms if (args.workload != "pantheon") else None,
                            solve_kernel: solve_ms},
-            "kernel_timing": f"HIP events on the launch stream, every {stride}th of the {args.steps} timed steps ({len(kms)} samples)",
+            "kernel_timing": f"HIP events on the launch stream, every {stride}th of the {args.steps} timed steps ({len(kms)} samples); a "
+                             "sampled step pays for its four event records (profiles/r02_event_overhead.txt), so kernels_ms overstate the "
+                             "untimed steps' kernels by 0.5-2.5 % and may sum to more than ms_per_step; roofline.frac is that much conservative",
             "preconditioning": {"untimed_evaluations_before_warmup": n_pre, "ms": args.precondition_ms},
             "from_idle": None if dt_idle is None else {
                 "value": W_total * args.steps / dt_idle, "ms_per_step": dt_idle / args.steps * 1e3,
@@ -314,6 +370,20 @@ def main():
         # kernel / its duration (small by design: the factor is reused by every walker from L2 / Infinity Cache);
         # `trsv_equivalent_gbps` = what a design without reuse would have to stream (8 N (N+1) / 2 bytes per eval),
         # quoted for comparison with the CPU path only -- it exceeds the 8 TB/s HBM peak because of the reuse.
+        if solve_kernel == "tri_gemm_chi2_kernel":
+            # frac = mfma_busy x useful / executed x clock / 2.4 GHz: the matrix instructions the launch EXECUTES are arithmetic
+            # (diagonal blocks and padded rows in full), their 64 cycles each on 1024 SIMDs against the kernel's duration at the
+            # clock the chip holds under it (in-kernel s_memtime / s_memrealtime of the diagnostic build, replayed from profiles/)
+            n_mfma = executed_mfmas_solve(args.n_sn, Wl)
+            clock_ghz, clock_source, bare = replay_clock()
+            r = out["roofline"]
+            r["executed_tflops"] = n_mfma * 2048 / (solve_ms * 1e-3) / 1e12
+            r["useful_over_executed"] = solve_flops / (n_mfma * 2048.0)
+            r["clock_ghz"], r["clock_source"] = clock_ghz, clock_source
+            r["mfma_busy"] = n_mfma * 64 / 1024.0 / (solve_ms * 1e-3 * clock_ghz * 1e9) if clock_ghz else None
+            r["frac_factors"] = None if not clock_ghz else {"mfma_busy": r["mfma_busy"], "useful_over_executed": r["useful_over_executed"],
+                                                            "clock_over_2p4": clock_ghz / 2.4}
+            r["bare_mfma_loop_tflops"] = bare  # what a register-only v_mfma_f64_16x16x4_f64 loop sustains on this silicon (same source)
         out["roofline"]["hbm_gbps_measured"] = traffic / (solve_ms * 1e-3) / 1e9 if traffic else None
         out["roofline"]["trsv_equivalent_gbps"] = 8.0 * args.n_sn * (args.n_sn + 1) / 2 * out["value"] / 1e9
         if world == 1 and not args.no_cpu_baseline:  # context probes (this and cpu_baseline) stay out of profiled runs
@@ -371,6 +441,85 @@ def host_cpu():
     except OSError:
         pass
     return {"model": model, "logical_cpus": os.cpu_count(), "usable": len(os.sched_getaffinity(0))}
+
+
+def replay_clock():
+    """(in-kernel shader clock of the solve kernel in GHz, source file, bare-MFMA-loop TFLOP/s) from the newest committed
+    profiles/r*_solve_clock.json (tools/solve_clock.py with the diagnostic build + tools/coexec_f64_rate on the same box); Nones
+    when there is none.  The production kernel executes no stamp, so the number is replayed and labelled as such."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_solve_clock.json")), reverse=True):
+        try:
+            prof = json.load(open(path))
+            return float(prof["solve_kernel_clock_ghz_median"]), os.path.relpath(path, ROOT), prof.get("bare_mfma_loop_tflops")
+        except Exception:
+            continue
+    return None, None, None
+
+
+def run_inprocess(args):
+    """SURVEY 8e form (1): the sampler's host process holds ONE handle over k devices and calls the vectorised callback with
+    host numpy buffers; cf_eval cuts the rows into contiguous slices of whole panels, one host thread + stream per device."""
+    import torch
+
+    if "RANK" in os.environ:
+        sys.exit("--mode inprocess is ONE process: do not start it under torch.distributed.run")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no HIP device visible); there is no CPU path to time instead")
+    if args.workload != "pantheon":
+        sys.exit("--mode inprocess times the headline workload (pantheon)")
+    try:
+        shape = plan("inprocess", args.scaling, 1, None, args.walkers_total, args.devices)
+    except ValueError as e:
+        sys.exit(str(e))
+    pkg = importlib.import_module("cosmology-model-fit_amd")
+    sn = pkg.sn_pantheon
+    syn = pkg.synthetic.pantheon_like(n_sn=args.n_sn, seed=0)
+    lk = sn.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"], devices=shape["devices"])
+    info = lk.engine.info()
+    devs = list(info["devices"])
+    W = shape["walkers_total"]
+    theta = pkg.synthetic.walkers(sn.bounds, W, seed=0)
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.precondition_ms:
+        lk.log_probs_vectorized(theta)
+    for _ in range(args.warmup):
+        lk.log_probs_vectorized(theta)
+    cpu0, t0 = time.process_time(), time.perf_counter()
+    for _ in range(args.steps):
+        res = lk.log_probs_vectorized(theta)
+    dt, cpu = time.perf_counter() - t0, time.process_time() - cpu0
+    assert np.all(np.isfinite(res))
+    one = sn.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"], device=devs[0])
+    assert np.array_equal(one.log_probs_vectorized(theta[:4096]), res[:4096]), "replicas changed a walker's result"
+    solve_flops = flops_per_eval_solve(args.n_sn) * W
+    idents = []
+    for d in sorted(set(devs)):
+        pr = torch.cuda.get_device_properties(d)
+        idents.append("%s pci %04x:%02x:%02x uuid %s" % (pr.name, getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0),
+                                                          getattr(pr, "pci_device_id", 0), getattr(pr, "uuid", "?")))
+    n_phys = len(set(devs))
+    out = {
+        "metric": "walker-logL evals/s, Pantheon+ 1701-SN full-cov chi2, host numpy buffers through ONE handle over k devices (cf_eval)",
+        "value": W * args.steps / dt, "unit": "evals/s", "n_gpus": n_phys, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic", "mode": "inprocess",
+        "config": {"workload": f"Pantheon+-shaped {args.n_sn}-SN full-cov flat-LCDM chi2 + prior, {W} walkers per call of ONE handle over "
+                               f"{len(devs)} replica(s) on {n_phys} physical GPU(s) (SURVEY 8e form 1: sn/pantheon.py:119-125's dispatch as one batched call)",
+                   "walkers_total": W, "n_sn": args.n_sn, "n_grid": 4000, "ndim": 4, "replicas": devs,
+                   "parallelism": f"rows of theta split over {len(devs)} replicas (cf_split_rows), one host thread + stream each, no collective",
+                   "rehearsal": "ordinals repeat: the replicas SHARE a GPU -- the split / threads / streams are exercised, the rate is not a k-GPU rate"
+                   if shape["rehearsal"] else None},
+        "device_ids": idents, "distinct_devices": n_phys,
+        "host_cpu_seconds_per_call": cpu / args.steps,  # all host threads of this process (the waiting policy: DESIGN section 6)
+        "roofline": {"kernel": "tri_gemm_chi2_kernel (whole call: H2D + kernels + D2H + sync on every replica)", "bound": "mfma",
+                     "achieved": solve_flops / (dt / args.steps) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS * n_phys, "unit": "TFLOP/s",
+                     "frac": solve_flops / (dt / args.steps) / 1e12 / (FP64_MFMA_PEAK_TFLOPS * n_phys), "traffic": None},
+    }
+    print(json.dumps(out), flush=True)
+    lk.engine.close()
+    one.engine.close()
 
 
 def pmc_traffic(workload, n_sn, walkers, kernel):

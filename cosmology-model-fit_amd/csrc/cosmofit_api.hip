@@ -4,6 +4,7 @@
 // handle, and the launches of the kernels in cosmofit_kernels.hip.  There is NO CPU evaluation
 // path here: without a HIP device every entry point returns CF_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <sys/prctl.h>
 
 #include <cmath>
 #include <cstdio>
@@ -960,7 +961,7 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
   return CF_OK;
 }
 
-static int eval_host_single(cf_handle* h, const double* theta, int64_t W, double* out, int out_kind);
+static int eval_host_single(cf_handle* h, const double* theta, int64_t W, double* out, int out_kind, bool worker_thread = false);
 
 // Worker thread of one replica: waits for a slice, evaluates it on its device, reports the status.
 static void worker_main(cf_handle* replica, cf_worker* w) {
@@ -970,7 +971,7 @@ static void worker_main(cf_handle* replica, cf_worker* w) {
     if (w->quit) return;
     w->has_job = false;
     lk.unlock();
-    const int rc = eval_host_single(replica, w->theta, w->W, w->out, w->out_kind);
+    const int rc = eval_host_single(replica, w->theta, w->W, w->out, w->out_kind, true);
     const std::string err = rc ? g_err : std::string();
     lk.lock();
     w->rc = rc;
@@ -1395,24 +1396,36 @@ extern "C" int cf_eval_device(cf_handle* h, const double* d_theta, int64_t W, do
   return launch_path(h, d_theta, W, d_out, out_kind, (hipStream_t)hip_stream, nullptr, nullptr, nullptr, nullptr);
 }
 
-// Wait for the handle's stream from a synchronous host call: poll (hipStreamQuery) for up to 5 ms before blocking -- a
-// blocking hipStreamSynchronize sleeps on an interrupt and adds tens of microseconds to a call that takes 0.07-0.3 ms, and
-// the caller (an MCMC step) has nothing else to do meanwhile.  CF_HOST_WAIT=block restores the plain blocking wait.
-static int wait_stream(hipStream_t st) {
-#ifndef CF_HOST_WAIT_BLOCK
-  static const bool block = [] { const char* e = getenv("CF_HOST_WAIT"); return e && !strcmp(e, "block"); }();
-  if (!block) {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-      const hipError_t q = hipStreamQuery(st);
-      if (q == hipSuccess) return 0;
-      if (q != hipErrorNotReady) return fail(CF_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
-    }
+// Wait for the handle's stream from a synchronous host call.  hipStreamSynchronize is no option either way: it SPINS a core for
+// the whole wait on this runtime (8 replica threads "blocked" in it burn 23 ms of CPU per 3.85 ms call, profiles/r04_host_wait.txt),
+// and where it does sleep it adds tens of microseconds to a call of 0.03-0.3 ms.  So the wait is a hipStreamQuery poll:
+//   * the CALLING thread (replica 0; the only thread of a one-device handle) spins for the first 300 us -- every batch a sampler
+//     waits for with nothing else to do (up to ~4096 walkers) ends inside that window, at no added latency;
+//   * a WORKER thread of a multi-device handle spins 50 us only: its slice is a large batch by construction (cf_eval sends batches
+//     of <= 32 walkers to replica 0 alone), eight spinning threads are eight cores taken from the sampler's process;
+//   * after that both sleep between polls, 1/16 of the time waited so far, at most 50 us: a 3.8 ms slice is noticed <= 50 us
+//     (1.3 %) late for ~2 % of a core instead of 100 %.
+// CF_HOST_WAIT=spin polls without ever sleeping (round-3 behaviour), CF_HOST_WAIT=block calls hipStreamSynchronize.
+static int wait_stream(hipStream_t st, bool worker_thread) {
+  static const int mode = [] { const char* e = getenv("CF_HOST_WAIT"); return !e ? 0 : !strcmp(e, "spin") ? 1 : !strcmp(e, "block") ? 2 : 0; }();
+  if (mode == 2) {
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
   }
-#endif
-  HIP_TRY(hipStreamSynchronize(st));
-  return 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  const auto spin = std::chrono::microseconds(worker_thread ? 50 : 300);
+  for (;;) {
+    const hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess) return 0;
+    if (q != hipErrorNotReady) return fail(CF_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+    const auto waited = std::chrono::steady_clock::now() - t0;
+    if (mode == 1 || waited < spin) continue;
+    // (the default timer slack of a thread, 50 us, would turn every short sleep into 60-110 us: 4.14 against 3.78 ms per call of an
+    // eight-replica handle; with 1 us of slack a 10 us sleep is 12-15 us)
+    static thread_local const bool slack_set = [] { return prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0) == 0; }();
+    (void)slack_set;
+    std::this_thread::sleep_for(std::min<std::chrono::nanoseconds>(waited / 16, std::chrono::microseconds(50)));
+  }
 }
 
 // Spin on the words the evaluation's last kernel sets (pinned host memory) for up to ~1 ms; false = not seen (the caller
@@ -1443,7 +1456,7 @@ static bool wait_done_flags(cf_handle* h) {
 }
 
 // One replica, host buffers: stage through the handle's pinned block, run on the handle's stream, wait.
-static int eval_host_single(cf_handle* h, const double* theta, int64_t W, double* out, int out_kind) {
+static int eval_host_single(cf_handle* h, const double* theta, int64_t W, double* out, int out_kind, bool worker_thread) {
   int rc;
   std::lock_guard<std::mutex> lk(h->mu);
   HIP_TRY(hipSetDevice(h->device));
@@ -1471,7 +1484,7 @@ static int eval_host_single(cf_handle* h, const double* theta, int64_t W, double
       return rc;
     HIP_TRY(hipMemcpyAsync(h->stage_out.p, h->out.p, (size_t)W * 8, hipMemcpyDeviceToHost, h->stream));
   }
-  if ((rc = wait_stream(h->stream))) return rc;
+  if ((rc = wait_stream(h->stream, worker_thread))) return rc;
   memcpy(out, h->stage_out.p, (size_t)W * 8);
   return CF_OK;
 }

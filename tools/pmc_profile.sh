@@ -14,6 +14,6 @@ for grp in \
   "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum" \
   "GRBM_GUI_ACTIVE GRBM_COUNT" ; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/pass$i -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --precondition-ms 0 "$@" > $out/pass$i.json 2> $out/pass$i.err || { echo "pass $i failed"; tail -5 $out/pass$i.err; }
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/pass$i -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > $out/pass$i.json 2> $out/pass$i.err || { echo "pass $i failed"; tail -5 $out/pass$i.err; }
 done
 python tools/pmc_summary.py $out

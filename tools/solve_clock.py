@@ -19,6 +19,7 @@ syn = pkg.synthetic.pantheon_like(n_sn=1701, seed=0)
 lk = pkg.sn_pantheon.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"])
 import torch
 
+results = {}
 for W in [int(a) for a in sys.argv[1:]] or [4096]:
     assert W <= 4096, "the stamp buffers hold 4096 workgroups"
     th = torch.from_numpy(pkg.synthetic.walkers(pkg.sn_pantheon.bounds, W, seed=0)).cuda()
@@ -77,4 +78,19 @@ for W in [int(a) for a in sys.argv[1:]] or [4096]:
     # the first 1024 workgroups: does block b sit with b + 256, b + 512, b + 768 (static placement of a resident grid)?
     same = np.mean([cu[i] == cu[i + 256] for i in range(min(256, n - 256))]) if n > 256 else float("nan")
     print("  blocks b and b + 256 on the same CU: %.0f %%" % (100 * same))
+    results[W] = {"kernel_span_us": float(end.max()), "clock_ghz_median": float(np.median(clk[long_])), "clock_ghz_p10_p90": [float(x) for x in np.percentile(clk[long_], [10, 90])],
+                  "share_of_wave_life_in_k_loops": float(kb[:, 0].sum() / life.sum()), "cycles_per_mfma_in_k_loops": float(kb[:, 0].sum() / mfmas.sum()),
+                  "idle_cu_fraction_at_the_end": float((cu_end.max() - cu_end).mean() / end.max()), "mean_workgroups_resident_per_cu": float(busy_wg.sum() / len(ids) / end.max())}
 lk.engine.close()
+if os.environ.get("OUT_JSON"):
+    import json, re
+    bare = None
+    if os.environ.get("BARE_TXT") and os.path.exists(os.environ["BARE_TXT"]):  # tools/coexec_f64_rate output of the same box
+        bare = {m.group(1) + " waves/SIMD": {"tflops": float(m.group(2)), "clock_ghz": float(c)} for c, m in
+                ((re.search(r"clock ([\d.]+) GHz", l).group(1), re.search(r"MFMA ([\d.]+) waves/SIMD: ([\d.]+) TFLOP/s", l))
+                 for l in open(os.environ["BARE_TXT"]) if "roles=0" in l and "MFMA" in l)}
+    w = 4096 if 4096 in results else max(results)
+    json.dump({"method": "diagnostic build (-DCF_DIAG_CLOCK): s_memtime / s_memrealtime x 100 MHz per workgroup of tri_gemm_chi2_kernel after >= 2 s of "
+                         "back-to-back evaluations, median over the longer half of the workgroups; bare loop: tools/coexec_f64_rate on the same box",
+               "solve_kernel_clock_ghz_median": results[w]["clock_ghz_median"], "walkers": w, "by_batch_size": {str(k): v for k, v in results.items()},
+               "bare_mfma_loop_tflops": bare}, open(os.environ["OUT_JSON"], "w"), indent=1)
