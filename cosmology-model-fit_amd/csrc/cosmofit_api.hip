@@ -161,7 +161,7 @@ template <int NP, int PF>
 __global__ void tri_gemm_chi2_kernel(const cf_epilogue* epi, const d2* frags, int n_ld, int ndim, int n_rb, const double* theta, int64_t W,
                                      const double* delta, int64_t w_pad, double* partial, unsigned int* arrivals, const double* chi2_extra,
                                      double* out, int out_kind, unsigned long long* nonfinite, double* chi2_sn_out, int panels_per_group,
-                                     int snake, unsigned long long* done_flag, unsigned long long done_seq);
+                                     int snake, int nt_last, unsigned long long* done_flag, unsigned long long done_seq);
 template <int PF, bool FRAG, int TPW>
 __global__ void tri_gemm_small_kernel(const cf_epilogue* epi, const d2* frags, int n_ld, int ndim, int n_rb, const double* theta, int64_t W,
                                       const double* delta, double* partial4, unsigned int* arrivals, const double* chi2_extra, double* out,
@@ -178,7 +178,7 @@ CF_DECLARE_TRIGEMM_SMALL(8, false, 2)
 #define CF_DECLARE_TRIGEMM(NP, PF)                                                                                                       \
   extern template __global__ void tri_gemm_chi2_kernel<NP, PF>(const cf_epilogue*, const d2*, int, int, int, const double*, int64_t,     \
                                                                const double*, int64_t, double*, unsigned int*, const double*, double*,  \
-                                                               int, unsigned long long*, double*, int, int, unsigned long long*,        \
+                                                               int, unsigned long long*, double*, int, int, int, unsigned long long*,   \
                                                                unsigned long long);
 CF_DECLARE_TRIGEMM(1, 2)
 CF_DECLARE_TRIGEMM(2, 2)
@@ -1141,6 +1141,7 @@ struct TriGemmArgs {
   const cf_epilogue* epi;
   const d2* frags;
   int n_ld, ndim, n_rb;
+  int nt_last;  // 16-row tiles of the last row block that hold rows of the factor (the others are padding)
   const double* theta;
   int64_t W;
   const double* delta;
@@ -1183,7 +1184,7 @@ static int launch_tri_gemm_t(const TriGemmArgs& a, hipStream_t st) {
   const int snake = order_env >= 0 ? order_env : (n_wgs <= 1024 ? 1 : 0);
   hipLaunchKernelGGL((tri_gemm_chi2_kernel<NP, PF>), dim3((unsigned)n_wgs), dim3(256), 0, st, a.epi, a.frags, a.n_ld, a.ndim, a.n_rb, a.theta,
                      a.W, a.delta, a.w_pad, a.partial, a.arrivals, a.chi2_extra, a.out, a.out_kind, a.nonfinite, a.chi2_sn_out, ppg, snake,
-                     a.done_flag, a.done_seq);
+                     a.nt_last, a.done_flag, a.done_seq);
   return 0;
 }
 
@@ -1309,7 +1310,9 @@ static int launch_eval(cf_handle* h, const double* th, int64_t Wc, double* out, 
   }
   if (ev) HIP_TRY(hipEventRecord(ev[2], st));
   if (d.n_sn > 0 && h->solve_mode == CF_SOLVE_INVERSE_GEMM) {
-    TriGemmArgs a{h->epi.as<const cf_epilogue>(), h->ipack.dev.frags, d.n_ld, d.ndim, h->ipack.dev.n_rowblocks, th, Wc, delta,
+    static const bool trim = cf_tune("gemm_trim", 1) != 0;  // 0: the padded tiles of the last row block are computed (A/B)
+    const int n_rb_ = h->ipack.dev.n_rowblocks, nt_last = trim ? std::max(1, std::min(4, (d.n_pad - 64 * (n_rb_ - 1)) / 16)) : 4;
+    TriGemmArgs a{h->epi.as<const cf_epilogue>(), h->ipack.dev.frags, d.n_ld, d.ndim, n_rb_, nt_last, th, Wc, delta,
                   h->max_walkers, h->partial.as<double>(), h->arrivals.as<unsigned int>(), extra, out,
                   out_kind, nf, chi2_sn_out, h->partial4.as<double>(), nullptr, 0ull, frag_b};
     // a synchronous zero-copy call: the solve kernel's last arrivers set one word per panel in pinned host memory and the host

@@ -20,6 +20,7 @@
 // batch fills the chip, one or two waves per walker below, the same bits either way) and growth_kernel (f sigma_8) between
 // the two.  A walker's result never depends on the batch it is evaluated in.  Written for wave64 / gfx950 only.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "cosmofit_device.h"
@@ -186,6 +187,15 @@ __device__ __forceinline__ double e2_of_z(const D& d, const WalkerCosmo& wc, dou
     if (nu < 0.0) nu = omnu_z(d, zp1);
   }
   return wc.Or * (cubed * zp1) + wc.Obc * cubed + de + wc.Onu * nu;  // bao/desi_cmb_des5y.py:43-48
+}
+
+// E^2(z) from a dark-energy density ratio f already in hand and the node's tabulated massive-neutrino density (table build).
+template <int MODEL>
+__device__ __forceinline__ double e2_from_fde(const WalkerCosmo& wc, double z, double f, double nu) {
+  const double zp1 = 1.0 + z;
+  const double cubed = zp1 * zp1 * zp1;
+  if (MODEL == CF_EZ_LATE_FLAT_D) return wc.Om * cubed + (1.0 - wc.Om) * f;
+  return wc.Or * (cubed * zp1) + wc.Obc * cubed + wc.Ode * f + wc.Onu * nu;  // bao/desi_cmb_des5y.py:43-48
 }
 
 // H(z) in the reference's form H0 * sqrt(E^2) (used where only a few values are needed).
@@ -432,12 +442,55 @@ __device__ __forceinline__ double chunk_eval(const D& d, const WalkerCosmo& wc, 
   const int G = d.n_grid;
   // nu_pre / ln: the tabulated neutrino density and ln(1 + z) of the nodes (theta-independent tables, fetched by the kernel
   // before anything else); the tables exist whenever the model needs them (cf_create), so no fallback is compiled in
+  constexpr bool POWER_LAW = FDE == CF_FDE_WCDM_D || FDE == CF_FDE_CPL_D;
+  double fde[CH];
+  if (POWER_LAW) {
+    // The dark-energy density of a thread's CH consecutive nodes: f = exp(x), x = 3 (1 + w0 + wa) ln(1 + z) - 3 wa z / (1 + z)
+    // (wCDM: wa = 0).  ONE table-driven exp (17 instructions) for the first node; from node to node x moves by
+    // |dx| <= 3 |1 + w0 + wa| dz / (1 + z) + 3 |wa| dz < 0.02 on a 4000-node grid inside any prior box of the scripts, so
+    // f_k = f_(k-1) (1 + expm1(dx)) with a degree-7 series (|dx|^8 / 8! < 2.3e-17 below the 2^-5 guard): 8 instead of 17
+    // instructions per node, the chain of CH - 1 products costs <= (CH - 1) ulp (profiles/r04_fde_chain_ab.txt).
+    double x[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int g = g0 + k;
+      double z = (double)g * d.step;
+      if (LAST) z = g >= G - 1 ? d.z_max : z;
+      if (FDE == CF_FDE_CPL_D) {  // z / (1 + z) through a refined reciprocal (1 + z in [1, 1 + z_max]: no special cases), <= 1 ulp from the quotient
+        const double zp1 = 1.0 + z;
+        double r = __builtin_amdgcn_rcp(zp1);
+        r = fma(fma(-zp1, r, 1.0), r, r);
+        x[k] = fma(3 * (1 + wc.w0 + wc.wa), ln[k], (-3 * wc.wa) * (z * r));
+      } else {
+        x[k] = 3 * (1 + wc.w0) * ln[k];
+      }
+    }
+    fde[0] = exp_tab(x[0], etab);
+    double dx_max = 0.0;
+#pragma unroll
+    for (int k = 1; k < CH; ++k) {
+      const double dx = x[k] - x[k - 1];
+      dx_max = fmax(dx_max, fabs(dx));
+      double p = fma(dx, 1.0 / 5040, 1.0 / 720);
+      p = fma(p, dx, 1.0 / 120);
+      p = fma(p, dx, 1.0 / 24);
+      p = fma(p, dx, 1.0 / 6);
+      p = fma(p, dx, 0.5);
+      p = fma(p * dx, dx, dx);  // expm1(dx)
+      fde[k] = fma(fde[k - 1], p, fde[k - 1]);
+    }
+    if (!(dx_max < 0x1p-5)) {  // a coarse grid or an extreme prior box: the series does not apply, an exp per node (NaN lands here too)
+#pragma unroll
+      for (int k = 1; k < CH; ++k) fde[k] = exp_tab(x[k], etab);
+    }
+  }
 #pragma unroll
   for (int k = 0; k < CH; ++k) {
     const int g = g0 + k;
     double z = (double)g * d.step;
     if (LAST) z = g >= G - 1 ? d.z_max : z;
-    const double v = c_over_H0 * rsqrt_pos(e2_of_z<MODEL, FDE, true, D>(d, wc, z, nu_pre[k], ln[k], etab));
+    const double e2 = POWER_LAW ? e2_from_fde<MODEL>(wc, z, fde[k], nu_pre[k]) : e2_of_z<MODEL, FDE, true, D>(d, wc, z, nu_pre[k], ln[k], etab);
+    const double v = c_over_H0 * rsqrt_pos(e2);
     dh[k] = (LAST && g >= G) ? 0.0 : v;
   }
   double prev = dpp_move<0x138, 0xF>(dh[CH - 1]);  // wave_shr:1; lane 0 gets 0 and skips its first interval
@@ -1916,7 +1969,7 @@ __global__ void __launch_bounds__(256, 4)  // four workgroups per CU: 128 VGPRs
 tri_gemm_chi2_kernel(const cf_epilogue* __restrict__ epi, const d2* __restrict__ frags, int n_ld, int ndim, int n_rb,
                      const double* __restrict__ theta, int64_t W, const double* __restrict__ delta, int64_t w_pad, double* partial,
                      unsigned int* arrivals, const double* __restrict__ chi2_extra, double* __restrict__ out, int out_kind,
-                     unsigned long long* nonfinite, double* __restrict__ chi2_sn_out, int panels_per_group, int snake,
+                     unsigned long long* nonfinite, double* __restrict__ chi2_sn_out, int panels_per_group, int snake, int nt_last,
                      unsigned long long* done_flag, unsigned long long done_seq) {
   __shared__ __align__(16) d4 part[4][4][64];  // [wave][tile][lane] of one 16-walker panel: 32 KB
   __shared__ double chi_tile[4][16 * NP];
@@ -1956,58 +2009,69 @@ tri_gemm_chi2_kernel(const cf_epilogue* __restrict__ epi, const d2* __restrict__
   // PF-deep software pipeline over the nq K-step pairs.  Nothing is loaded past the wave's K range (but for row
   // block 0, covered by the buffers' slack): a load that nobody consumes still has to land before the wave may
   // retire, and it misses every cache.
-  d2 a[PF][4], bf[PF][NP];
-  auto load_stage = [&](int p) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) a[p][j] = A[(p * 4 + j) * 64];
-#pragma unroll
-    for (int c = 0; c < NP; ++c) bf[p][c] = Bq[c * bstride + p * 4];
-  };
-  auto mfma_stage = [&](int p) {
-#pragma unroll
-    for (int c = 0; c < NP; ++c)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[c][j] = mfma_f64(a[p][j].x, bf[p][c].x, acc[c][j]);
-#pragma unroll
-    for (int c = 0; c < NP; ++c)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[c][j] = mfma_f64(a[p][j].y, bf[p][c].y, acc[c][j]);
-  };
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int p = 0; p < PF; ++p) {
-    load_stage(p);  // unconditional (a guard costs hipcc its exact vmcnt bookkeeping); only row block 0 has nq < PF
-    __builtin_amdgcn_sched_barrier(0);  // stage 0 must be the oldest load
-  }
-  A += PF * 4 * 64;
-  Bq += PF * 4;
-  const int n_groups = nq / PF, rem = nq - n_groups * PF;
+  // NT = the 16-row tiles of the row block that hold rows of the factor: 4, but for the LAST row block, whose rows N .. n_ld - 1
+  // are padding -- N = 1701: one of its four tiles is nothing else (1.8 % of the launch's matrix instructions, on its 128 longest
+  // units), N = 1820: two (3.3 %).  A padded tile's accumulators stay zero, which is what multiplying by the zero rows gives.
   CF_KLOOP_DECL;
-  CF_KLOOP_BEGIN;
-  if (lane == 0) { CF_PHASE(2 * g); }
-  for (int kg = 0; kg + 1 < n_groups; ++kg) {  // branch-free body: a guard around the MFMAs makes hipcc drain vmcnt(0) per stage
+  auto k_loop = [&](auto nt_const) {
+    constexpr int NT = decltype(nt_const)::value;
+    d2 a[PF][NT], bf[PF][NP];
+    auto load_stage = [&](int p) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) a[p][j] = A[(p * 4 + j) * 64];
+#pragma unroll
+      for (int c = 0; c < NP; ++c) bf[p][c] = Bq[c * bstride + p * 4];
+    };
+    auto mfma_stage = [&](int p) {
+#pragma unroll
+      for (int c = 0; c < NP; ++c)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[c][j] = mfma_f64(a[p][j].x, bf[p][c].x, acc[c][j]);
+#pragma unroll
+      for (int c = 0; c < NP; ++c)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[c][j] = mfma_f64(a[p][j].y, bf[p][c].y, acc[c][j]);
+    };
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
-      mfma_stage(p);
-      __builtin_amdgcn_sched_barrier(0);
-      load_stage(p);
-      __builtin_amdgcn_sched_barrier(0);
+      load_stage(p);  // unconditional (a guard costs hipcc its exact vmcnt bookkeeping); only row block 0 has nq < PF
+      __builtin_amdgcn_sched_barrier(0);  // stage 0 must be the oldest load
     }
     A += PF * 4 * 64;
     Bq += PF * 4;
-  }
-  if (n_groups > 0) {  // last full group: only the nq % PF pairs of the tail are still to be fetched
+    const int n_groups = nq / PF, rem = nq - n_groups * PF;
+    CF_KLOOP_BEGIN;
+    if (lane == 0) { CF_PHASE(2 * g); }
+    for (int kg = 0; kg + 1 < n_groups; ++kg) {  // branch-free body: a guard around the MFMAs makes hipcc drain vmcnt(0) per stage
 #pragma unroll
-    for (int p = 0; p < PF; ++p) {
-      mfma_stage(p);
-      __builtin_amdgcn_sched_barrier(0);
-      if (p < rem) load_stage(p);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int p = 0; p < PF; ++p) {
+        mfma_stage(p);
+        __builtin_amdgcn_sched_barrier(0);
+        load_stage(p);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      A += PF * 4 * 64;
+      Bq += PF * 4;
     }
-  }
+    if (n_groups > 0) {  // last full group: only the nq % PF pairs of the tail are still to be fetched
 #pragma unroll
-  for (int p = 0; p < PF - 1; ++p)
-    if (p < rem) mfma_stage(p);
+      for (int p = 0; p < PF; ++p) {
+        mfma_stage(p);
+        __builtin_amdgcn_sched_barrier(0);
+        if (p < rem) load_stage(p);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < PF - 1; ++p)
+      if (p < rem) mfma_stage(p);
+  };
+  const int nt = rb == n_rb - 1 ? nt_last : 4;
+  if (nt == 4) k_loop(std::integral_constant<int, 4>{});
+  else if (nt == 3) k_loop(std::integral_constant<int, 3>{});
+  else if (nt == 2) k_loop(std::integral_constant<int, 2>{});
+  else k_loop(std::integral_constant<int, 1>{});
   CF_KLOOP_END(nq);
   if (lane == 0) { CF_PHASE(2 * g + 1); }
   // the four K quarters meet in LDS, one 16-walker panel at a time; wave g owns tile g: y, then the column sums of y^2
@@ -2056,7 +2120,8 @@ tri_gemm_chi2_kernel(const cf_epilogue* __restrict__ epi, const d2* __restrict__
 #define CF_INSTANTIATE_TRIGEMM(NP, PF)                                                                                              \
   template __global__ void tri_gemm_chi2_kernel<NP, PF>(const cf_epilogue*, const d2*, int, int, int, const double*, int64_t,       \
                                                         const double*, int64_t, double*, unsigned int*, const double*, double*, int, \
-                                                        unsigned long long*, double*, int, int, unsigned long long*, unsigned long long);
+                                                        unsigned long long*, double*, int, int, int, unsigned long long*,             \
+                                                        unsigned long long);
 CF_INSTANTIATE_TRIGEMM(1, 2)  // up to 512 walkers
 CF_INSTANTIATE_TRIGEMM(2, 2)  // beyond: an A fragment feeds two MFMAs
 
