@@ -66,11 +66,19 @@ def plan(mode, scaling, world, walkers_per_gpu=None, walkers_total=65536, device
     return {"mode": "ranks", "devices": None, "walkers_total": wl * world, "walkers_per_gpu": wl, "scaling": scaling, "rehearsal": False}
 
 
-def executed_mfmas_solve(n_sn, walkers):
-    """v_mfma_f64_16x16x4_f64 instructions one launch of the inverse-GEMM solve executes: per 16-walker panel and 64-row block rb,
-    4 tiles x 16 (rb + 1) K-steps (the diagonal blocks and the rows N .. n_ld - 1 are computed in full: DESIGN 3.2)."""
+def executed_mfmas_solve(n_sn, walkers, skip_padding=True):
+    """v_mfma_f64_16x16x4_f64 instructions one launch of the inverse-GEMM solve executes.  Per 16-walker panel and 64-row block rb:
+    4 tiles x 16 (rb + 1) K-steps; with `skip_padding` (the library's default) less the all-padding tiles of the last row
+    block (16 n_rb K-steps each) and the zero tiles of every diagonal block (6 tile-groups of 4 K-steps; of the last block only those
+    of its kept tiles)."""
     n_rb = (n_sn + 63) // 64
-    return ((walkers + 15) // 16) * 64 * n_rb * (n_rb + 1) // 2
+    per_panel = 64 * n_rb * (n_rb + 1) // 2
+    if skip_padding:
+        nt_last = max(1, min(4, ((n_sn + 15) // 16 * 16 - 64 * (n_rb - 1)) // 16))
+        zero_groups = lambda nt: nt * (nt - 1) // 2  # tile j of a diagonal block skips the groups m > j: sum over kept tiles of (nt - 1 - j) ... = nt (nt - 1) / 2
+        per_panel -= (4 - nt_last) * 16 * n_rb                      # padded tiles of the last row block
+        per_panel -= 4 * ((n_rb - 1) * zero_groups(4) + (zero_groups(4) - sum(3 - j for j in range(nt_last, 4))))
+    return ((walkers + 15) // 16) * per_panel
 
 
 def main():

@@ -161,7 +161,7 @@ template <int NP, int PF>
 __global__ void tri_gemm_chi2_kernel(const cf_epilogue* epi, const d2* frags, int n_ld, int ndim, int n_rb, const double* theta, int64_t W,
                                      const double* delta, int64_t w_pad, double* partial, unsigned int* arrivals, const double* chi2_extra,
                                      double* out, int out_kind, unsigned long long* nonfinite, double* chi2_sn_out, int panels_per_group,
-                                     int snake, int nt_last, unsigned long long* done_flag, unsigned long long done_seq);
+                                     int snake, int nt_last, int diag_skip, unsigned long long* done_flag, unsigned long long done_seq);
 template <int PF, bool FRAG, int TPW>
 __global__ void tri_gemm_small_kernel(const cf_epilogue* epi, const d2* frags, int n_ld, int ndim, int n_rb, const double* theta, int64_t W,
                                       const double* delta, double* partial4, unsigned int* arrivals, const double* chi2_extra, double* out,
@@ -178,8 +178,8 @@ CF_DECLARE_TRIGEMM_SMALL(8, false, 2)
 #define CF_DECLARE_TRIGEMM(NP, PF)                                                                                                       \
   extern template __global__ void tri_gemm_chi2_kernel<NP, PF>(const cf_epilogue*, const d2*, int, int, int, const double*, int64_t,     \
                                                                const double*, int64_t, double*, unsigned int*, const double*, double*,  \
-                                                               int, unsigned long long*, double*, int, int, int, unsigned long long*,   \
-                                                               unsigned long long);
+                                                               int, unsigned long long*, double*, int, int, int, int,                   \
+                                                               unsigned long long*, unsigned long long);
 CF_DECLARE_TRIGEMM(1, 2)
 CF_DECLARE_TRIGEMM(2, 2)
 extern "C" __global__ void finalize_kernel(cf_epilogue d, const double* theta, int64_t W, const double* chi2_extra,
@@ -1142,6 +1142,7 @@ struct TriGemmArgs {
   const d2* frags;
   int n_ld, ndim, n_rb;
   int nt_last;  // 16-row tiles of the last row block that hold rows of the factor (the others are padding)
+  int diag_skip;  // 1: wave 3 skips the all-zero tiles of the diagonal block's K-step pairs
   const double* theta;
   int64_t W;
   const double* delta;
@@ -1184,7 +1185,7 @@ static int launch_tri_gemm_t(const TriGemmArgs& a, hipStream_t st) {
   const int snake = order_env >= 0 ? order_env : (n_wgs <= 1024 ? 1 : 0);
   hipLaunchKernelGGL((tri_gemm_chi2_kernel<NP, PF>), dim3((unsigned)n_wgs), dim3(256), 0, st, a.epi, a.frags, a.n_ld, a.ndim, a.n_rb, a.theta,
                      a.W, a.delta, a.w_pad, a.partial, a.arrivals, a.chi2_extra, a.out, a.out_kind, a.nonfinite, a.chi2_sn_out, ppg, snake,
-                     a.nt_last, a.done_flag, a.done_seq);
+                     a.nt_last, a.diag_skip, a.done_flag, a.done_seq);
   return 0;
 }
 
@@ -1312,7 +1313,8 @@ static int launch_eval(cf_handle* h, const double* th, int64_t Wc, double* out, 
   if (d.n_sn > 0 && h->solve_mode == CF_SOLVE_INVERSE_GEMM) {
     static const bool trim = cf_tune("gemm_trim", 1) != 0;  // 0: the padded tiles of the last row block are computed (A/B)
     const int n_rb_ = h->ipack.dev.n_rowblocks, nt_last = trim ? std::max(1, std::min(4, (d.n_pad - 64 * (n_rb_ - 1)) / 16)) : 4;
-    TriGemmArgs a{h->epi.as<const cf_epilogue>(), h->ipack.dev.frags, d.n_ld, d.ndim, n_rb_, nt_last, th, Wc, delta,
+    static const int diag_skip = cf_tune("gemm_diag_skip", 1) != 0;  // 0: the zero tiles of the diagonal blocks are multiplied (A/B)
+    TriGemmArgs a{h->epi.as<const cf_epilogue>(), h->ipack.dev.frags, d.n_ld, d.ndim, n_rb_, nt_last, diag_skip, th, Wc, delta,
                   h->max_walkers, h->partial.as<double>(), h->arrivals.as<unsigned int>(), extra, out,
                   out_kind, nf, chi2_sn_out, h->partial4.as<double>(), nullptr, 0ull, frag_b};
     // a synchronous zero-copy call: the solve kernel's last arrivers set one word per panel in pinned host memory and the host

@@ -1970,7 +1970,7 @@ tri_gemm_chi2_kernel(const cf_epilogue* __restrict__ epi, const d2* __restrict__
                      const double* __restrict__ theta, int64_t W, const double* __restrict__ delta, int64_t w_pad, double* partial,
                      unsigned int* arrivals, const double* __restrict__ chi2_extra, double* __restrict__ out, int out_kind,
                      unsigned long long* nonfinite, double* __restrict__ chi2_sn_out, int panels_per_group, int snake, int nt_last,
-                     unsigned long long* done_flag, unsigned long long done_seq) {
+                     int diag_skip, unsigned long long* done_flag, unsigned long long done_seq) {
   __shared__ __align__(16) d4 part[4][4][64];  // [wave][tile][lane] of one 16-walker panel: 32 KB
   __shared__ double chi_tile[4][16 * NP];
   __shared__ unsigned int arrived_before;
@@ -2009,69 +2009,78 @@ tri_gemm_chi2_kernel(const cf_epilogue* __restrict__ epi, const d2* __restrict__
   // PF-deep software pipeline over the nq K-step pairs.  Nothing is loaded past the wave's K range (but for row
   // block 0, covered by the buffers' slack): a load that nobody consumes still has to land before the wave may
   // retire, and it misses every cache.
-  // NT = the 16-row tiles of the row block that hold rows of the factor: 4, but for the LAST row block, whose rows N .. n_ld - 1
-  // are padding -- N = 1701: one of its four tiles is nothing else (1.8 % of the launch's matrix instructions, on its 128 longest
-  // units), N = 1820: two (3.3 %).  A padded tile's accumulators stay zero, which is what multiplying by the zero rows gives.
+  //
+  // WHICH TILES A PAIR MULTIPLIES.  Every pair's four factor fragments are fetched (the loads' bookkeeping stays that of a
+  // branch-free loop), but a tile whose fragment is all zeros is not multiplied: wave-uniform branches around IN-PLACE matrix
+  // instructions (tiles j_lo .. j_hi - 1).  An accumulator that receives 0 x b keeps its value -- it is never -0: it starts at
+  // +0 -- so the bits are those of the full product.
+  //  * j_hi: the LAST row block's rows N .. n_ld - 1 are padding -- N = 1701: one of its four tiles is nothing else (1.8 % of the
+  //    launch's matrix instructions, on its 128 longest units), N = 1820: two (3.3 %).
+  //  * j_lo: the last 64 columns of the K range are the row block's diagonal 64 x 64 block, lower triangular: its pairs 2 m,
+  //    2 m + 1 (columns 16 m .. 16 m + 15 of the block) meet only zeros in the tiles above tile m.  From row block 3 on those eight
+  //    pairs are the END of wave 3's quarter, four PF-groups of two pairs: group m takes the tiles m .. 3 -- 24 NP of the wave's
+  //    16 NP (rb + 1) matrix instructions; in row blocks 0 - 2 the block is spread over several waves, same rule.  2.7 % of the
+  //    launch's matrix instructions.
+  // (As straight-line variants per tile count the compiler kept a second set of 64 accumulator registers across the variants'
+  // merge: 162-182 VGPRs.)
+  d2 a[PF][4], bf[PF][NP];
+  auto load_stage = [&](int p) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[p][j] = A[(p * 4 + j) * 64];
+#pragma unroll
+    for (int c = 0; c < NP; ++c) bf[p][c] = Bq[c * bstride + p * 4];
+  };
+  auto mfma_stage = [&](int p, int j_lo, int j_hi) {  // per accumulator the pair's two K steps in order
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j >= j_lo && j < j_hi) {
+#pragma unroll
+        for (int c = 0; c < NP; ++c) acc[c][j] = mfma_f64(a[p][j].x, bf[p][c].x, acc[c][j]);
+#pragma unroll
+        for (int c = 0; c < NP; ++c) acc[c][j] = mfma_f64(a[p][j].y, bf[p][c].y, acc[c][j]);
+      }
+  };
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int p = 0; p < PF; ++p) {
+    load_stage(p);  // unconditional (a guard costs hipcc its exact vmcnt bookkeeping); only row block 0 has nq < PF
+    __builtin_amdgcn_sched_barrier(0);  // stage 0 must be the oldest load
+  }
+  A += PF * 4 * 64;
+  Bq += PF * 4;
+  const int n_groups = nq / PF, rem = nq - n_groups * PF;
+  const int j_hi = rb == n_rb - 1 ? nt_last : 4;
+  // the wave's group kg is 16-column group g n_groups + kg of the K range, the diagonal block starts at group 4 rb (PF = 2: a group
+  // is two pairs = 16 columns); diag_skip = 0 multiplies everything (A/B)
+  const int diag_off = (PF == 2 && diag_skip) ? g * n_groups - 4 * rb : -(1 << 20);
   CF_KLOOP_DECL;
-  auto k_loop = [&](auto nt_const) {
-    constexpr int NT = decltype(nt_const)::value;
-    d2 a[PF][NT], bf[PF][NP];
-    auto load_stage = [&](int p) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) a[p][j] = A[(p * 4 + j) * 64];
-#pragma unroll
-      for (int c = 0; c < NP; ++c) bf[p][c] = Bq[c * bstride + p * 4];
-    };
-    auto mfma_stage = [&](int p) {
-#pragma unroll
-      for (int c = 0; c < NP; ++c)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[c][j] = mfma_f64(a[p][j].x, bf[p][c].x, acc[c][j]);
-#pragma unroll
-      for (int c = 0; c < NP; ++c)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[c][j] = mfma_f64(a[p][j].y, bf[p][c].y, acc[c][j]);
-    };
-    __builtin_amdgcn_sched_barrier(0);
+  CF_KLOOP_BEGIN;
+  if (lane == 0) { CF_PHASE(2 * g); }
+  for (int kg = 0; kg + 1 < n_groups; ++kg) {
+    const int j_lo = diag_off + kg;  // <= 0 left of the diagonal block: every tile
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
-      load_stage(p);  // unconditional (a guard costs hipcc its exact vmcnt bookkeeping); only row block 0 has nq < PF
-      __builtin_amdgcn_sched_barrier(0);  // stage 0 must be the oldest load
+      mfma_stage(p, j_lo, j_hi);
+      __builtin_amdgcn_sched_barrier(0);
+      load_stage(p);
+      __builtin_amdgcn_sched_barrier(0);
     }
     A += PF * 4 * 64;
     Bq += PF * 4;
-    const int n_groups = nq / PF, rem = nq - n_groups * PF;
-    CF_KLOOP_BEGIN;
-    if (lane == 0) { CF_PHASE(2 * g); }
-    for (int kg = 0; kg + 1 < n_groups; ++kg) {  // branch-free body: a guard around the MFMAs makes hipcc drain vmcnt(0) per stage
+  }
+  if (n_groups > 0) {  // last full group: only the nq % PF pairs of the tail are still to be fetched
+    const int j_lo = diag_off + n_groups - 1;
 #pragma unroll
-      for (int p = 0; p < PF; ++p) {
-        mfma_stage(p);
-        __builtin_amdgcn_sched_barrier(0);
-        load_stage(p);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      A += PF * 4 * 64;
-      Bq += PF * 4;
+    for (int p = 0; p < PF; ++p) {
+      mfma_stage(p, j_lo, j_hi);
+      __builtin_amdgcn_sched_barrier(0);
+      if (p < rem) load_stage(p);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (n_groups > 0) {  // last full group: only the nq % PF pairs of the tail are still to be fetched
+  }
 #pragma unroll
-      for (int p = 0; p < PF; ++p) {
-        mfma_stage(p);
-        __builtin_amdgcn_sched_barrier(0);
-        if (p < rem) load_stage(p);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-#pragma unroll
-    for (int p = 0; p < PF - 1; ++p)
-      if (p < rem) mfma_stage(p);
-  };
-  const int nt = rb == n_rb - 1 ? nt_last : 4;
-  if (nt == 4) k_loop(std::integral_constant<int, 4>{});
-  else if (nt == 3) k_loop(std::integral_constant<int, 3>{});
-  else if (nt == 2) k_loop(std::integral_constant<int, 2>{});
-  else k_loop(std::integral_constant<int, 1>{});
+  for (int p = 0; p < PF - 1; ++p)
+    if (p < rem) mfma_stage(p, 0, j_hi);
   CF_KLOOP_END(nq);
   if (lane == 0) { CF_PHASE(2 * g + 1); }
   // the four K quarters meet in LDS, one 16-walker panel at a time; wave g owns tile g: y, then the column sums of y^2
@@ -2120,7 +2129,7 @@ tri_gemm_chi2_kernel(const cf_epilogue* __restrict__ epi, const d2* __restrict__
 #define CF_INSTANTIATE_TRIGEMM(NP, PF)                                                                                              \
   template __global__ void tri_gemm_chi2_kernel<NP, PF>(const cf_epilogue*, const d2*, int, int, int, const double*, int64_t,       \
                                                         const double*, int64_t, double*, unsigned int*, const double*, double*, int, \
-                                                        unsigned long long*, double*, int, int, int, unsigned long long*,             \
+                                                        unsigned long long*, double*, int, int, int, int, unsigned long long*,        \
                                                         unsigned long long);
 CF_INSTANTIATE_TRIGEMM(1, 2)  // up to 512 walkers
 CF_INSTANTIATE_TRIGEMM(2, 2)  // beyond: an A fragment feeds two MFMAs

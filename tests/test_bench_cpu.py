@@ -71,8 +71,11 @@ def test_one_per_gpu_shape_at_every_world_size_and_the_inprocess_arguments():
     with pytest.raises(ValueError, match="ONE process"):
         bench.plan("inprocess", "weak", 2)
     # the arithmetic behind roofline.useful_over_executed: N = 1701 -> 27 row blocks, 64 (rb + 1) MFMAs per 16-walker panel and block
-    assert bench.executed_mfmas_solve(1701, 4096) == 256 * 64 * 378 == 6193152
+    assert bench.executed_mfmas_solve(1701, 4096, skip_padding=False) == 256 * 64 * 378 == 6193152  # (= the PMC count of round 4's first pass)
     assert abs(bench.flops_per_eval_solve(1701) * 16 / (64 * 378 * 2048.0) - 0.9355) < 1e-4
+    # less one all-padding tile of row block 26 (16 x 27 K-steps) and six zero tile-groups of 4 K-steps per diagonal block
+    assert bench.executed_mfmas_solve(1701, 16) == 64 * 378 - 432 - 27 * 24 == 23112
+    assert bench.executed_mfmas_solve(1820, 16) == 64 * 435 - 2 * 16 * 29 - 4 * (28 * 6 + 5) == 26220
 
 
 def test_inprocess_mode_refuses_without_a_gpu_and_under_torchrun():
