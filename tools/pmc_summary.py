@@ -64,16 +64,15 @@ for k, cs in acc.items():
     if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
         name = "trsm_chi2_kernel" if "trsm" in k else ("tri_gemm_chi2_kernel" if "tri_gemm" in k else ("walker_kernel" if "walker" in k else None))
         if name:
-            # a chunked evaluation dispatches the kernel several times per step: bytes per step = per-dispatch mean x dispatches
-            per_step = cfg.get("dispatches_per_step") or (max(1, round(len(cs["FETCH_SIZE"]) / steps_total)) if steps_total else 1)
-            f = cs["FETCH_SIZE"][2 * per_step:] or cs["FETCH_SIZE"]
-            w = cs["WRITE_SIZE"][2 * per_step:] or cs["WRITE_SIZE"]
+            per_step = 1  # one dispatch of each kernel per evaluation (the preconditioning evaluations are dispatches of the same shape)
+            f = cs["FETCH_SIZE"][2:] or cs["FETCH_SIZE"]
+            w = cs["WRITE_SIZE"][2:] or cs["WRITE_SIZE"]
             fk, wk = sum(f) / len(f), sum(w) / len(w)
             traffic[name] = {"FETCH_SIZE_KB_per_dispatch": fk, "WRITE_SIZE_KB_per_dispatch": wk, "dispatches_per_step": per_step,
                              "hbm_bytes_per_launch": (2 * fk + wk) * 1024 * per_step}
 json.dump({"config": {"n_sn": cfg.get("n_sn"), "walkers_per_gpu": cfg.get("walkers_per_gpu"), "n_grid": cfg.get("n_grid"),
                       "workload": cfg.get("workload_key", "pantheon")},
            "kernels": traffic,
-           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of `python bench.py --steps 5 --warmup 2`; "
-                     "bytes per step of W walkers = (2*FETCH_SIZE + WRITE_SIZE) KB per dispatch (gfx950 correction) x dispatches per step"},
+           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of `python bench.py --steps 5 --warmup 2` "
+                     "(preconditioned device); bytes per launch of W walkers = (2*FETCH_SIZE + WRITE_SIZE) KB per dispatch (gfx950 correction)"},
           open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
