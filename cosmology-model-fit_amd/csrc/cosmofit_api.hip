@@ -161,7 +161,8 @@ template <int NP, int PF>
 __global__ void tri_gemm_chi2_kernel(const cf_epilogue* epi, const d2* frags, int n_ld, int ndim, int n_rb, const double* theta, int64_t W,
                                      const double* delta, int64_t w_pad, double* partial, unsigned int* arrivals, const double* chi2_extra,
                                      double* out, int out_kind, unsigned long long* nonfinite, double* chi2_sn_out, int panels_per_group,
-                                     int snake, int nt_last, int diag_skip, unsigned long long* done_flag, unsigned long long done_seq);
+                                     int snake, int nt_last, int diag_skip, int split_levels, unsigned long long* done_flag,
+                                     unsigned long long done_seq);
 template <int PF, bool FRAG, int TPW>
 __global__ void tri_gemm_small_kernel(const cf_epilogue* epi, const d2* frags, int n_ld, int ndim, int n_rb, const double* theta, int64_t W,
                                       const double* delta, double* partial4, unsigned int* arrivals, const double* chi2_extra, double* out,
@@ -178,7 +179,7 @@ CF_DECLARE_TRIGEMM_SMALL(8, false, 2)
 #define CF_DECLARE_TRIGEMM(NP, PF)                                                                                                       \
   extern template __global__ void tri_gemm_chi2_kernel<NP, PF>(const cf_epilogue*, const d2*, int, int, int, const double*, int64_t,     \
                                                                const double*, int64_t, double*, unsigned int*, const double*, double*,  \
-                                                               int, unsigned long long*, double*, int, int, int, int,                   \
+                                                               int, unsigned long long*, double*, int, int, int, int, int,              \
                                                                unsigned long long*, unsigned long long);
 CF_DECLARE_TRIGEMM(1, 2)
 CF_DECLARE_TRIGEMM(2, 2)
@@ -1178,14 +1179,20 @@ static int launch_tri_gemm_t(const TriGemmArgs& a, hipStream_t st) {
     ppg = ((panels + n_groups - 1) / n_groups + 7) / 8 * 8;
   }
   const int n_groups = (panels + ppg - 1) / ppg;
-  const int n_wgs = n_groups * ppg * a.n_rb;
+  // the lowest row blocks of a 32-walker panel as two 16-walker units each (the kernel: HALF UNITS).  Measured over 0 / 4 / 8 / 12 / 16
+  // levels (profiles/r04_half_units_ab_raw.txt): 12 levels gain 3-4 % at 768-2048 walkers, where the ragged end is 8.5 % of the
+  // launch; from 4096 walkers on every level split costs (the factor fragments feed one panel instead of two: 8 levels -4 %), so
+  // batches of more than 64 panels keep whole units.  CF_TUNE gemm_split=<levels> forces a number.
+  static const int split_env = (int)cf_tune("gemm_split", -1);
+  const int split_levels = NP == 2 ? std::max(0, std::min(a.n_rb - 1, split_env >= 0 ? split_env : (panels <= 64 ? 12 : 0))) : 0;
+  const int n_wgs = n_groups * ppg * (a.n_rb + split_levels);
   // order of the row blocks inside the grid: descending; for a grid that is resident all at once, alternate blocks of 256 workgroups
   // ascending (see the kernel).  CF_TUNE gemm_order=0|1 forces one.
   static const int order_env = (int)cf_tune("gemm_order", -1);
-  const int snake = order_env >= 0 ? order_env : (n_wgs <= 1024 ? 1 : 0);
+  const int snake = order_env >= 0 ? order_env : (n_wgs <= 1024 + 256 ? 1 : 0);  // (a few half units beyond the resident 1024 change nothing)
   hipLaunchKernelGGL((tri_gemm_chi2_kernel<NP, PF>), dim3((unsigned)n_wgs), dim3(256), 0, st, a.epi, a.frags, a.n_ld, a.ndim, a.n_rb, a.theta,
                      a.W, a.delta, a.w_pad, a.partial, a.arrivals, a.chi2_extra, a.out, a.out_kind, a.nonfinite, a.chi2_sn_out, ppg, snake,
-                     a.nt_last, a.diag_skip, a.done_flag, a.done_seq);
+                     a.nt_last, a.diag_skip, split_levels, a.done_flag, a.done_seq);
   return 0;
 }
 

@@ -1970,7 +1970,7 @@ tri_gemm_chi2_kernel(const cf_epilogue* __restrict__ epi, const d2* __restrict__
                      const double* __restrict__ theta, int64_t W, const double* __restrict__ delta, int64_t w_pad, double* partial,
                      unsigned int* arrivals, const double* __restrict__ chi2_extra, double* __restrict__ out, int out_kind,
                      unsigned long long* nonfinite, double* __restrict__ chi2_sn_out, int panels_per_group, int snake, int nt_last,
-                     int diag_skip, unsigned long long* done_flag, unsigned long long done_seq) {
+                     int diag_skip, int split_levels, unsigned long long* done_flag, unsigned long long done_seq) {
   __shared__ __align__(16) d4 part[4][4][64];  // [wave][tile][lane] of one 16-walker panel: 32 KB
   __shared__ double chi_tile[4][16 * NP];
   __shared__ unsigned int arrived_before;
@@ -1978,7 +1978,13 @@ tri_gemm_chi2_kernel(const cf_epilogue* __restrict__ epi, const d2* __restrict__
   const int tid = threadIdx.x, lane = tid & 63;
   const int g = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave's K quarter, in a scalar register: its address arithmetic too
   const int col = lane & 15, kq = lane >> 4;
-  const int per_group = panels_per_group * n_rb;
+  // HALF UNITS.  The `split_levels` lowest row blocks of a 32-walker panel are worked as two units of 16 walkers each (NP = 2 only;
+  // the launcher asks for it at 513-2048 walkers): a launch's ragged end -- at 1024-2048 walkers 8.5 % of it -- is as long as the
+  // units in flight when the grid runs out, and those are the short row blocks' (profiles/NOTES_r04.md section 1).  A half unit computes its 16 walkers exactly as the
+  // full unit would (the panels of a unit share nothing but the factor fragments), so the bits are the same; a panel then has
+  // n_rb + split_levels arrivals.
+  const int n_full_levels = n_rb - split_levels;
+  const int per_group = panels_per_group * (n_rb + split_levels);
   const int grp = (int)blockIdx.x / per_group;
   int rem_id = (int)blockIdx.x % per_group;
   // `snake`: a grid that is resident all at once (<= 1024 workgroups) is placed statically, workgroups i, i + 256, i + 512, ... on the
@@ -1990,109 +1996,127 @@ tri_gemm_chi2_kernel(const cf_epilogue* __restrict__ epi, const d2* __restrict__
     const int b = rem_id >> 8, len = (per_group - (b << 8)) < 256 ? per_group - (b << 8) : 256;
     if (b & 1) rem_id = (b << 8) + (len - 1 - (rem_id & 255));
   }
-  const int rb = n_rb - 1 - rem_id / panels_per_group;  // largest row blocks first
-  const int px = grp * panels_per_group + rem_id % panels_per_group;
-  const int64_t w0 = (int64_t)px * PW;
-  if (w0 >= W) return;  // the last group may be partly empty
-  CF_CLOCK_STAMP(0);
-  const int nq = 2 * (rb + 1);  // K-step pairs per wave
-  // the factor stream of (row block, K quarter) in closed form (cf_inv_stream_off): no dependent load in front of the first fragment
-  const d2* A = frags + cf_inv_stream_off(rb, g) * 64 + lane;
-  // B fragments: 16 bytes per lane from the walker's residual row; panel c is 16 rows (8 n_ld d2) further on
-  const d2* Bq = reinterpret_cast<const d2*>(delta) + ((w0 + col) * (int64_t)n_ld + 8 * g * nq + 2 * kq) / 2;
-  const int64_t bstride = 8 * (int64_t)n_ld;
-  d4 acc[NP][4];
-#pragma unroll
-  for (int c = 0; c < NP; ++c)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[c][j] = (d4){0.0, 0.0, 0.0, 0.0};
-  // PF-deep software pipeline over the nq K-step pairs.  Nothing is loaded past the wave's K range (but for row
-  // block 0, covered by the buffers' slack): a load that nobody consumes still has to land before the wave may
-  // retire, and it misses every cache.
-  //
-  // WHICH TILES A PAIR MULTIPLIES.  Every pair's four factor fragments are fetched (the loads' bookkeeping stays that of a
-  // branch-free loop), but a tile whose fragment is all zeros is not multiplied: wave-uniform branches around IN-PLACE matrix
-  // instructions (tiles j_lo .. j_hi - 1).  An accumulator that receives 0 x b keeps its value -- it is never -0: it starts at
-  // +0 -- so the bits are those of the full product.
-  //  * j_hi: the LAST row block's rows N .. n_ld - 1 are padding -- N = 1701: one of its four tiles is nothing else (1.8 % of the
-  //    launch's matrix instructions, on its 128 longest units), N = 1820: two (3.3 %).
-  //  * j_lo: the last 64 columns of the K range are the row block's diagonal 64 x 64 block, lower triangular: its pairs 2 m,
-  //    2 m + 1 (columns 16 m .. 16 m + 15 of the block) meet only zeros in the tiles above tile m.  From row block 3 on those eight
-  //    pairs are the END of wave 3's quarter, four PF-groups of two pairs: group m takes the tiles m .. 3 -- 24 NP of the wave's
-  //    16 NP (rb + 1) matrix instructions; in row blocks 0 - 2 the block is spread over several waves, same rule.  2.7 % of the
-  //    launch's matrix instructions.
-  // (As straight-line variants per tile count the compiler kept a second set of 64 accumulator registers across the variants'
-  // merge: 162-182 VGPRs.)
-  d2 a[PF][4], bf[PF][NP];
-  auto load_stage = [&](int p) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) a[p][j] = A[(p * 4 + j) * 64];
-#pragma unroll
-    for (int c = 0; c < NP; ++c) bf[p][c] = Bq[c * bstride + p * 4];
-  };
-  auto mfma_stage = [&](int p, int j_lo, int j_hi) {  // per accumulator the pair's two K steps in order
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (j >= j_lo && j < j_hi) {
-#pragma unroll
-        for (int c = 0; c < NP; ++c) acc[c][j] = mfma_f64(a[p][j].x, bf[p][c].x, acc[c][j]);
-#pragma unroll
-        for (int c = 0; c < NP; ++c) acc[c][j] = mfma_f64(a[p][j].y, bf[p][c].y, acc[c][j]);
-      }
-  };
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int p = 0; p < PF; ++p) {
-    load_stage(p);  // unconditional (a guard costs hipcc its exact vmcnt bookkeeping); only row block 0 has nq < PF
-    __builtin_amdgcn_sched_barrier(0);  // stage 0 must be the oldest load
+  int rb, px_in_group, half = -1;  // largest row blocks first; half: -1 a full unit, 0 / 1 the panel's first / second 16 walkers
+  if (rem_id < panels_per_group * n_full_levels) {
+    rb = n_rb - 1 - rem_id / panels_per_group;
+    px_in_group = rem_id % panels_per_group;
+  } else {
+    const int r2 = rem_id - panels_per_group * n_full_levels;
+    rb = split_levels - 1 - r2 / (2 * panels_per_group);
+    px_in_group = (r2 % (2 * panels_per_group)) >> 1;
+    half = r2 & 1;
   }
-  A += PF * 4 * 64;
-  Bq += PF * 4;
-  const int n_groups = nq / PF, rem = nq - n_groups * PF;
-  const int j_hi = rb == n_rb - 1 ? nt_last : 4;
-  // the wave's group kg is 16-column group g n_groups + kg of the K range, the diagonal block starts at group 4 rb (PF = 2: a group
-  // is two pairs = 16 columns); diag_skip = 0 multiplies everything (A/B)
-  const int diag_off = (PF == 2 && diag_skip) ? g * n_groups - 4 * rb : -(1 << 20);
+  const int px = grp * panels_per_group + px_in_group;
+  const int np_u = half < 0 ? NP : 1;                                    // 16-walker panels of this unit
+  const int64_t w0 = (int64_t)px * PW + (half > 0 ? 16 : 0);             // its first walker
+  if ((int64_t)px * PW >= W) return;  // the last group may be partly empty
+  // (the second half of a batch's last panel may hold no walker: it computes nothing and stores nothing, but it ARRIVES -- the
+  // panel counts n_rb + split_levels arrivals whatever its fill)
+  const bool empty_half = w0 >= W;
   CF_KLOOP_DECL;
-  CF_KLOOP_BEGIN;
-  if (lane == 0) { CF_PHASE(2 * g); }
-  for (int kg = 0; kg + 1 < n_groups; ++kg) {
-    const int j_lo = diag_off + kg;  // <= 0 left of the diagonal block: every tile
+  CF_CLOCK_STAMP(0);
+  if (!empty_half) {
+    const int nq = 2 * (rb + 1);  // K-step pairs per wave
+    // the factor stream of (row block, K quarter) in closed form (cf_inv_stream_off): no dependent load in front of the first fragment
+    const d2* A = frags + cf_inv_stream_off(rb, g) * 64 + lane;
+    // B fragments: 16 bytes per lane from the walker's residual row; panel c is 16 rows (8 n_ld d2) further on
+    const d2* Bq = reinterpret_cast<const d2*>(delta) + ((w0 + col) * (int64_t)n_ld + 8 * g * nq + 2 * kq) / 2;
+    const int64_t bstride = half < 0 ? 8 * (int64_t)n_ld : 0;  // (a half unit's second-panel loads re-read its own rows: never multiplied)
+    d4 acc[NP][4];
+#pragma unroll
+    for (int c = 0; c < NP; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[c][j] = (d4){0.0, 0.0, 0.0, 0.0};
+    // PF-deep software pipeline over the nq K-step pairs.  Nothing is loaded past the wave's K range (but for row
+    // block 0, covered by the buffers' slack): a load that nobody consumes still has to land before the wave may
+    // retire, and it misses every cache.
+    //
+    // WHICH TILES A PAIR MULTIPLIES.  Every pair's four factor fragments are fetched (the loads' bookkeeping stays that of a
+    // branch-free loop), but a tile whose fragment is all zeros is not multiplied: wave-uniform branches around IN-PLACE matrix
+    // instructions (tiles j_lo .. j_hi - 1).  An accumulator that receives 0 x b keeps its value -- it is never -0: it starts at
+    // +0 -- so the bits are those of the full product.
+    //  * j_hi: the LAST row block's rows N .. n_ld - 1 are padding -- N = 1701: one of its four tiles is nothing else (1.8 % of the
+    //    launch's matrix instructions, on its 128 longest units), N = 1820: two (3.3 %).
+    //  * j_lo: the last 64 columns of the K range are the row block's diagonal 64 x 64 block, lower triangular: its pairs 2 m,
+    //    2 m + 1 (columns 16 m .. 16 m + 15 of the block) meet only zeros in the tiles above tile m.  From row block 3 on those eight
+    //    pairs are the END of wave 3's quarter, four PF-groups of two pairs: group m takes the tiles m .. 3 -- 24 NP of the wave's
+    //    16 NP (rb + 1) matrix instructions; in row blocks 0 - 2 the block is spread over several waves, same rule.  2.7 % of the
+    //    launch's matrix instructions.
+    // (As straight-line variants per tile count the compiler kept a second set of 64 accumulator registers across the variants'
+    // merge: 162-182 VGPRs.)
+    d2 a[PF][4], bf[PF][NP];
+    auto load_stage = [&](int p) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[p][j] = A[(p * 4 + j) * 64];
+#pragma unroll
+      for (int c = 0; c < NP; ++c) bf[p][c] = Bq[c * bstride + p * 4];
+    };
+    auto mfma_stage = [&](int p, int j_lo, int j_hi) {  // per accumulator the pair's two K steps in order
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j >= j_lo && j < j_hi) {
+#pragma unroll
+          for (int c = 0; c < NP; ++c)
+            if (c < np_u) {
+              acc[c][j] = mfma_f64(a[p][j].x, bf[p][c].x, acc[c][j]);
+              acc[c][j] = mfma_f64(a[p][j].y, bf[p][c].y, acc[c][j]);
+            }
+        }
+    };
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
-      mfma_stage(p, j_lo, j_hi);
-      __builtin_amdgcn_sched_barrier(0);
-      load_stage(p);
-      __builtin_amdgcn_sched_barrier(0);
+      load_stage(p);  // unconditional (a guard costs hipcc its exact vmcnt bookkeeping); only row block 0 has nq < PF
+      __builtin_amdgcn_sched_barrier(0);  // stage 0 must be the oldest load
     }
     A += PF * 4 * 64;
     Bq += PF * 4;
-  }
-  if (n_groups > 0) {  // last full group: only the nq % PF pairs of the tail are still to be fetched
-    const int j_lo = diag_off + n_groups - 1;
+    const int n_groups = nq / PF, rem = nq - n_groups * PF;
+    const int j_hi = rb == n_rb - 1 ? nt_last : 4;
+    // the wave's group kg is 16-column group g n_groups + kg of the K range, the diagonal block starts at group 4 rb (PF = 2: a group
+    // is two pairs = 16 columns); diag_skip = 0 multiplies everything (A/B)
+    const int diag_off = (PF == 2 && diag_skip) ? g * n_groups - 4 * rb : -(1 << 20);
+    CF_KLOOP_BEGIN;
+    if (lane == 0) { CF_PHASE(2 * g); }
+    for (int kg = 0; kg + 1 < n_groups; ++kg) {
+      const int j_lo = diag_off + kg;  // <= 0 left of the diagonal block: every tile
 #pragma unroll
-    for (int p = 0; p < PF; ++p) {
-      mfma_stage(p, j_lo, j_hi);
-      __builtin_amdgcn_sched_barrier(0);
-      if (p < rem) load_stage(p);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int p = 0; p < PF; ++p) {
+        mfma_stage(p, j_lo, j_hi);
+        __builtin_amdgcn_sched_barrier(0);
+        load_stage(p);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      A += PF * 4 * 64;
+      Bq += PF * 4;
     }
-  }
+    if (n_groups > 0) {  // last full group: only the nq % PF pairs of the tail are still to be fetched
+      const int j_lo = diag_off + n_groups - 1;
 #pragma unroll
-  for (int p = 0; p < PF - 1; ++p)
-    if (p < rem) mfma_stage(p, 0, j_hi);
-  CF_KLOOP_END(nq);
-  if (lane == 0) { CF_PHASE(2 * g + 1); }
-  // the four K quarters meet in LDS, one 16-walker panel at a time; wave g owns tile g: y, then the column sums of y^2
+      for (int p = 0; p < PF; ++p) {
+        mfma_stage(p, j_lo, j_hi);
+        __builtin_amdgcn_sched_barrier(0);
+        if (p < rem) load_stage(p);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
 #pragma unroll
-  for (int c = 0; c < NP; ++c) {
-    if (c > 0) lds_barrier();
+    for (int p = 0; p < PF - 1; ++p)
+      if (p < rem) mfma_stage(p, 0, j_hi);
+    CF_KLOOP_END(nq);
+    if (lane == 0) { CF_PHASE(2 * g + 1); }
+    // the four K quarters meet in LDS, one 16-walker panel at a time; wave g owns tile g: y, then the column sums of y^2
 #pragma unroll
-    for (int j = 0; j < 4; ++j) part[g][j][lane] = acc[c][j];
-    lds_barrier();
-    if (c == 0 && tid == 0) { CF_PHASE(8); }
-    const double v = tile_chi2_share(part[0][g][lane], part[1][g][lane], part[2][g][lane], part[3][g][lane]);
-    if (lane < 16) chi_tile[g][c * 16 + lane] = v;
+    for (int c = 0; c < NP; ++c) {
+      if (c >= np_u) break;
+      if (c > 0) lds_barrier();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) part[g][j][lane] = acc[c][j];
+      lds_barrier();
+      if (c == 0 && tid == 0) { CF_PHASE(8); }
+      const double v = tile_chi2_share(part[0][g][lane], part[1][g][lane], part[2][g][lane], part[3][g][lane]);
+      if (lane < 16) chi_tile[g][c * 16 + lane] = v;
+    }
   }
   lds_barrier();
   if (tid == 0) { CF_PHASE(9); }
@@ -2105,7 +2129,7 @@ tri_gemm_chi2_kernel(const cf_epilogue* __restrict__ epi, const d2* __restrict__
   // and read every share back with agent-scope (sc1) loads, add the row blocks in a fixed order (the result does not
   // depend on which workgroup it was) and re-arm the counter for the next launch (panel_last_arriver).
   if (g == 0) {
-    if (lane < PW)
+    if (lane < 16 * np_u && !empty_half)
       __hip_atomic_store(&partial[(int64_t)rb * w_pad + w0 + lane],
                          rowblock_share(chi_tile[0][lane], chi_tile[1][lane], chi_tile[2][lane], chi_tile[3][lane]), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
@@ -2119,8 +2143,8 @@ tri_gemm_chi2_kernel(const cf_epilogue* __restrict__ epi, const d2* __restrict__
   CF_CLOCK_STAMP(1);
   CF_KLOOP_STORE;
   CF_CLOCK_COUNT(6, ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4));  // XCC_ID, HW_ID
-  CF_CLOCK_COUNT(7, arrived_before == (unsigned)n_rb - 1u);
-  if (arrived_before != (unsigned)n_rb - 1u) return;
+  CF_CLOCK_COUNT(7, arrived_before == (unsigned)(n_rb + split_levels) - 1u);
+  if (arrived_before != (unsigned)(n_rb + split_levels) - 1u) return;
   panel_last_arriver<NP>(reinterpret_cast<double*>(part), epi, ndim, n_rb, theta, W, w_pad, partial, arrivals, chi2_extra, out, out_kind,
                          nonfinite, chi2_sn_out, px, done_flag, done_seq);
   CF_CLOCK_STAMP(2);
@@ -2129,8 +2153,8 @@ tri_gemm_chi2_kernel(const cf_epilogue* __restrict__ epi, const d2* __restrict__
 #define CF_INSTANTIATE_TRIGEMM(NP, PF)                                                                                              \
   template __global__ void tri_gemm_chi2_kernel<NP, PF>(const cf_epilogue*, const d2*, int, int, int, const double*, int64_t,       \
                                                         const double*, int64_t, double*, unsigned int*, const double*, double*, int, \
-                                                        unsigned long long*, double*, int, int, int, int, unsigned long long*,        \
-                                                        unsigned long long);
+                                                        unsigned long long*, double*, int, int, int, int, int,                        \
+                                                        unsigned long long*, unsigned long long);
 CF_INSTANTIATE_TRIGEMM(1, 2)  // up to 512 walkers
 CF_INSTANTIATE_TRIGEMM(2, 2)  // beyond: an A fragment feeds two MFMAs
 
