@@ -1179,12 +1179,12 @@ static int launch_tri_gemm_t(const TriGemmArgs& a, hipStream_t st) {
     ppg = ((panels + n_groups - 1) / n_groups + 7) / 8 * 8;
   }
   const int n_groups = (panels + ppg - 1) / ppg;
-  // the lowest row blocks of a 32-walker panel as two 16-walker units each (the kernel: HALF UNITS).  Measured over 0 / 4 / 8 / 12 / 16
-  // levels (profiles/r04_half_units_ab_raw.txt): 12 levels gain 3-4 % at 768-2048 walkers, where the ragged end is 8.5 % of the
-  // launch; from 4096 walkers on every level split costs (the factor fragments feed one panel instead of two: 8 levels -4 %), so
-  // batches of more than 64 panels keep whole units.  CF_TUNE gemm_split=<levels> forces a number.
+  // the lowest row blocks of a 32-walker panel as two 16-walker units each (the kernel: HALF UNITS).  Measured with the final kernel
+  // over 0 / 6 / 12 levels (profiles/r04_half_units_final_kernel_raw.txt): 6 levels gain 2 % at 1024-1536 walkers (0.643 -> 0.654,
+  // 0.698 -> 0.715), nothing at 640-768 and 2048, and cost 3 % at 3072 (the factor fragments feed one panel instead of two; every
+  // stage of a half unit runs the guarded form).  CF_TUNE gemm_split=<levels> forces a number.
   static const int split_env = (int)cf_tune("gemm_split", -1);
-  const int split_levels = NP == 2 ? std::max(0, std::min(a.n_rb - 1, split_env >= 0 ? split_env : (panels <= 64 ? 12 : 0))) : 0;
+  const int split_levels = NP == 2 ? std::max(0, std::min(a.n_rb - 1, split_env >= 0 ? split_env : (panels >= 28 && panels <= 56 ? 6 : 0))) : 0;
   const int n_wgs = n_groups * ppg * (a.n_rb + split_levels);
   // order of the row blocks inside the grid: descending; for a grid that is resident all at once, alternate blocks of 256 workgroups
   // ascending (see the kernel).  CF_TUNE gemm_order=0|1 forces one.

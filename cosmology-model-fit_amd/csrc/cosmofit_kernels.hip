@@ -1979,7 +1979,7 @@ tri_gemm_chi2_kernel(const cf_epilogue* __restrict__ epi, const d2* __restrict__
   const int g = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave's K quarter, in a scalar register: its address arithmetic too
   const int col = lane & 15, kq = lane >> 4;
   // HALF UNITS.  The `split_levels` lowest row blocks of a 32-walker panel are worked as two units of 16 walkers each (NP = 2 only;
-  // the launcher asks for it at 513-2048 walkers): a launch's ragged end -- at 1024-2048 walkers 8.5 % of it -- is as long as the
+  // the launcher asks for six levels at ~900-1800 walkers): a launch's ragged end -- at 1024-2048 walkers 8.5 % of it -- is as long as the
   // units in flight when the grid runs out, and those are the short row blocks' (profiles/NOTES_r04.md section 1).  A half unit computes its 16 walkers exactly as the
   // full unit would (the panels of a unit share nothing but the factor fragments), so the bits are the same; a panel then has
   // n_rb + split_levels arrivals.
@@ -2051,6 +2051,16 @@ tri_gemm_chi2_kernel(const cf_epilogue* __restrict__ epi, const d2* __restrict__
 #pragma unroll
       for (int c = 0; c < NP; ++c) bf[p][c] = Bq[c * bstride + p * 4];
     };
+    auto mfma_stage_full = [&](int p) {  // every tile, every panel: one straight line of independent accumulators
+#pragma unroll
+      for (int c = 0; c < NP; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[c][j] = mfma_f64(a[p][j].x, bf[p][c].x, acc[c][j]);
+#pragma unroll
+      for (int c = 0; c < NP; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[c][j] = mfma_f64(a[p][j].y, bf[p][c].y, acc[c][j]);
+    };
     auto mfma_stage = [&](int p, int j_lo, int j_hi) {  // per accumulator the pair's two K steps in order
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -2078,7 +2088,22 @@ tri_gemm_chi2_kernel(const cf_epilogue* __restrict__ epi, const d2* __restrict__
     const int diag_off = (PF == 2 && diag_skip) ? g * n_groups - 4 * rb : -(1 << 20);
     CF_KLOOP_BEGIN;
     if (lane == 0) { CF_PHASE(2 * g); }
-    for (int kg = 0; kg + 1 < n_groups; ++kg) {
+    // The guards are not free (every tile's instructions become a basic block of their own: with guarded stages everywhere the
+    // launch took 4 % longer, profiles/r04_net_ab_guards_everywhere_raw.txt): the groups that multiply everything -- all but the
+    // wave's diagonal groups, in a whole unit that is not of the last row block -- run the straight-line stage.
+    const int n_fast = (j_hi < 4 || np_u < NP) ? 0 : (1 - diag_off < n_groups - 1 ? (1 - diag_off > 0 ? 1 - diag_off : 0) : n_groups - 1);
+    for (int kg = 0; kg < n_fast; ++kg) {
+#pragma unroll
+      for (int p = 0; p < PF; ++p) {
+        mfma_stage_full(p);
+        __builtin_amdgcn_sched_barrier(0);
+        load_stage(p);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      A += PF * 4 * 64;
+      Bq += PF * 4;
+    }
+    for (int kg = n_fast; kg + 1 < n_groups; ++kg) {
       const int j_lo = diag_off + kg;  // <= 0 left of the diagonal block: every tile
 #pragma unroll
       for (int p = 0; p < PF; ++p) {
