@@ -26,9 +26,11 @@ def gpu(pkg):
     return pkg
 
 
-def _chi2_with(lib_path, W, tmp_path, tag):
+def _chi2_with(lib_path, W, tmp_path, tag, tune=None):
     out = str(tmp_path / f"{tag}_{W}.npy")
     env = dict(os.environ, COSMOFIT_LIB=lib_path)
+    if tune is not None:
+        env["CF_TUNE"] = tune
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "handoff_worker.py"), str(W), out], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -46,6 +48,20 @@ def test_release_ordered_arrival_gives_the_same_bits(gpu, tmp_path):
         b = _chi2_with(variant, W, tmp_path, "release")
         assert a.shape == (W,) and np.all(np.isfinite(a)) and np.all(a > 0)
         assert np.array_equal(a, b), f"W = {W}: the relaxed and the release-ordered hand-off disagree"
+
+
+def test_skipping_zero_tiles_and_splitting_units_changes_no_bit(gpu, tmp_path):
+    """Round 4: the throughput solve kernel does not multiply the all-padding tiles of the last row block nor the zero tiles of the
+    diagonal blocks, and works the lowest row blocks of a panel as two half units at ~900-1800 walkers.  With every one of these
+    switched off through CF_TUNE (a fresh process: the string is read once) the chi^2 must be the same BITS -- an accumulator that
+    receives 0 x b keeps its value, a half unit computes its walkers exactly as the whole unit would."""
+    default = os.path.join(PKG_DIR, "libcosmofit_hip.so")
+    for W in (1040, 1500, 4096):  # half units with an empty / a partly filled second half; whole units
+        a = _chi2_with(default, W, tmp_path, "as_shipped")
+        b = _chi2_with(default, W, tmp_path, "everything_multiplied", tune="gemm_trim=0,gemm_diag_skip=0,gemm_split=0")
+        c = _chi2_with(default, W, tmp_path, "twelve_split_levels", tune="gemm_split=12")
+        assert a.shape == (W,) and np.all(np.isfinite(a)) and np.all(a > 0)
+        assert np.array_equal(a, b) and np.array_equal(a, c), f"W = {W}"
 
 
 def test_handoff_under_a_skewed_co_runner(gpu):

@@ -170,8 +170,13 @@ def test_config2_batch_invariance(config2):
     np.testing.assert_array_equal(halves, full)
     # ragged panels; the small-batch path (<= 160 walkers: residuals in fragment order, 4 / 2 workgroups per walker up to 64 / 160,
     # one / two tiles per solve workgroup up to 96 / 160) and the throughput kernel
-    for W in (1, 2, 15, 16, 17, 31, 33, 48, 63, 64, 65, 96, 97, 100, 127, 128, 129, 160, 161, 256, 257, 512, 513, 1000):  # 512 / 513: 16- / 32-walker panels
-        np.testing.assert_array_equal(lk.chi_squared(theta[:W]), full[:W])
+    # 512 / 513: 16- / 32-walker panels.  865 .. 1792 walkers (28 .. 56 panels): the six lowest row blocks of a panel as two 16-walker
+    # units each -- with the last panel's second half empty (W mod 32 in 1 .. 16: 897, 1040, 1777), partly filled (1000, 1500) and
+    # full (896, 1792); 1793: whole units again.  The 4096-walker batch multiplies nothing it may skip either (padded tiles of the
+    # last row block, zero tiles of the diagonal blocks), like every batch here.
+    for W in (1, 2, 15, 16, 17, 31, 33, 48, 63, 64, 65, 96, 97, 100, 127, 128, 129, 160, 161, 256, 257, 512, 513, 864, 865, 896, 897, 1000,
+              1040, 1500, 1777, 1792, 1793, 3000):
+        np.testing.assert_array_equal(lk.chi_squared(theta[:W]), full[:W], err_msg=f"W={W}")
     assert lk.chi_squared(theta[:0]).shape == (0,)
 
 
