@@ -63,3 +63,23 @@ def test_bench_two_ranks_rehearsed_over_gloo_on_one_gpu(pkg):
     assert d["config"]["walkers_per_gpu"] == 512 and d["config"]["walkers_total"] == 1024
     assert len(d["ms_per_step_by_rank"]) == 2 and max(d["ms_per_step_by_rank"]) == pytest.approx(d["ms_per_step"], rel=1e-9)
     assert d["allgather_ms_per_step"] is None and d["distinct_devices"] == 1 and len(d["device_ids"]) == 2
+
+
+
+def test_bench_inprocess_mode_over_repeated_ordinals(pkg):
+    """SURVEY 8e form (1) as bench.py measures it: ONE process, one handle over k replicas, host buffers through cf_eval.  On the
+    one-GPU box the ordinal repeats (a rehearsal, labelled as such in the line); the replicas must not change a walker's result
+    (bench.py itself asserts bit-equality with a one-device handle) and the host CPU time per call is reported."""
+    if pkg.lib().cf_device_count() < 1:
+        pytest.fail("GPU tests need an MI355X; no HIP device visible (there is no fallback path)")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "inprocess", "--devices", "0,0,0", "--walkers-total", "6144",
+           "--n-sn", "300", "--steps", "3", "--warmup", "1", "--precondition-ms", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[:800]
+    d = json.loads(lines[0])
+    assert d["mode"] == "inprocess" and d["n_gpus"] == 1 and d["distinct_devices"] == 1 and d["config"]["replicas"] == [0, 0, 0]
+    assert d["config"]["rehearsal"] and d["config"]["walkers_total"] == 6144 and d["value"] > 0 and d["scaling"] == "strong"
+    assert 0 < d["host_cpu_seconds_per_call"] and d["roofline"]["frac"] > 0 and d["vs_baseline"] is None
