@@ -8,6 +8,8 @@ timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; rc=
 [ $rc -ne 0 ] && exit $rc
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 || { echo "smoke failed"; tail -20 $O/smoke.log; exit 1; }
 tail -1 $O/smoke.log | cut -c1-160
+[ -x tools/coexec_f64_rate ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/coexec_f64_rate.hip -o tools/coexec_f64_rate
+[ -f cosmology-model-fit_amd/libcosmofit_hip_clock.so ] || tools/build_variant.sh clock -DCF_DIAG_CLOCK > /dev/null
 timeout -k 10 120 tools/coexec_f64_rate > $O/bare_mfma_rate.txt 2>&1; head -4 $O/bare_mfma_rate.txt
 OUT_JSON=$O/solve_clock.json BARE_TXT=$O/bare_mfma_rate.txt COSMOFIT_LIB=$PWD/cosmology-model-fit_amd/libcosmofit_hip_clock.so timeout -k 10 300 python tools/solve_clock.py 1024 2048 4096 2>&1 | grep -v amdgpu.ids > $O/solve_clock.txt; grep "W =\|shader clock\|idle CU" $O/solve_clock.txt
 cp $O/solve_clock.json profiles/r04_solve_clock.json   # what bench.py replays as roofline.clock_ghz (also copied back by hand)
