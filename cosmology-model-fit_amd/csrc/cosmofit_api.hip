@@ -619,11 +619,32 @@ static void fs8_points(const cf_dev_desc& d, const double* zs, int n, std::vecto
   }
 }
 
+// The calling thread's current device is the caller's business (a torch process has its own idea of it): every entry point switches
+// to the handle's device for its own HIP calls and switches back on the way out.  One hipGetDevice per call when the two agree.
+struct DeviceScope {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceScope(int dev) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+    if (cur != dev) {
+      err = hipSetDevice(dev);
+      if (err == hipSuccess) prev = cur;
+    }
+  }
+  ~DeviceScope() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
 static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** out) {
   cf_handle* h = new cf_handle();
   auto bail = [&](int code) { cf_destroy(h); return code; };
   h->device = device;
-  if (hipSetDevice(h->device) != hipSuccess) return bail(fail(CF_ERR_HIP, "hipSetDevice failed"));
+  DeviceScope on_device(h->device);
+  if (on_device.err != hipSuccess) return bail(fail(CF_ERR_HIP, "hipSetDevice failed"));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) {
     h->cu_count = prop.multiProcessorCount;
@@ -966,6 +987,7 @@ static int eval_host_single(cf_handle* h, const double* theta, int64_t W, double
 
 // Worker thread of one replica: waits for a slice, evaluates it on its device, reports the status.
 static void worker_main(cf_handle* replica, cf_worker* w) {
+  (void)hipSetDevice(replica->device);  // this thread's device for its whole life: the evaluations' DeviceScope then has nothing to do
   std::unique_lock<std::mutex> lk(w->m);
   for (;;) {
     w->cv.wait(lk, [&] { return w->has_job || w->quit; });
@@ -1011,7 +1033,6 @@ extern "C" int cf_create(const cf_desc* c, cf_handle** out) {
     cf_worker* w = primary->workers.back().get();
     w->th = std::thread(worker_main, r, w);
   }
-  (void)hipSetDevice(devs[0]);
   *out = primary;
   return CF_OK;
 }
@@ -1027,7 +1048,7 @@ extern "C" void cf_destroy(cf_handle* h) {
     if (w->th.joinable()) w->th.join();
   }
   for (cf_handle* r : h->peers) cf_destroy(r);
-  (void)hipSetDevice(h->device);
+  DeviceScope on_device(h->device);
   (void)hipDeviceSynchronize();  // evaluations launched on callers' streams may still use the workspace
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
@@ -1054,7 +1075,8 @@ extern "C" int cf_get_info(cf_handle* h, cf_info* info) {
   for (size_t k = 0; k < h->peers.size() && k + 1 < 16; ++k) info->devices[k + 1] = h->peers[k]->device;
   snprintf(info->gcn_arch, sizeof(info->gcn_arch), "%s", h->arch);
   unsigned long long nf = 0;
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceScope on_device(h->device);
+  HIP_TRY(on_device.err);
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(&nf, h->nonfinite.p, 8, hipMemcpyDeviceToHost));
   info->nonfinite_count = (int64_t)nf;
@@ -1065,7 +1087,8 @@ extern "C" int cf_enable_timing(cf_handle* h, int slots) {
   if (!h) return fail(CF_ERR_INVALID, "cf_enable_timing: null handle");
   if (slots < 0 || slots > 4096) return fail(CF_ERR_INVALID, "cf_enable_timing: slots must be in 0..4096");
   std::lock_guard<std::mutex> lk(h->mu);
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceScope on_device(h->device);
+  HIP_TRY(on_device.err);
   while ((int)h->ev.size() < 4 * slots) {
     hipEvent_t e;
     HIP_TRY(hipEventCreate(&e));
@@ -1402,7 +1425,8 @@ extern "C" int cf_eval_device(cf_handle* h, const double* d_theta, int64_t W, do
     return fail(CF_ERR_INVALID, "cf_eval_device: this handle spans several devices; device-resident evaluation needs one handle per device");
   if (W == 0) return CF_OK;
   std::lock_guard<std::mutex> lk(h->mu);
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceScope on_device(h->device);
+  HIP_TRY(on_device.err);
   if ((rc = ensure_workspace(h, W))) return rc;
   // exactly the caller's stream; NULL is HIP's default (null) stream, which is what torch reports as 0
   return launch_path(h, d_theta, W, d_out, out_kind, (hipStream_t)hip_stream, nullptr, nullptr, nullptr, nullptr);
@@ -1471,7 +1495,8 @@ static bool wait_done_flags(cf_handle* h) {
 static int eval_host_single(cf_handle* h, const double* theta, int64_t W, double* out, int out_kind, bool worker_thread) {
   int rc;
   std::lock_guard<std::mutex> lk(h->mu);
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceScope on_device(h->device);
+  HIP_TRY(on_device.err);
   if ((rc = ensure_workspace(h, W))) return rc;
   memcpy(h->stage_in.p, theta, (size_t)W * h->d.ndim * 8);
   // Small batches are latency-bound: the kernels then read theta from, and write the results to, the pinned (device-visible,
@@ -1544,7 +1569,6 @@ extern "C" int cf_eval(cf_handle* h, const double* theta, int64_t W, double* out
       err = w->err;
     }
   }
-  (void)hipSetDevice(h->device);
   return rc ? fail(rc, err) : CF_OK;
 }
 
@@ -1556,7 +1580,8 @@ extern "C" int cf_eval_parts(cf_handle* h, const double* theta, int64_t W, doubl
   if (fs8_theory && h->d.n_fs8 == 0) return fail(CF_ERR_INVALID, "cf_eval_parts: this likelihood has no growth-rate block");
   if ((dm_obs || mu_corr || delta) && h->d.n_sn == 0) return fail(CF_ERR_INVALID, "cf_eval_parts: this likelihood has no SN block");
   std::lock_guard<std::mutex> lk(h->mu);
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceScope on_device(h->device);
+  HIP_TRY(on_device.err);
   int rc;
   if ((rc = ensure_workspace(h, W))) return rc;
   const int64_t n = h->d.n_sn, n_ld = h->d.n_ld, nb = h->d.n_bao, nf = h->d.n_fs8;
@@ -1609,7 +1634,8 @@ extern "C" int cf_eval_table(cf_handle* h, const double* theta, int64_t W, doubl
   if (!h || !theta || !cum_dm || !dh) return fail(CF_ERR_INVALID, "cf_eval_table: null argument");
   if (W <= 0 || W > 4096) return fail(CF_ERR_INVALID, "cf_eval_table: W must be in 1..4096");
   std::lock_guard<std::mutex> lk(h->mu);
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceScope on_device(h->device);
+  HIP_TRY(on_device.err);
   int rc;
   if ((rc = ensure_workspace(h, W))) return rc;
   if ((rc = order_behind_last(h, h->stream))) return rc;
@@ -1646,7 +1672,8 @@ extern "C" int cf_eval_fs8_at(cf_handle* h, const double* theta, const double* z
       return fail(CF_ERR_INVALID, "cf_eval_fs8_at: redshifts must lie in a_init <= a <= 1");
   if (n == 0) return CF_OK;
   std::lock_guard<std::mutex> lk(h->mu);
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceScope on_device(h->device);
+  HIP_TRY(on_device.err);
   int rc;
   if ((rc = ensure_workspace(h, 1))) return rc;
   if ((rc = order_behind_last(h, h->stream))) return rc;
@@ -1698,7 +1725,8 @@ extern "C" int cf_eval_hz(cf_handle* h, const double* theta, const double* z, in
   if (n < 0) return fail(CF_ERR_INVALID, "cf_eval_hz: n must be >= 0");
   if (n == 0) return CF_OK;
   std::lock_guard<std::mutex> lk(h->mu);
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceScope on_device(h->device);
+  HIP_TRY(on_device.err);
   int rc;
   if ((rc = ensure_workspace(h, 1))) return rc;
   if ((rc = order_behind_last(h, h->stream))) return rc;
@@ -1723,7 +1751,8 @@ extern "C" int cf_eval_bao_at(cf_handle* h, const double* theta, const double* z
   }
   if (n == 0) return CF_OK;
   std::lock_guard<std::mutex> lk(h->mu);
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceScope on_device(h->device);
+  HIP_TRY(on_device.err);
   int rc;
   if ((rc = ensure_workspace(h, 1))) return rc;
   if ((rc = order_behind_last(h, h->stream))) return rc;

@@ -299,33 +299,53 @@ __device__ __forceinline__ double hermite_tab(const TAB& T, double xi) {
   return h00 * e0.x + h10 * h_i * e0.y + h01 * e1.x + h11 * h_i * e1.y;
 }
 
+// v_fma_f64 with its addend / one factor in a scalar register pair.  Written out because the compiler turns fma(p, r, C) with a loop-
+// invariant C into a 64-bit register copy + the two-address v_fmac (one more issue slot per term of every polynomial of the SN loop).
+__device__ __forceinline__ double fma_vvs(double a, double b, double c_uniform) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_uniform));
+  return r;
+}
+__device__ __forceinline__ double fma_vvv(double a, double b, double c) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ double fma_vsv(double a, double b_uniform, double c) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+  return r;
+}
+
 // The same interpolant for the production SN loop.  The interval comes from one truncation, without restoring
 // x[i] < xi <= x[i+1] at the ulp level: at a node both neighbouring cubics give the node value (C1 interpolant), so
 // an xi within rounding of a node may use either; t = xi/step - i instead of (xi - x_i)/h_i and h = step also in
 // the last interval (z_max vs (G-1)*step: a rounding apart) move the result by ~1e-14 relative, far inside the
 // 1e-10 bar (tests/test_gpu_parity.py).  With the cubic in Horner form ~55 instructions fewer per supernova than
-// hermite_tab.
+// hermite_tab.  Node i + 1 is read from the slot behind node i: the table builders put a copy of each chunk's first
+// node into the spare slot behind the previous chunk.
 __device__ __forceinline__ double hermite_fast(const DistTable& T, double xi) {
   const int G = T.G;
+  if (__builtin_expect(xi > 0.0 && xi < T.z_max, 1)) {
+    const double u = xi * T.inv_step;
+    int i = (int)u;
+    i = i > G - 2 ? G - 2 : i;
+    const double t = u - (double)i;
+    const d2* p = T.tab + (i + (i >> T.chs));
+    const d2 e0 = p[0], e1 = p[1];
+    // the same cubic in powers of t: y0 + t (h m0 + t (c + t d)), c = 3 dy - h (2 m0 + m1), d = h (m0 + m1) - 2 dy
+    const double b = T.step * e0.y, hm1 = T.step * e1.y, dy = e1.x - e0.x;
+    const double sm = b + hm1;
+    const double dd = fma(-2.0, dy, sm);
+    const double cc = fma(3.0, dy, -(sm + b));
+    return fma(t, fma(t, fma(t, dd, cc), b), e0.x);
+  }
   if (xi <= 0.0) {
     const d2 e = T.at(0);
     return e.x + e.y * xi;
   }
-  if (xi >= T.z_max) {
-    const d2 e = T.at(G - 1);
-    return e.x + e.y * (xi - T.z_max);
-  }
-  const double u = xi * T.inv_step;
-  int i = (int)u;
-  i = i > G - 2 ? G - 2 : i;
-  const double t = u - (double)i;
-  const d2 e0 = T.at(i), e1 = T.at(i + 1);
-  // the same cubic in powers of t: y0 + t (h m0 + t (c + t d)), c = 3 dy - h (2 m0 + m1), d = h (m0 + m1) - 2 dy
-  const double b = T.step * e0.y, hm1 = T.step * e1.y, dy = e1.x - e0.x;
-  const double sm = b + hm1;
-  const double dd = fma(-2.0, dy, sm);
-  const double cc = fma(3.0, dy, -(sm + b));
-  return fma(t, fma(t, fma(t, dd, cc), b), e0.x);
+  const d2 e = T.at(G - 1);  // xi >= z_max, or NaN (which the sum keeps)
+  return e.x + e.y * (xi - T.z_max);
 }
 
 // log10 for positive, finite, normal arguments (distances in Mpc): the fdlibm / msun algorithm
@@ -386,15 +406,15 @@ __device__ __forceinline__ double log10_tab(double x, const d2* __restrict__ tab
   const double m = __builtin_amdgcn_frexp_mant(x);
   const d2 t = tab[(__double2hiint(m) >> 14) & 63];
   const double r = fma(m, t.x, -1.0);
-  double p = fma(C8, r, C7);
-  p = fma(p, r, C6);
-  p = fma(p, r, C5);
-  p = fma(p, r, C4);
-  p = fma(p, r, C3);
-  p = fma(p, r, C2);
-  p = fma(p, r, C1);
+  double p = fma_vsv(r, C8, C7);
+  p = fma_vvs(p, r, C6);
+  p = fma_vvs(p, r, C5);
+  p = fma_vvs(p, r, C4);
+  p = fma_vvs(p, r, C3);
+  p = fma_vvs(p, r, C2);
+  p = fma_vvs(p, r, C1);
   const double ek = (double)e;
-  return fma(ek, log10_2hi, t.y) + fma(r, p, ek * log10_2lo);
+  return fma_vsv(ek, log10_2hi, t.y) + fma(r, p, ek * log10_2lo);
 }
 
 // Inclusive scan across the 64 lanes of a wave on DPP row operations (no LDS round trips, unlike
@@ -499,7 +519,7 @@ __device__ __forceinline__ double chunk_eval(const D& d, const WalkerCosmo& wc, 
 #pragma unroll
   for (int k = 0; k < CH; ++k) {
     const bool counts = (k > 0 || lane > 0) && (!LAST || g0 + k < G);
-    run = counts ? fma(prev + dh[k], half, run) : run;
+    run = counts ? fma_vsv(prev + dh[k], half, run) : run;  // three-address: loc[k - 1] stays where it is
     loc[k] = run;
     prev = dh[k];
   }
@@ -546,6 +566,7 @@ __device__ __forceinline__ void build_distance_table_regs(const D& d, const Walk
 #pragma unroll
   for (int k = 0; k < CH; ++k)
     if (g0 + k < G) tab[base + k] = (d2){loc[k] + carry, dh[k]};
+  if (tid > 0 && g0 < G) tab[base - 1] = (d2){loc[0] + carry, dh[0]};  // hermite_fast reads node i + 1 behind node i
   __syncthreads();
 }
 
@@ -581,6 +602,7 @@ __device__ __forceinline__ void build_distance_table_lds(const cf_dev_desc& d, c
   double carry = incl - run;
   for (int w = 0; w < wave; ++w) carry += wave_tot[w];
   for (int k = 0; k < n_own; ++k) tab[base + k].x += carry;
+  if (tid > 0 && n_own > 0) tab[base - 1] = tab[base];  // hermite_fast reads node i + 1 behind node i
   __syncthreads();
 }
 
@@ -683,10 +705,12 @@ __device__ __forceinline__ void sn_fast_loop(const D& d, const DistTable& T, con
   // part / n_parts: a small batch spreads a walker's SNe over n_parts workgroups (walker_fast_kernel): this one takes the SNe
   // part * CF_TPB_A + tid, then every n_parts * CF_TPB_A-th
   const int n_sn = d.n_sn, first = part * CF_TPB_A + tid, stride = n_parts * CF_TPB_A;
-  double r_pos = 1.0, r_neg = 1.0;
+  // PM1: z_cosmo = fma(za, r, c0) -- {r, c0} = {1 / (1 + z_pec), -1} on 1 + z_cmb with a velocity step, {1, 0} on z_cmb (exact) without
+  double r_pos = 1.0, r_neg = 1.0, c0 = 0.0;
   if (PM1 && d.has_vstep) {
     r_pos = 1.0 / (1.0 + v100 / d.c);
     r_neg = 1.0 / (1.0 + (-v100) / d.c);
+    c0 = -1.0;
   }
   // {has_vstep ? 1 + z_cmb : z_cmb, step, 1 + z_hel, obs}: the two sums are the reference's own first operations
   const d4* __restrict__ rec = reinterpret_cast<const d4*>(d.sn_rec) + first;
@@ -695,16 +719,14 @@ __device__ __forceinline__ void sn_fast_loop(const D& d, const DistTable& T, con
   auto one_sn = [&](const d4& r, int i) {
     const double za = r[0], st = r[1], zhp1 = r[2], ob = r[3];
     double z_cosmo = za;
-    if (!LIN && d.has_vstep) {
-      if (PM1) {
-        z_cosmo = -1.0 + za * (st > 0.0 ? r_pos : r_neg);
-      } else {  // general weights (dipole fits): sn/pantheon.py:43-48 as written
-        const double z_pec = (v100 * st) / d.c;
-        z_cosmo = -1.0 + za / (1.0 + z_pec);
-      }
+    if (!LIN && PM1) {
+      z_cosmo = fma(za, st > 0.0 ? r_pos : r_neg, c0);
+    } else if (!LIN && d.has_vstep) {  // general weights (dipole fits): sn/pantheon.py:43-48 as written
+      const double z_pec = (v100 * st) / d.c;
+      z_cosmo = -1.0 + za / (1.0 + z_pec);
     }
     const double off_i = LIN ? off + lin * st : off;
-    out[delta_index<FRAG>(i)] = ob - off_i - (25.0 + 5 * log10_tab(zhp1 * hermite_fast(T, z_cosmo), log_tab));
+    out[delta_index<FRAG>(i)] = ob - off_i - fma_vsv(log10_tab(zhp1 * hermite_fast(T, z_cosmo), log_tab), 5.0, 25.0);
   };
   // two records in flight, ping-pong (no register copies); the record array carries CF_SN_REC_SLACK spare entries past n_ld.
   // (A variant with three branch-free evaluations per iteration -- selects instead of the extrapolation / range guards, so

@@ -31,6 +31,11 @@
  *
  * Threading: one caller per handle at a time (the reference callers are single-threaded per
  * process). Different handles may be used from different threads.
+ *
+ * Current device: a handle lives on the device(s) named at cf_create; every function taking a handle
+ * switches the calling thread to that device for its own HIP calls and restores the thread's previous
+ * current device before it returns. The cf_ens_* functions take device pointers and a stream and launch
+ * on the calling thread's current device, which must be the one those belong to.
  */
 #ifndef COSMOFIT_H
 #define COSMOFIT_H
