@@ -189,9 +189,18 @@ def test_config2_random_small_batches_soak(config2):
     rng = np.random.default_rng(11)
     sizes = np.concatenate([rng.integers(1, 200, 2700), rng.integers(200, 3000, 300)])
     rng.shuffle(sizes)
+    prev = (0, 0)
     for W in sizes:
         o = int(rng.integers(0, len(theta) - W + 1))
-        np.testing.assert_array_equal(lk.log_probs_vectorized(theta[o:o + W]), full[o:o + W], err_msg=f"W={W} offset={o}")
+        got = lk.log_probs_vectorized(theta[o:o + W])
+        if not np.array_equal(got, full[o:o + W]):  # whose results are the wrong ones? another walker's = stale theta / table / results
+            j = int(np.flatnonzero(got != full[o:o + W])[0])
+            owners = np.flatnonzero(full == got[j]).tolist()
+            again = np.array_equal(lk.log_probs_vectorized(theta[o:o + W]), full[o:o + W])
+            pytest.fail(f"W={W} offset={o}: {int((got != full[o:o + W]).sum())} of {W} wrong, first at row {j}: {got[j]!r} instead of "
+                        f"{full[o + j]!r}; that value is walker {owners}'s; previous call W={prev[0]} offset={prev[1]}; the same call again is "
+                        f"{'right' if again else 'wrong again'}")
+        prev = (int(W), o)
 
 
 @pytest.mark.parametrize("W", [8192, 65536])

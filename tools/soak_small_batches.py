@@ -35,6 +35,7 @@ calls = int(os.environ.get("CALLS", "6000"))
 sizes = np.concatenate([rng.integers(1, 200, calls - calls // 10), rng.integers(200, 3000, calls // 10)])
 rng.shuffle(sizes)
 bad = 0
+prev = (0, 0)
 t0 = time.perf_counter()
 for i, W in enumerate(sizes):
     o = int(rng.integers(0, 4096 - W + 1))
@@ -42,9 +43,12 @@ for i, W in enumerate(sizes):
     if not np.array_equal(got, ref[o:o + W]):
         bad += 1
         j = int(np.flatnonzero(got != ref[o:o + W])[0])
-        print(f"MISMATCH call {i}: W={W} offset={o} first at {j}: {got[j]!r} vs {ref[o + j]!r}", flush=True)
+        elsewhere = np.flatnonzero(ref == got[j])  # a result that belongs to ANOTHER walker says: stale theta / stale table, not arithmetic
+        print(f"MISMATCH call {i}: W={W} offset={o} first at {j} ({int((got != ref[o:o + W]).sum())} of {W} wrong): {got[j]!r} vs {ref[o + j]!r}; "
+              f"that value is walker {elsewhere.tolist()}'s; previous call: W={prev[0]} offset={prev[1]}", flush=True)
         if bad > 5:
             break
+    prev = (int(W), o)
 print(f"{wl}: {len(sizes)} calls, sizes 1..{int(sizes.max())}, {bad} mismatches, {time.perf_counter() - t0:.1f} s")
 lk.engine.close()
 sys.exit(1 if bad else 0)
