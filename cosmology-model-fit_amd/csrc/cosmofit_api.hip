@@ -936,6 +936,18 @@ static int create_one(const cf_desc* c, int device, HostPrep& prep, cf_handle** 
       d.exp2_tab = h->exp2_tab.as<const double>();
     }
   }
+  if (c->cmb_mode != CF_CMB_NONE && (c->fde == CF_FDE_WCDM || c->fde == CF_FDE_CPL)) {
+    // the dark-energy factor at the Gauss-Legendre nodes of the CMB distances goes through exp_tab / log10_tab (H_at_gl_node)
+    int rc;
+    if (!d.exp2_tab) {
+      if ((rc = upload_exp2_table(h->exp2_tab))) return bail(rc);
+      d.exp2_tab = h->exp2_tab.as<const double>();
+    }
+    if (!d.log10_tab) {
+      if ((rc = upload_log10_table(h->log10_tab))) return bail(rc);
+      d.log10_tab = h->log10_tab.p;
+    }
+  }
   if (c->n_cc > 0) {
     int rc;
     if ((rc = upload_vec(h->cc_z, c->cc_z, c->n_cc))) return bail(rc);

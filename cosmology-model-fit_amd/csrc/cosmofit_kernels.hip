@@ -218,6 +218,27 @@ __device__ __forceinline__ double rsqrt_pos(double x) {
   return fma(y0 * e, fma(e, 0.375, 0.5), y0);
 }
 
+// sqrt and quotient for positive, finite, normal operands whose results are normal too (densities, 1 + z, E^2 at the Gauss-Legendre
+// nodes of the CMB distances): the library routines' own sequences -- v_rsq + one Goldschmidt step + two corrections; v_rcp + two
+// Newton steps + the residual step of v_div_fmas -- without their exponent scaling and class selects, which is what such operands
+// never take: the SAME BITS as sqrt() and a / b there, 10 instead of 19 and 8 instead of 12 instructions.
+__device__ __forceinline__ double sqrt_pos(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  g = fma(fma(-g, g, x), h, g);
+  return fma(fma(-g, g, x), h, g);
+}
+__device__ __forceinline__ double div_pos(double a, double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  r = fma(fma(-b, r, 1.0), r, r);
+  r = fma(fma(-b, r, 1.0), r, r);
+  const double q = a * r;
+  return fma(fma(-b, q, a), r, q);
+}
+
 // Grid node i of np.linspace(0, z_max, G): i*step, last node forced to z_max (sn/pantheon.py:16).
 __device__ __forceinline__ double grid_z(int i, int G, double step, double z_max) {
   return i == G - 1 ? z_max : (double)i * step;
@@ -926,6 +947,43 @@ walker_fast_kernel(cf_walker_args d, const double* __restrict__ theta, int64_t W
   }
 }
 
+// H(z) at a Gauss-Legendre node of the compressed-CMB distances (small_blocks_kernel evaluates it 2 n_gl times per walker: this is
+// where that kernel's instructions go, and it is bound by the instructions it issues -- profiles/NOTES_r04.md).  E^2 as e2_of_z
+// writes it, with sqrt_pos / div_pos (the library's bits) and, for the power-law dark-energy forms, ONE table-driven exp of
+// a ln(1 + z) + b with ln through the table-driven log10 (both tables in LDS): 3 (1 + w0 + wa) <= 12 times the logarithm's
+// <= 3e-16 max(1, log10(1 + z)) leaves the density ratio within ~4e-14 of the library's exp(a log(1 + z) + b) where 1 + z ~ 1e7
+// and the term is negligible, within 1e-15 at z < 10 where it is not.
+template <int MODEL, int FDE>
+__device__ __forceinline__ double H_at_gl_node(const cf_dev_desc& d, const WalkerCosmo& wc, double z, const double* __restrict__ etab,
+                                               const d2* __restrict__ ltab) {
+  const double zp1 = 1.0 + z;
+  const double cubed = zp1 * zp1 * zp1;
+  double f = 1.0;
+  if (FDE == CF_FDE_WCDM_D) {
+    f = exp_tab((3 * (1 + wc.w0)) * (log10_tab(zp1, ltab) * 2.30258509299404568402), etab);
+  } else if (FDE == CF_FDE_CPL_D) {
+    f = exp_tab(fma(3 * (1 + wc.w0 + wc.wa), log10_tab(zp1, ltab) * 2.30258509299404568402, div_pos(-3 * wc.wa * z, zp1)), etab);
+  } else if (FDE == CF_FDE_THAWING_D) {
+    const double r = div_pos(2 * cubed, (1.0 + wc.w0) + (1.0 - wc.w0) * cubed);
+    f = r * r;
+  }
+  double e2;
+  if (MODEL == CF_EZ_LATE_FLAT_D) {
+    e2 = (FDE == CF_FDE_LCDM_D) ? wc.Om * cubed + (1.0 - wc.Om) : wc.Om * cubed + (1.0 - wc.Om) * f;
+  } else {
+    const double de = (FDE == CF_FDE_LCDM_D) ? wc.Ode : wc.Ode * f;
+    // omnu_z with the positive-operand sqrt / quotient   cmb/data_planck_act_compression.py:53-66
+    const double r = div_pos(d.nu_m0, zp1), mz_sq = r * r;
+    const double ws = sqrt_pos(d.nu_qs_sq[0] + mz_sq) * d.nu_ws[0] + sqrt_pos(d.nu_qs_sq[1] + mz_sq) * d.nu_ws[1] +
+                      sqrt_pos(d.nu_qs_sq[2] + mz_sq) * d.nu_ws[2] + sqrt_pos(d.nu_qs_sq[3] + mz_sq) * d.nu_ws[3] +
+                      sqrt_pos(d.nu_qs_sq[4] + mz_sq) * d.nu_ws[4];
+    const double zp1_2 = zp1 * zp1;
+    const double nu = div_pos(zp1_2 * zp1_2 * ws, d.nu_rho0);
+    e2 = wc.Or * (cubed * zp1) + wc.Obc * cubed + de + wc.Onu * nu;  // bao/desi_cmb_des5y.py:43-48
+  }
+  return wc.H0 * sqrt_pos(e2);
+}
+
 // ------------------------------------------------------------------------------------------------
 // The small blocks of the joint likelihoods -- z* / r_drag fitting formulae, compressed CMB (2 x n_gl
 // Gauss-Legendre nodes), cosmic chronometers, BAO -- after walker_kernel, SIXTEEN LANES per walker (four walkers
@@ -996,8 +1054,17 @@ __device__ __forceinline__ double group_quadratic_form(const double* __restrict_
   const int iters = (n + LANES - 1) / LANES;
   for (int it = 0; it < iters; ++it) {
     const int j = sl + it * LANES, jc = j < n ? j : n - 1;
+    // eight entries of the column in flight at a time (one load + one add per iteration waited a memory round trip each: the kernel
+    // spent half its life in s_waitcnt, profiles/NOTES_r04.md); the additions keep their order
     double t = 0.0;
-    for (int i = 0; i < n; ++i) t += dl[i] * inv_cov[i * n + jc];
+    for (int i0 = 0; i0 < n; i0 += 8) {
+      double c[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) c[k] = inv_cov[(i0 + k < n ? i0 + k : n - 1) * n + jc];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (i0 + k < n) t += dl[i0 + k] * c[k];
+    }
     acc.push(j < n ? t * dl[jc] : 0.0);
   }
   return acc.total(iters);
@@ -1019,6 +1086,22 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
   constexpr int WALKERS_PER_WG = 256 / (LANES * ROLES);
   __shared__ double delta_s[WALKERS_PER_WG][CF_MAX_BAO > CF_MAX_CC ? CF_MAX_BAO : CF_MAX_CC];
   __shared__ double xch[WALKERS_PER_WG][4];  // SPLIT: {r_d from wave A; chi2_bao, chi2_cc from wave B}
+  // reduction tables of exp_tab / log10_tab for the dark-energy factor at the Gauss-Legendre nodes (H_at_gl_node); cf_create uploads
+  // them whenever a compressed-CMB block meets a power-law dark energy
+  constexpr bool POWER_LAW = FDE == CF_FDE_WCDM_D || FDE == CF_FDE_CPL_D;
+  __shared__ double exp2_s[POWER_LAW ? 64 : 1];
+  __shared__ __align__(16) d2 log_s[POWER_LAW ? 64 : 1];
+  // ... and the Gauss-Legendre nodes and weights: fetched by the loop they were two loads per iteration, each waited for on the spot
+  static_assert(CF_MAX_GL <= 256, "one Gauss-Legendre node per thread of the workgroup");
+  __shared__ __align__(16) d2 gl_s[CF_MAX_GL];  // {x, w}
+  if (d.cmb_mode) {
+    if (threadIdx.x < d.n_gl) gl_s[threadIdx.x] = (d2){d.gl_x[threadIdx.x], d.gl_w[threadIdx.x]};  // n_gl <= CF_MAX_GL = the workgroup's 256 threads
+    if (POWER_LAW) {
+      if (threadIdx.x >= 128 && threadIdx.x < 192) exp2_s[threadIdx.x - 128] = d.exp2_tab[threadIdx.x - 128];
+      else if (threadIdx.x >= 192) log_s[threadIdx.x - 192] = reinterpret_cast<const d2*>(d.log10_tab)[threadIdx.x - 192];
+    }
+    __syncthreads();
+  }
   const int grp = threadIdx.x / (LANES * ROLES), sl = threadIdx.x % LANES;
   const bool do_a = !SPLIT || ((threadIdx.x / LANES) & 1) == 0;  // powers, CMB, output
   const bool do_b = !SPLIT || ((threadIdx.x / LANES) & 1) == 1;  // cosmic chronometers, BAO
@@ -1083,12 +1166,13 @@ small_blocks_kernel(cf_dev_desc d, const double* __restrict__ theta, int64_t W, 
     const int gl_iters = (d.n_gl + LANES - 1) / LANES;  // the same for every lane (VirtualLaneSum); a lane past the last node adds 0
     for (int it = 0; it < gl_iters; ++it) {
       const int k_raw = sl + it * LANES, k = k_raw < d.n_gl ? k_raw : d.n_gl - 1;
-      const double gw = k_raw < d.n_gl ? d.gl_w[k] : 0.0;
-      const double a = half_a * d.gl_x[k] + half_a;
-      const double z = (1.0 / a) - 1.0;
+      const d2 xw = gl_s[k];
+      const double gw = k_raw < d.n_gl ? xw.y : 0.0;
+      const double a = half_a * xw.x + half_a;
+      const double z = div_pos(1.0, a) - 1.0;
       const double Rb = (3.0 / 4.0) * (Ob / d.o_gamma_h2) * a;
-      s_rs.push(gw * (d.c / (a * a * H_of_z<MODEL, FDE>(d, wc, z) * sqrt(3.0 * (1.0 + Rb)))));
-      s_dm.push(gw * (d.c / H_of_z<MODEL, FDE>(d, wc, half_z * d.gl_x[k] + half_z)));
+      s_rs.push(gw * div_pos(d.c, a * a * H_at_gl_node<MODEL, FDE>(d, wc, z, exp2_s, log_s) * sqrt_pos(3.0 * (1.0 + Rb))));
+      s_dm.push(gw * div_pos(d.c, H_at_gl_node<MODEL, FDE>(d, wc, half_z * xw.x + half_z, exp2_s, log_s)));
     }
     const double i_rs = s_rs.total(gl_iters), i_dm = s_dm.total(gl_iters);
     const double rs_star = half_a * i_rs;

@@ -8,7 +8,7 @@ for f in sorted(glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 lines = []
 for k, cs in acc.items():
-    if not ("trsm" in k or "tri_gemm" in k or "walker" in k):
+    if not ("trsm" in k or "tri_gemm" in k or "walker" in k or "small_blocks" in k):
         continue
     lines.append(f"== {k[:60]}  (dispatches: {max(len(v) for v in cs.values())})")
     for c, v in sorted(cs.items()):
