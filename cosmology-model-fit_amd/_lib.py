@@ -123,6 +123,7 @@ EXPORTS = {
     "cf_selftest_log10": (C.c_int, [_VP, _I64, _VP]),
     "cf_selftest_log10_tab": (C.c_int, [_VP, _I64, _VP]),
     "cf_selftest_exp_tab": (C.c_int, [_VP, _I64, _VP]),
+    "cf_selftest_pos_ops": (C.c_int, [_VP, _VP, _I64, _VP]),
     "cf_ens_active_count": (_I64, [C.c_uint64, _I32, _I32, _I64, _I64]),
     "cf_ens_comp_count": (_I64, [C.c_uint64, _I32, _I32, _I64]),
     "cf_ens_active_set": (C.c_int, [C.c_uint64, _I32, _I32, _I64, _I64, _VP, _VP, _VP]),

@@ -189,6 +189,7 @@ extern "C" __global__ void finalize_kernel(cf_epilogue d, const double* theta, i
 extern "C" __global__ void interp_kernel(const double* xq, int64_t nq, const double* x, const double* y,
                                          const double* yp, int64_t n, double* out, int mode);
 extern "C" __global__ void log10_selftest_kernel(const double* x, int64_t n, double* out, int mode, const cf_d2* tab);
+extern "C" __global__ void pos_ops_selftest_kernel(const double* a, const double* b, int64_t n, double* out);
 extern "C" __global__ void pad_rhs_kernel(const double* b, int64_t nrhs, int64_t n, int64_t n_ld, double* delta);
 
 // ------------------------------------------------------------------------------------------------
@@ -1911,6 +1912,20 @@ extern "C" int cf_selftest_log10_tab(const double* x, int64_t n, double* out) {
 }
 extern "C" int cf_selftest_exp_tab(const double* x, int64_t n, double* out) {
   return selftest_log10(x, n, out, 2, "cf_selftest_exp_tab");
+}
+extern "C" int cf_selftest_pos_ops(const double* a, const double* b, int64_t n, double* out) {
+  if (!a || !b || !out || n < 0) return fail(CF_ERR_INVALID, "cf_selftest_pos_ops: bad argument");
+  if (cf_device_count() == 0) return fail(CF_ERR_NO_DEVICE, "cf_selftest_pos_ops: no HIP device visible");
+  if (n == 0) return CF_OK;
+  DevBuf da, db, dout;
+  if (da.ensure((size_t)n * 8) || db.ensure((size_t)n * 8) || dout.ensure((size_t)n * 32)) return CF_ERR_HIP;
+  HIP_TRY(hipMemcpy(da.p, a, (size_t)n * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(db.p, b, (size_t)n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(pos_ops_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, da.as<const double>(),
+                     db.as<const double>(), n, dout.as<double>());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * 32, hipMemcpyDeviceToHost));
+  return CF_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

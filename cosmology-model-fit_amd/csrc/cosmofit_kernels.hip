@@ -2588,6 +2588,17 @@ extern "C" __global__ void interp_kernel(const double* __restrict__ xq, int64_t 
 }
 
 // Self-test hook: the in-kernel log10 on arbitrary inputs (tests/test_gpu_parity.py checks its ulp error).
+// out[4 k .. 4 k + 3] = {sqrt_pos(a), sqrt(a), div_pos(a, b), a / b}: the positive-operand routines beside the library's (cf_selftest_pos_ops)
+extern "C" __global__ void pos_ops_selftest_kernel(const double* __restrict__ a, const double* __restrict__ b, int64_t n,
+                                                   double* __restrict__ out) {
+  const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  out[4 * k + 0] = sqrt_pos(a[k]);
+  out[4 * k + 1] = sqrt(a[k]);
+  out[4 * k + 2] = div_pos(a[k], b[k]);
+  out[4 * k + 3] = a[k] / b[k];
+}
+
 // mode 0: log10_pos; mode 1: log10_tab with the table at `tab`; mode 2: exp_tab with the 2^(j/64) table at `tab`
 extern "C" __global__ void log10_selftest_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ out, int mode,
                                                  const cf_d2* __restrict__ tab) {

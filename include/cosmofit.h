@@ -421,6 +421,10 @@ int cf_selftest_log10(const double* x, int64_t n, double* out);
 int cf_selftest_log10_tab(const double* x, int64_t n, double* out);
 /* The table-driven exp of the wCDM / CPL table build (|x| < ~700, no special cases): out[k] = exp(x[k]), <= 1.5 ulp. */
 int cf_selftest_exp_tab(const double* x, int64_t n, double* out);
+/* sqrt / quotient of the compressed-CMB Gauss-Legendre nodes (positive, finite, normal operands: the library routines' instruction
+ * sequences without their exponent scaling and class selects): out[4 k .. 4 k + 3] = {sqrt_pos(a[k]), the library's sqrt(a[k]),
+ * div_pos(a[k], b[k]), the library's a[k] / b[k]}, all on the device -- the pairs must be the same bits. */
+int cf_selftest_pos_ops(const double* a, const double* b, int64_t n, double* out);
 
 /* ---- Device-resident ensemble moves (the sampler side of sn/pantheon.py:108-125: emcee with KDEMove 30 % +
  * DEMove 70 %, StretchMove by default elsewhere).  All pointers are device pointers on the current device, all

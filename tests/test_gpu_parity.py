@@ -418,6 +418,24 @@ def test_table_build_exp_is_within_two_ulp(gpu):
     assert out[x == 0.0][0] == 1.0
 
 
+def test_positive_operand_sqrt_and_quotient_are_the_library_bits(gpu):
+    """sqrt_pos / div_pos (H(z) at the Gauss-Legendre nodes of the compressed-CMB distances, small_blocks_kernel): the library
+    routines' instruction sequences without the exponent scaling and class selects that positive, finite, normal operands never take.
+    The claim is THE SAME BITS as sqrt() and a / b on the device -- and, both being correctly rounded there, as numpy's."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    a = np.concatenate([np.exp(rng.uniform(np.log(1e-6), np.log(1e30), 400000)), rng.uniform(0.5, 4.0, 100000),
+                        np.exp(rng.uniform(-230, 230, 100000)), [1.0, 2.0, 4.0, 0.25, 3.0, 1e-200, 1e200]])
+    b = np.concatenate([np.exp(rng.uniform(np.log(1e-6), np.log(1e12), 400000)), rng.uniform(0.5, 4.0, 100000),
+                        np.exp(rng.uniform(-230, 230, 100000)), [3.0, 3.0, 7.0, 0.1, 1.0, 1e-100, 1e-100]])
+    out = np.empty((a.size, 4))
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    gpu._lib.check(gpu.lib().cf_selftest_pos_ops(p(a), p(b), a.size, p(out)))
+    assert np.array_equal(out[:, 0], out[:, 1]), "sqrt_pos differs from the device library's sqrt"
+    assert np.array_equal(out[:, 2], out[:, 3]), "div_pos differs from the device library's quotient"
+    assert np.array_equal(out[:, 1], np.sqrt(a)) and np.array_equal(out[:, 3], a / b)
+
+
 def test_production_loop_log10_absolute_error(gpu):
     """log10_tab (table-driven, production SN loop): what a distance modulus needs is ABSOLUTE accuracy of 5 log10(d)
     at the 1e-15 level on mu ~ 25..45; bound it at 3e-16 max(1, |log10 x|) over the whole double range."""
