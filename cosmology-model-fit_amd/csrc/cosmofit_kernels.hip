@@ -327,11 +327,6 @@ __device__ __forceinline__ double fma_vvs(double a, double b, double c_uniform) 
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_uniform));
   return r;
 }
-__device__ __forceinline__ double fma_vvv(double a, double b, double c) {
-  double r;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
 __device__ __forceinline__ double fma_vsv(double a, double b_uniform, double c) {
   double r;
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
