@@ -203,6 +203,42 @@ def test_config2_random_small_batches_soak(config2):
         prev = (int(W), o)
 
 
+@pytest.mark.parametrize("W", [16, 1000, 4096])
+def test_device_evaluation_is_captured_into_a_graph_and_replayed(gpu, W):
+    """evaluations that stay on one stream are purely asynchronous and may be captured into a hipGraph.  Capture one
+    cf_eval_device of each kernel family (small-batch, throughput) on a torch stream, overwrite theta in place, replay: the replayed
+    result must be the bits of a direct call on the new theta."""
+    torch = pytest.importorskip("torch")
+    syn = gpu.synthetic.pantheon_like(n_sn=1701, seed=0)
+    lk = gpu.sn_pantheon.PantheonLikelihood(syn["z_cmb"], syn["z_hel"], syn["obs"], chol=syn["chol"])
+    try:
+        f = lk.engine.torch_log_prob()
+        dev = torch.device("cuda:0")
+        th_a = torch.from_numpy(gpu.synthetic.walkers(gpu.sn_pantheon.bounds, W, seed=1)).to(dev)
+        th_b = torch.from_numpy(gpu.synthetic.walkers(gpu.sn_pantheon.bounds, W, seed=2)).to(dev)
+        x = th_a.clone()
+        s = torch.cuda.Stream(dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            want_a = f(x).clone()  # the first call on this stream: workspace, stream switch -- neither may happen under capture
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=s):
+                out = f(x)
+            graph.replay()
+            s.synchronize()
+            assert torch.equal(out, want_a)
+            x.copy_(th_b)
+            graph.replay()
+            graph.replay()  # back to back: the arrival counters re-arm themselves
+            s.synchronize()
+            got_b = out.clone()
+            want_b = f(th_b)
+            s.synchronize()
+        assert torch.equal(got_b, want_b) and not torch.equal(want_a, want_b)
+    finally:
+        lk.engine.close()
+
+
 @pytest.mark.parametrize("W", [8192, 65536])
 def test_configs3_shape_per_rank_and_whole_ensemble(config2, W):
     """BASELINE configs[3]: 65536 walkers over 8 GPUs = 8192 per rank.  Both shapes on ONE GPU (the per-rank batch, and the
